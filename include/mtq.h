@@ -1,0 +1,160 @@
+/*
+ * mtq.h — C ABI of libmtq_hip.so, the MI355X (gfx950) backend of the mixed-tile
+ * quantization-format search path.
+ *
+ * The reference (johanna-rock/quantization_analysis) is pure Python and has no FFI; its seam for
+ * this path is the `--backend` selector (wq:57-62) → `Quantizer.quantize` (compression_algorithms/
+ * quantizer.py:13-34) and `CompressionAlgorithm.run` (compression_algorithms/base.py:36-44).  Each
+ * entry point below names the reference code it replaces; INTEGRATION.md shows the ctypes binding a
+ * maintainer of the reference would add.
+ *
+ * Conventions
+ *   - plain C types only; no torch / HIP types in signatures (`stream` is a hipStream_t passed as void*,
+ *     NULL = the default stream).
+ *   - pointers named x / y / stats / map in the DEVICE section are device pointers owned by the caller;
+ *     calls are asynchronous on `stream`.  Pointers in the HOST section are host pointers.
+ *   - every function returns MTQ_OK (0) or a negative mtq_status; mtq_last_error() gives a
+ *     thread-local message.  Nothing throws across the boundary.  There is NO CPU fallback: device
+ *     entry points fail with MTQ_ERR_NO_DEVICE when no gfx950 device is usable.
+ *   - matrices are row-major (rows × cols) with a leading dimension `ld` in ELEMENTS; this is the 2-D
+ *     flatten of compression_algorithms/tile_utils.py:91-107 (a 1-D vector of n elements is passed as
+ *     its zero-filled ceil(n/32) × 32 matrix, an N-D tensor as prod(shape[:-1]) × shape[-1]).
+ *     32×32 tiles are numbered tile = tr * tiles_w + tc (mixed_tile_greedy.py:89-93); elements outside
+ *     rows × cols read as +0.0 (tile_utils.py:109-113).
+ */
+#ifndef MTQ_H
+#define MTQ_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MTQ_VERSION 100 /* 0.1.0 */
+
+typedef enum {
+    MTQ_OK = 0,
+    MTQ_ERR_INVALID = -1,     /* bad argument (shape, dtype, mask, alignment, null pointer) */
+    MTQ_ERR_HIP = -2,         /* a HIP runtime call failed; message carries hipGetErrorString */
+    MTQ_ERR_NO_DEVICE = -3,   /* no usable gfx950 device */
+    MTQ_ERR_UNSUPPORTED = -4  /* recognised but not built (e.g. unknown format code) */
+} mtq_status;
+
+/* input element types */
+enum { MTQ_DTYPE_BF16 = 0, MTQ_DTYPE_F32 = 1 };
+
+/* format codes = index into MIXED_TILE_FORMATS (tile_utils.py:8) = value stored in assignment maps;
+ * FP0 is quantize-only (quantization_formats.py:167-168). */
+enum { MTQ_FMT_BF16 = 0, MTQ_FMT_BFP8 = 1, MTQ_FMT_BFP4 = 2, MTQ_FMT_BFP2 = 3, MTQ_FMT_FP0 = 4 };
+#define MTQ_NUM_TILE_FORMATS 4
+#define MTQ_MASK_ALL 0xFu
+
+/* metrics (compression_algorithms/metrics.py:19-39) */
+enum { MTQ_METRIC_PCC = 0, MTQ_METRIC_MAE = 1, MTQ_METRIC_ATOL = 2 };
+
+/* ------------------------------------------------------------------ library */
+
+int mtq_version(void);
+const char *mtq_last_error(void);
+/* Number of visible HIP devices; MTQ_ERR_NO_DEVICE if the runtime reports none. */
+int mtq_device_count(int *count);
+
+/* ------------------------------------------------------------------ DEVICE: kernels */
+
+/* Doubles per tile record for a format mask: 2 + 5 * popcount(mask & 0xF). */
+size_t mtq_stats_record_doubles(uint32_t fmt_mask);
+
+/*
+ * K1 tile_stats — fused BFP quantize + per-tile reduction; y never leaves registers.
+ * Replaces, per candidate format, quantization_formats.py:84-164 (via quantizer.py:34) plus the
+ * per-tile sums of mixed_tile_greedy.py:147-174,192-220,245-254,288-291,313-318 and is the input of the
+ * per-tile scores of tile_utils.py:46-57.
+ *
+ * stats[tile][0..1] = Σx, Σx²; then for each bit set in fmt_mask (ascending: bf16, bfp8, bfp4, bfp2)
+ * five doubles Σy, Σy², Σxy, Σ|x−y|, max|x−y|.  Every term is the float32 expression the reference
+ * forms (x*x, y*y, x*y, |x−y|) summed in float64; summation order: 16 elements of a shared-exponent
+ * group sequentially, the 64 groups of a tile by a balanced binary tree over (2*row + half).
+ * Sums run over the zero-padded 1024 elements (pads contribute exactly 0).
+ */
+int mtq_tile_stats(const void *x, int in_dtype, int64_t rows, int64_t cols, int64_t ld,
+                   uint32_t fmt_mask, double *stats, void *stream);
+
+/*
+ * Same kernel over `count` equally shaped matrices at x + i*stride_elems (one launch);
+ * stats holds count × tiles × record doubles.  Used for model-sized streams of tensors.
+ */
+int mtq_tile_stats_batched(const void *x, int in_dtype, int64_t count, int64_t stride_elems,
+                           int64_t rows, int64_t cols, int64_t ld,
+                           uint32_t fmt_mask, double *stats, void *stream);
+
+/*
+ * K2 quantize — materialise y = quantize→dequantize(x) for one format as float32.
+ * Replaces quantize_weight_values (quantization_formats.py:171-194) behind Quantizer.quantize
+ * (quantizer.py:34) for fmt in {bf16, bfp8, bfp4, bfp2, fp0}.  Bit-exact, including the
+ * reference's saturating round-up, sign-of-zero, denormal→0 and uint32 wrap-around quirks.
+ */
+int mtq_quantize(const void *x, int in_dtype, int64_t rows, int64_t cols, int64_t ld,
+                 int fmt, float *y, int64_t ldy, void *stream);
+
+/*
+ * K3 apply_assignment — y where each 32×32 tile uses the format its int8 map entry names.
+ * Replaces the tile gather/scatter of mixed_tile_threshold.py:125-132, mixed_tile_greedy.py:273,348-352
+ * and scripts/reconstruct_mixed_tile_assignment.py:82-94.  map is tiles_h × tiles_w, row-major, on device.
+ */
+int mtq_apply_assignment(const void *x, int in_dtype, int64_t rows, int64_t cols, int64_t ld,
+                         const int8_t *map, float *y, int64_t ldy, void *stream);
+
+/* ------------------------------------------------------------------ HOST: decisions on stats records */
+
+/*
+ * H1 greedy scan — the sequential part of mixed_tile_greedy.py:133-346 on HOST copies of the stats.
+ * The visiting order of every pass comes from the caller (numpy's Generator, :222-231), so the
+ * NumPy PCG64 stream stays the caller's.
+ */
+typedef struct mtq_greedy mtq_greedy; /* opaque */
+
+/* elem_count = float(xf.size) (:134).  stats/rec as written by mtq_tile_stats for fmt_mask. */
+int mtq_greedy_create(mtq_greedy **out, const double *stats, int64_t tiles, uint32_t fmt_mask,
+                      int metric, double threshold, double elem_count, int base_fmt);
+/* One `for fmt in tile_formats` iteration (:227-346) over order[0..n). */
+int mtq_greedy_pass(mtq_greedy *g, int fmt, const int64_t *order, int64_t n);
+/* Copies of the scan state: assignment int8[tiles], fixed uint8[tiles], counts int64[4]. */
+int mtq_greedy_assignment(const mtq_greedy *g, int8_t *assign);
+int mtq_greedy_fixed(const mtq_greedy *g, uint8_t *fixed);
+int mtq_greedy_counts(const mtq_greedy *g, int64_t counts[4]);
+/* Current global metric value (pcc_value :176-190, mae :280, atol :305). */
+int mtq_greedy_value(const mtq_greedy *g, double *value);
+void mtq_greedy_destroy(mtq_greedy *g);
+
+/*
+ * Per-tile scores from the raw sums, n = 1024 (tile_utils.py:46-57 semantics on float64 moments):
+ * pcc via the moment formula, mae = Σ|d|/1024, atol = max|d|.  scores is [popcount(mask)][tiles],
+ * formats in ascending mask-bit order.
+ */
+int mtq_tile_scores(const double *stats, int64_t tiles, uint32_t fmt_mask, int metric, double *scores);
+
+/*
+ * K4 threshold_assign — mixed_tile_threshold.py:111-123 / scripts/sweep_mixed_tile_threshold.py:145-155:
+ * per tile the lowest-bytes format among `formats` whose score passes, else the highest-bytes one.
+ * The reference compares float32 scores with a float32-rounded threshold (NumPy ≥ 2, NEP 50);
+ * tiles whose float64 score lies within `band` of float32(threshold) are listed in knife_ids
+ * (capacity knife_cap) so the caller can re-score exactly those with the literal float32 expression.
+ */
+int mtq_threshold_assign(const double *stats, int64_t tiles, uint32_t fmt_mask,
+                         const int *formats, int n_formats, int metric, double threshold, double band,
+                         int8_t *map, int64_t *knife_ids, int64_t knife_cap, int64_t *n_knife);
+
+/*
+ * Tensor-level columns (pcc, mae, atol) of the reconstruction a map implies, from the raw sums in
+ * float64 (replaces wq:683-687 for the hip backend; see DESIGN.md on the float32 column).
+ * out[0..2] = pcc, mae, atol; out[3..8] = Σx, Σx², Σy, Σy², Σxy, Σ|d|.
+ */
+int mtq_columns_from_stats(const double *stats, int64_t tiles, uint32_t fmt_mask, const int8_t *map,
+                           double elem_count, double out[9]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MTQ_H */

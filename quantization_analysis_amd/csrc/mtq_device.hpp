@@ -1,0 +1,109 @@
+// mtq_device.hpp — gfx950 device helpers shared by the kernels: the literal uint32 BFP / bf16
+// quantize→dequantize of one value inside a shared-exponent group (reference:
+// quantization_formats.py:29-45, 71-81, 115-158).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mtq {
+
+constexpr int kTile = 32;    // tile edge (compression_algorithms/tile_utils.py:32)
+constexpr int kGroup = 16;   // shared-exponent group length (quantization_formats.py:115)
+constexpr int kNumFmt = 4;   // bf16, bfp8, bfp4, bfp2 (tile_utils.py:8)
+
+__device__ __forceinline__ constexpr int mant_bits(int fmt) { return fmt == 1 ? 7 : (fmt == 2 ? 3 : 1); }
+
+// quantization_formats.py:29-45: RNE to bf16 on the raw word (uint32 wrap, no NaN special case), widened back.
+__device__ __forceinline__ uint32_t bf16_round_bits(uint32_t u)
+{
+    const uint32_t r = u + (0x7FFFu + ((u >> 16) & 1u));
+    return r & 0xFFFF0000u;
+}
+
+// One element of quantize_dequantize_bfp_ttnn (quantization_formats.py:118-158) given the group's
+// shared (max) biased exponent.  M = mantissa bits kept (7 / 3 / 1).
+template <int M>
+__device__ __forceinline__ uint32_t bfp_elem_bits(uint32_t u, uint32_t shared)
+{
+    constexpr uint32_t shift = 24u - M;
+    constexpr uint32_t round_mask = (1u << shift) - 1u;
+    constexpr uint32_t tie = 1u << (shift - 1u);
+    constexpr uint32_t qmax = (1u << M) - 1u;
+    const uint32_t e = (u >> 23) & 0xFFu;
+    const uint32_t d = shared - e;                       // :126
+    uint32_t man = (1u << 23) | (u & 0x007FFFFFu);      // :121,125
+    man = d > 31u ? 0u : (man >> d);                     // :127-131
+    const uint32_t rv = man & round_mask;                // :136
+    man >>= shift;                                       // :137
+    const uint32_t up = (rv > tie) | ((rv == tie) & (man & 1u)); // :138-139
+    man = min(man + up, qmax);                           // :140-141 (saturating round-up)
+    man = e == 0u ? 0u : man;                            // :145 zero / denormal input → code 0
+    if (man == 0u) return 0u;                            // :143,155: sign cleared, exp_out = 0
+    const uint32_t msb = 31u - (uint32_t)__clz((int)man); // :77
+    const uint32_t sc = (uint32_t)(M - 1) - msb;         // :78
+    const uint32_t ms = (man << (sc + 1u)) & qmax;       // :80
+    const uint32_t exp_out = shared - sc;                // :154 (wraps below sc, kept)
+    return (u & 0x80000000u) | (exp_out << 23) | (ms << (23u - M)); // :158
+}
+
+__device__ __forceinline__ uint32_t quant_elem_bits(int fmt, uint32_t u, uint32_t shared)
+{
+    switch (fmt) {
+    case 0: return bf16_round_bits(u);
+    case 1: return bfp_elem_bits<7>(u, shared);
+    case 2: return bfp_elem_bits<3>(u, shared);
+    case 3: return bfp_elem_bits<1>(u, shared);
+    default: return 0u; // fp0, quantization_formats.py:167-168
+    }
+}
+
+// numpy's max propagates NaN (tile_utils.py:56).
+__device__ __forceinline__ double nanmax(double m, double d) { return (d > m || d != d) ? d : m; }
+
+// Load one 16-element group as raw fp32 words; elements outside the matrix read as +0.0
+// (tile_utils.py:109-113).  `fast` = whole group in bounds and 16-byte aligned.
+template <typename T> struct Loader;
+
+template <> struct Loader<uint16_t> { // bf16 storage
+    static __device__ __forceinline__ void group(const uint16_t *__restrict__ p, int64_t row, int64_t col0,
+                                                  int64_t rows, int64_t cols, int64_t ld, bool vec_ok, uint32_t u[kGroup])
+    {
+        if (row < rows && col0 + kGroup <= cols && vec_ok) {
+            const uint4 *q = reinterpret_cast<const uint4 *>(p + row * ld + col0);
+            const uint4 a = q[0], b = q[1];
+            const uint32_t w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { u[2 * i] = w[i] << 16; u[2 * i + 1] = w[i] & 0xFFFF0000u; }
+        } else {
+#pragma unroll
+            for (int i = 0; i < kGroup; ++i)
+                u[i] = (row < rows && col0 + i < cols) ? ((uint32_t)p[row * ld + col0 + i] << 16) : 0u;
+        }
+    }
+};
+
+template <> struct Loader<float> {
+    static __device__ __forceinline__ void group(const float *__restrict__ p, int64_t row, int64_t col0,
+                                                  int64_t rows, int64_t cols, int64_t ld, bool vec_ok, uint32_t u[kGroup])
+    {
+        if (row < rows && col0 + kGroup <= cols && vec_ok) {
+            const uint4 *q = reinterpret_cast<const uint4 *>(p + row * ld + col0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { const uint4 a = q[i]; u[4 * i] = a.x; u[4 * i + 1] = a.y; u[4 * i + 2] = a.z; u[4 * i + 3] = a.w; }
+        } else {
+#pragma unroll
+            for (int i = 0; i < kGroup; ++i)
+                u[i] = (row < rows && col0 + i < cols) ? __float_as_uint(p[row * ld + col0 + i]) : 0u;
+        }
+    }
+};
+
+__device__ __forceinline__ uint32_t group_shared_exp(const uint32_t u[kGroup])
+{
+    uint32_t m = 0u;
+#pragma unroll
+    for (int i = 0; i < kGroup; ++i) m = max(m, u[i] & 0x7F800000u); // :118-119 (max exponent field)
+    return m >> 23;
+}
+
+} // namespace mtq

@@ -1,0 +1,353 @@
+// mtq_host.cpp — host side of libmtq_hip.so: error state, device probe, and the decision steps that
+// run on HOST copies of the per-tile stats records (include/mtq.h, HOST section): the sequential
+// greedy scan, per-tile scores, threshold assignment and tensor-level columns.
+//
+// Build with -ffp-contract=off: the reference evaluates these formulas as separately rounded
+// Python-float (IEEE double) operations (mixed_tile_greedy.py:176-190).
+#include <hip/hip_runtime_api.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "../../include/mtq.h"
+#include "mtq_error.hpp"
+
+namespace mtq {
+
+static thread_local char g_err[512] = "";
+
+int fail(int code, const char *msg)
+{
+    std::snprintf(g_err, sizeof g_err, "%s", msg);
+    return code;
+}
+
+int failf(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    std::vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+int require_device()
+{
+    static int cached = 1; // 1 = unknown
+    if (cached == 1) {
+        int n = 0;
+        const hipError_t e = hipGetDeviceCount(&n);
+        cached = (e == hipSuccess && n > 0) ? MTQ_OK : MTQ_ERR_NO_DEVICE;
+    }
+    if (cached != MTQ_OK) return fail(MTQ_ERR_NO_DEVICE, "no usable HIP device (libmtq_hip has no CPU fallback)");
+    return MTQ_OK;
+}
+
+int check_launch(const char *what)
+{
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return failf(MTQ_ERR_HIP, "%s: %s", what, hipGetErrorString(e));
+    return MTQ_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+
+static inline int popcount4(uint32_t m) { return __builtin_popcount(m & MTQ_MASK_ALL); }
+
+// slot of format f among the set bits of mask, or -1
+static inline int slot_of(uint32_t mask, int f)
+{
+    if (f < 0 || f >= MTQ_NUM_TILE_FORMATS || !(mask & (1u << f))) return -1;
+    return __builtin_popcount(mask & ((1u << f) - 1u));
+}
+
+static inline double nanmax(double m, double d) { return (d > m || d != d) ? d : m; }
+
+// metrics.py:30-33
+static inline bool is_good(double v, int metric, double thr) { return metric == MTQ_METRIC_PCC ? v >= thr : v <= thr; }
+
+// mixed_tile_greedy.py:176-190; every operation individually rounded, evaluation order as written there.
+static inline double pcc_from_moments(double n, double sx, double sx2, double sy, double sy2, double sxy, double sab)
+{
+    if (n == 0.0) return 1.0;
+    const double mean_x = sx / n;
+    const double mean_y = sy / n;
+    double am2 = sx2 - n * mean_x * mean_x;
+    double bm2 = sy2 - n * mean_y * mean_y;
+    if (am2 < 0.0) am2 = 0.0;
+    if (bm2 < 0.0) bm2 = 0.0;
+    const double denom = std::sqrt(am2 * bm2);
+    if (denom == 0.0) return sab == 0.0 ? 1.0 : 0.0;
+    return (sxy - n * mean_x * mean_y) / denom;
+}
+
+} // namespace mtq
+
+using namespace mtq;
+
+struct mtq_greedy {
+    int64_t T;
+    uint32_t mask;
+    int rec;
+    int metric;
+    double thr, n;
+    const double *stats; // caller-owned, must outlive the handle
+    double sum_x, sum_x2, sum_y, sum_y2, sum_xy, sum_abs;
+    double max_abs;
+    int64_t max_count;
+    std::vector<double> cur; // per tile: sy, sy2, sxy, sab, max of the CURRENT format
+    std::vector<int8_t> assign;
+    std::vector<uint8_t> fixed;
+    int64_t counts[MTQ_NUM_TILE_FORMATS];
+};
+
+extern "C" int mtq_version(void) { return MTQ_VERSION; }
+extern "C" const char *mtq_last_error(void) { return g_err; }
+
+extern "C" int mtq_device_count(int *count)
+{
+    if (!count) return fail(MTQ_ERR_INVALID, "count is null");
+    int n = 0;
+    const hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        *count = 0;
+        return fail(MTQ_ERR_NO_DEVICE, "no usable HIP device");
+    }
+    *count = n;
+    return MTQ_OK;
+}
+
+extern "C" int mtq_greedy_create(mtq_greedy **out, const double *stats, int64_t tiles, uint32_t fmt_mask, int metric,
+                                 double threshold, double elem_count, int base_fmt)
+{
+    if (!out || !stats) return fail(MTQ_ERR_INVALID, "null argument");
+    if (tiles <= 0) return fail(MTQ_ERR_INVALID, "tiles must be positive");
+    if (metric < MTQ_METRIC_PCC || metric > MTQ_METRIC_ATOL) return fail(MTQ_ERR_INVALID, "unknown metric");
+    const int bslot = slot_of(fmt_mask, base_fmt);
+    if (bslot < 0) return fail(MTQ_ERR_INVALID, "base format is not in fmt_mask");
+    mtq_greedy *g = new (std::nothrow) mtq_greedy();
+    if (!g) return fail(MTQ_ERR_INVALID, "out of memory");
+    g->T = tiles;
+    g->mask = fmt_mask & MTQ_MASK_ALL;
+    g->rec = 2 + 5 * popcount4(fmt_mask);
+    g->metric = metric;
+    g->thr = threshold;
+    g->n = elem_count;
+    g->stats = stats;
+    g->cur.resize((size_t)tiles * 5);
+    g->assign.assign((size_t)tiles, (int8_t)base_fmt); // :99
+    g->fixed.assign((size_t)tiles, 0);                 // :100
+    for (int f = 0; f < MTQ_NUM_TILE_FORMATS; ++f) g->counts[f] = 0;
+    g->counts[base_fmt] = tiles;                       // :102-103
+    g->sum_x = g->sum_x2 = g->sum_y = g->sum_y2 = g->sum_xy = g->sum_abs = 0.0;
+    // running globals accumulated in tile order (:147-174, :195-204, :208-218)
+    for (int64_t t = 0; t < tiles; ++t) {
+        const double *r = stats + t * g->rec, *b = r + 2 + 5 * bslot;
+        g->sum_x += r[0];
+        g->sum_x2 += r[1];
+        g->sum_y += b[0];
+        g->sum_y2 += b[1];
+        g->sum_xy += b[2];
+        g->sum_abs += b[3];
+        std::memcpy(&g->cur[(size_t)t * 5], b, 5 * sizeof(double));
+    }
+    double m = g->cur[4]; // :219-220
+    for (int64_t t = 1; t < tiles; ++t) m = nanmax(m, g->cur[(size_t)t * 5 + 4]);
+    int64_t c = 0;
+    for (int64_t t = 0; t < tiles; ++t) c += (g->cur[(size_t)t * 5 + 4] == m);
+    g->max_abs = m;
+    g->max_count = c;
+    *out = g;
+    return MTQ_OK;
+}
+
+extern "C" int mtq_greedy_pass(mtq_greedy *g, int fmt, const int64_t *order, int64_t n)
+{
+    if (!g || (!order && n > 0)) return fail(MTQ_ERR_INVALID, "null argument");
+    const int slot = slot_of(g->mask, fmt);
+    if (slot < 0) return fail(MTQ_ERR_INVALID, "format is not in the handle's fmt_mask");
+    const double thr = g->thr, N = g->n;
+    for (int64_t k = 0; k < n; ++k) {
+        const int64_t t = order[k];
+        if (t < 0 || t >= g->T) return fail(MTQ_ERR_INVALID, "order contains a tile id out of range");
+        const int prev = g->assign[(size_t)t];
+        double *cur = &g->cur[(size_t)t * 5];
+        const double *q = g->stats + t * g->rec + 2 + 5 * slot;
+        bool accept;
+        if (g->metric == MTQ_METRIC_PCC) {
+            if (prev == fmt) { // :238-241
+                if (!is_good(pcc_from_moments(N, g->sum_x, g->sum_x2, g->sum_y, g->sum_y2, g->sum_xy, g->sum_abs), MTQ_METRIC_PCC, thr))
+                    g->fixed[(size_t)t] = 1;
+                continue;
+            }
+            const double cy = g->sum_y + (q[0] - cur[0]);   // :259
+            const double cy2 = g->sum_y2 + (q[1] - cur[1]); // :260
+            const double cxy = g->sum_xy + (q[2] - cur[2]); // :261
+            const double cab = g->sum_abs + (q[3] - cur[3]); // :262
+            accept = is_good(pcc_from_moments(N, g->sum_x, g->sum_x2, cy, cy2, cxy, cab), MTQ_METRIC_PCC, thr);
+            if (accept) { g->sum_y = cy; g->sum_y2 = cy2; g->sum_xy = cxy; g->sum_abs = cab; }
+        } else if (g->metric == MTQ_METRIC_MAE) {
+            if (prev == fmt) { // :280-284
+                if (!is_good(N != 0.0 ? g->sum_abs / N : 0.0, MTQ_METRIC_MAE, thr)) g->fixed[(size_t)t] = 1;
+                continue;
+            }
+            const double cab = g->sum_abs + (q[3] - cur[3]); // :293
+            accept = is_good(N != 0.0 ? cab / N : 0.0, MTQ_METRIC_MAE, thr);
+            if (accept) g->sum_abs = cab;
+        } else {
+            if (prev == fmt) { // :305-309
+                if (!is_good(g->max_abs, MTQ_METRIC_ATOL, thr)) g->fixed[(size_t)t] = 1;
+                continue;
+            }
+            const double new_max = q[4], old_max = cur[4];
+            double cand_max = g->max_abs;
+            int64_t cand_count = g->max_count;
+            if (new_max > g->max_abs) { // :322-324
+                cand_max = new_max;
+                cand_count = 1;
+            } else if (new_max == g->max_abs) { // :325-327
+                if (old_max != g->max_abs) cand_count = g->max_count + 1;
+            } else if (old_max == g->max_abs) { // :329
+                if (g->max_count > 1) cand_count = g->max_count - 1; // :330-331
+                else {                                                 // :333-336 full recount
+                    double m = (t == 0) ? new_max : g->cur[4];
+                    for (int64_t j = 1; j < g->T; ++j) m = nanmax(m, j == t ? new_max : g->cur[(size_t)j * 5 + 4]);
+                    int64_t c = 0;
+                    for (int64_t j = 0; j < g->T; ++j) c += ((j == t ? new_max : g->cur[(size_t)j * 5 + 4]) == m);
+                    cand_max = m;
+                    cand_count = c;
+                }
+            }
+            accept = is_good(cand_max, MTQ_METRIC_ATOL, thr); // :337
+            if (accept) { g->max_abs = cand_max; g->max_count = cand_count; }
+        }
+        if (accept) { // :264-276 / :295-301 / :337-344
+            std::memcpy(cur, q, 5 * sizeof(double));
+            g->counts[prev]--;
+            g->counts[fmt]++;
+            g->assign[(size_t)t] = (int8_t)fmt;
+        } else {
+            g->fixed[(size_t)t] = 1; // :277-278
+        }
+    }
+    return MTQ_OK;
+}
+
+extern "C" int mtq_greedy_assignment(const mtq_greedy *g, int8_t *assign)
+{
+    if (!g || !assign) return fail(MTQ_ERR_INVALID, "null argument");
+    std::memcpy(assign, g->assign.data(), (size_t)g->T);
+    return MTQ_OK;
+}
+
+extern "C" int mtq_greedy_fixed(const mtq_greedy *g, uint8_t *fixed)
+{
+    if (!g || !fixed) return fail(MTQ_ERR_INVALID, "null argument");
+    std::memcpy(fixed, g->fixed.data(), (size_t)g->T);
+    return MTQ_OK;
+}
+
+extern "C" int mtq_greedy_counts(const mtq_greedy *g, int64_t counts[4])
+{
+    if (!g || !counts) return fail(MTQ_ERR_INVALID, "null argument");
+    for (int f = 0; f < MTQ_NUM_TILE_FORMATS; ++f) counts[f] = g->counts[f];
+    return MTQ_OK;
+}
+
+extern "C" int mtq_greedy_value(const mtq_greedy *g, double *value)
+{
+    if (!g || !value) return fail(MTQ_ERR_INVALID, "null argument");
+    if (g->metric == MTQ_METRIC_PCC) *value = pcc_from_moments(g->n, g->sum_x, g->sum_x2, g->sum_y, g->sum_y2, g->sum_xy, g->sum_abs);
+    else if (g->metric == MTQ_METRIC_MAE) *value = g->n != 0.0 ? g->sum_abs / g->n : 0.0;
+    else *value = g->max_abs;
+    return MTQ_OK;
+}
+
+extern "C" void mtq_greedy_destroy(mtq_greedy *g) { delete g; }
+
+// Per-tile score of one record slot, n = 1024 (tile_utils.py:46-57 on the raw sums).
+static inline double tile_score(const double *r, int slot, int metric)
+{
+    const double *b = r + 2 + 5 * slot;
+    if (metric == MTQ_METRIC_MAE) return b[3] / 1024.0;
+    if (metric == MTQ_METRIC_ATOL) return b[4];
+    return pcc_from_moments(1024.0, r[0], r[1], b[0], b[1], b[2], b[3]);
+}
+
+extern "C" int mtq_tile_scores(const double *stats, int64_t tiles, uint32_t fmt_mask, int metric, double *scores)
+{
+    if (!stats || !scores) return fail(MTQ_ERR_INVALID, "null argument");
+    if (metric < MTQ_METRIC_PCC || metric > MTQ_METRIC_ATOL) return fail(MTQ_ERR_INVALID, "unknown metric");
+    const int nf = popcount4(fmt_mask), rec = 2 + 5 * nf;
+    for (int s = 0; s < nf; ++s)
+        for (int64_t t = 0; t < tiles; ++t) scores[(int64_t)s * tiles + t] = tile_score(stats + t * rec, s, metric);
+    return MTQ_OK;
+}
+
+extern "C" int mtq_threshold_assign(const double *stats, int64_t tiles, uint32_t fmt_mask, const int *formats, int n_formats,
+                                    int metric, double threshold, double band, int8_t *map, int64_t *knife_ids,
+                                    int64_t knife_cap, int64_t *n_knife)
+{
+    if (!stats || !formats || !map) return fail(MTQ_ERR_INVALID, "null argument");
+    if (n_formats <= 0 || n_formats > MTQ_NUM_TILE_FORMATS) return fail(MTQ_ERR_INVALID, "n_formats must be 1..4");
+    if (metric < MTQ_METRIC_PCC || metric > MTQ_METRIC_ATOL) return fail(MTQ_ERR_INVALID, "unknown metric");
+    // MIXED_TILE_BYTES_PER_ELEM (tile_utils.py:9-14)
+    static const double bytes_per_elem[MTQ_NUM_TILE_FORMATS] = {2.0, 1.088, 0.50097, 0.25097};
+    int order[MTQ_NUM_TILE_FORMATS], slots[MTQ_NUM_TILE_FORMATS];
+    for (int i = 0; i < n_formats; ++i) {
+        if (slot_of(fmt_mask, formats[i]) < 0) return fail(MTQ_ERR_INVALID, "a requested format is not in fmt_mask");
+        order[i] = formats[i];
+    }
+    // stable sort ascending bytes (mixed_tile_threshold.py:112-114); best_precision = FIRST max in that order (:115)
+    for (int i = 1; i < n_formats; ++i)
+        for (int j = i; j > 0 && bytes_per_elem[order[j]] < bytes_per_elem[order[j - 1]]; --j) { int tmp = order[j]; order[j] = order[j - 1]; order[j - 1] = tmp; }
+    int best = order[0];
+    for (int i = 1; i < n_formats; ++i) if (bytes_per_elem[order[i]] > bytes_per_elem[best]) best = order[i];
+    for (int i = 0; i < n_formats; ++i) slots[i] = slot_of(fmt_mask, order[i]);
+    const int rec = 2 + 5 * popcount4(fmt_mask);
+    // NumPy >= 2 compares np.float32 score with float32(threshold) (metrics.py:30-33 under NEP 50).
+    const double thr32 = (double)(float)threshold;
+    int64_t nk = 0;
+    for (int64_t t = 0; t < tiles; ++t) {
+        const double *r = stats + t * rec;
+        int chosen = best;
+        bool knife = false;
+        for (int i = 0; i < n_formats; ++i) {
+            const double s = tile_score(r, slots[i], metric);
+            if (std::fabs(s - thr32) <= band) knife = true; // decision of this format is within the float32 noise band
+            if (is_good((double)(float)s, metric, thr32)) { chosen = order[i]; break; }
+        }
+        map[t] = (int8_t)chosen;
+        if (knife) {
+            if (knife_ids && nk < knife_cap) knife_ids[nk] = t;
+            ++nk;
+        }
+    }
+    if (n_knife) *n_knife = nk;
+    return MTQ_OK;
+}
+
+extern "C" int mtq_columns_from_stats(const double *stats, int64_t tiles, uint32_t fmt_mask, const int8_t *map,
+                                      double elem_count, double out[9])
+{
+    if (!stats || !map || !out) return fail(MTQ_ERR_INVALID, "null argument");
+    const int rec = 2 + 5 * popcount4(fmt_mask);
+    double sx = 0, sx2 = 0, sy = 0, sy2 = 0, sxy = 0, sab = 0, mx = 0;
+    for (int64_t t = 0; t < tiles; ++t) {
+        const int slot = slot_of(fmt_mask, map[t]);
+        if (slot < 0) return fail(MTQ_ERR_INVALID, "map names a format that is not in fmt_mask");
+        const double *r = stats + t * rec, *b = r + 2 + 5 * slot;
+        sx += r[0]; sx2 += r[1]; sy += b[0]; sy2 += b[1]; sxy += b[2]; sab += b[3];
+        mx = nanmax(mx, b[4]);
+    }
+    out[0] = pcc_from_moments(elem_count, sx, sx2, sy, sy2, sxy, sab);
+    out[1] = elem_count != 0.0 ? sab / elem_count : 0.0;
+    out[2] = mx;
+    out[3] = sx; out[4] = sx2; out[5] = sy; out[6] = sy2; out[7] = sxy; out[8] = sab;
+    return MTQ_OK;
+}

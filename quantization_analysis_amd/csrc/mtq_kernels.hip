@@ -1,0 +1,217 @@
+// mtq_kernels.hip — gfx950 kernels of the mixed-tile search path and their C-ABI launchers
+// (include/mtq.h, DEVICE section).  Written for wave64 / CDNA4 only.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/mtq.h"
+#include "mtq_device.hpp"
+#include "mtq_error.hpp"
+
+namespace mtq {
+
+// ---------------------------------------------------------------------------------------------
+// K1 (generic form): one wave64 per 32×32 tile, lane ℓ owns the shared-exponent group
+// (row = ℓ>>1, half = ℓ&1).  Literal uint32 quantisation per candidate format, float32 terms,
+// float64 accumulation; lane-sequential over the 16 elements, xor-butterfly over the 64 lanes
+// (= balanced tree over 2*row+half, the order include/mtq.h documents).  Handles every input
+// (fp32 or bf16 storage, specials, ragged edges); the bf16 fast kernel defers to the same
+// arithmetic for groups it cannot take.
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void tile_stats_generic(const T *__restrict__ x, int64_t count, int64_t stride,
+                                                          int64_t rows, int64_t cols, int64_t ld, int tiles_w,
+                                                          int64_t tiles, uint32_t fmt_mask, int rec,
+                                                          double *__restrict__ stats, int vec_ok)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t gt = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); // global tile over the batch
+    if (gt >= count * tiles) return;                                   // wave-uniform
+    const int64_t b = gt / tiles, t = gt - b * tiles;
+    const int64_t tr = t / tiles_w, tc = t - tr * tiles_w;
+    const T *xb = x + b * stride;
+
+    uint32_t u[kGroup];
+    Loader<T>::group(xb, tr * kTile + (lane >> 1), tc * kTile + (lane & 1) * kGroup, rows, cols, ld, vec_ok != 0, u);
+    const uint32_t shared = group_shared_exp(u);
+
+    double acc[2 + 5 * kNumFmt];
+    {
+        double sx = 0.0, sx2 = 0.0;
+#pragma unroll
+        for (int i = 0; i < kGroup; ++i) {
+            const float xv = __uint_as_float(u[i]);
+            const float p = xv * xv;
+            sx += (double)xv;
+            sx2 += (double)p;
+        }
+        acc[0] = sx;
+        acc[1] = sx2;
+    }
+#pragma unroll
+    for (int f = 0; f < kNumFmt; ++f) {
+        double sy = 0.0, sy2 = 0.0, sxy = 0.0, sab = 0.0, mx = 0.0;
+        if (fmt_mask & (1u << f)) { // wave-uniform
+#pragma unroll
+            for (int i = 0; i < kGroup; ++i) {
+                const float xv = __uint_as_float(u[i]);
+                const float yv = __uint_as_float(quant_elem_bits(f, u[i], shared));
+                const float p2 = yv * yv, pxy = xv * yv, df = fabsf(xv - yv);
+                sy += (double)yv;
+                sy2 += (double)p2;
+                sxy += (double)pxy;
+                sab += (double)df;
+                mx = nanmax(mx, (double)df);
+            }
+        }
+        // registers are indexed by FORMAT (static); the record is compacted when it is written
+        acc[2 + 5 * f] = sy; acc[3 + 5 * f] = sy2; acc[4 + 5 * f] = sxy; acc[5 + 5 * f] = sab; acc[6 + 5 * f] = mx;
+    }
+
+#pragma unroll
+    for (int k = 0; k < 2 + 5 * kNumFmt; ++k) {
+        const bool live = k < 2 || (fmt_mask & (1u << ((k - 2) / 5))); // wave-uniform
+        if (live) {
+            const bool is_max = k >= 2 && ((k - 2) % 5) == 4;
+            double v = acc[k];
+#pragma unroll
+            for (int s = 1; s < 64; s <<= 1) {
+                const double o = __shfl_xor(v, s, 64);
+                v = is_max ? nanmax(v, o) : v + o;
+            }
+            acc[k] = v;
+        }
+    }
+    if (lane == 0) {
+        double *out = stats + gt * rec;
+        out[0] = acc[0];
+        out[1] = acc[1];
+        int o = 2;
+#pragma unroll
+        for (int f = 0; f < kNumFmt; ++f)
+            if (fmt_mask & (1u << f)) {
+#pragma unroll
+                for (int j = 0; j < 5; ++j) out[o + j] = acc[2 + 5 * f + j];
+                o += 5;
+            }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K2 / K3: one thread per shared-exponent group; fmt >= 0 → that format everywhere (K2),
+// fmt < 0 → the format named by map[tile] (K3).  Output float32.
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void quantize_groups(const T *__restrict__ x, int64_t rows, int64_t cols, int64_t ld,
+                                                       int groups_w, int tiles_w, int fmt, const int8_t *__restrict__ map,
+                                                       float *__restrict__ y, int64_t ldy, int vec_ok, int vec_ok_y)
+{
+    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t row = g / groups_w;
+    if (row >= rows) return;
+    const int64_t col0 = (g - row * groups_w) * kGroup;
+    uint32_t u[kGroup];
+    Loader<T>::group(x, row, col0, rows, cols, ld, vec_ok != 0, u);
+    const uint32_t shared = group_shared_exp(u);
+    int f = fmt;
+    if (f < 0) f = map[(row / kTile) * tiles_w + col0 / kTile];
+    uint32_t o[kGroup];
+#pragma unroll
+    for (int i = 0; i < kGroup; ++i) o[i] = quant_elem_bits(f, u[i], shared);
+    float *yr = y + row * ldy + col0;
+    if (col0 + kGroup <= cols && vec_ok_y) {
+        uint4 *q = reinterpret_cast<uint4 *>(yr);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) q[i] = make_uint4(o[4 * i], o[4 * i + 1], o[4 * i + 2], o[4 * i + 3]);
+    } else {
+#pragma unroll
+        for (int i = 0; i < kGroup; ++i)
+            if (col0 + i < cols) yr[i] = __uint_as_float(o[i]);
+    }
+}
+
+static bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+static int check_matrix(const void *x, int in_dtype, int64_t rows, int64_t cols, int64_t ld)
+{
+    if (!x) return fail(MTQ_ERR_INVALID, "x is null");
+    if (in_dtype != MTQ_DTYPE_BF16 && in_dtype != MTQ_DTYPE_F32) return fail(MTQ_ERR_INVALID, "in_dtype must be MTQ_DTYPE_BF16 or MTQ_DTYPE_F32");
+    if (rows <= 0 || cols <= 0) return fail(MTQ_ERR_INVALID, "rows and cols must be positive (empty tensors are handled by the caller)");
+    if (ld < cols) return fail(MTQ_ERR_INVALID, "ld < cols");
+    if (rows > (int64_t)1 << 40 || cols > (int64_t)1 << 30) return fail(MTQ_ERR_INVALID, "matrix too large");
+    return MTQ_OK;
+}
+
+} // namespace mtq
+
+using namespace mtq;
+
+extern "C" size_t mtq_stats_record_doubles(uint32_t fmt_mask) { return 2 + 5 * (size_t)__builtin_popcount(fmt_mask & MTQ_MASK_ALL); }
+
+extern "C" int mtq_tile_stats_batched(const void *x, int in_dtype, int64_t count, int64_t stride_elems, int64_t rows,
+                                      int64_t cols, int64_t ld, uint32_t fmt_mask, double *stats, void *stream)
+{
+    if (int rc = check_matrix(x, in_dtype, rows, cols, ld)) return rc;
+    if (!stats) return fail(MTQ_ERR_INVALID, "stats is null");
+    if (count <= 0) return fail(MTQ_ERR_INVALID, "count must be positive");
+    if ((fmt_mask & ~MTQ_MASK_ALL) != 0) return fail(MTQ_ERR_INVALID, "fmt_mask has bits outside bf16|bfp8|bfp4|bfp2");
+    if (int rc = require_device()) return rc;
+    const int64_t th = (rows + kTile - 1) / kTile, tw = (cols + kTile - 1) / kTile, tiles = th * tw;
+    if (tw > INT32_MAX || count * tiles > ((int64_t)1 << 33)) return fail(MTQ_ERR_INVALID, "too many tiles for one launch");
+    const int rec = (int)mtq_stats_record_doubles(fmt_mask);
+    const int64_t esz = in_dtype == MTQ_DTYPE_BF16 ? 2 : 4;
+    const int vec_ok = aligned16(x) && (ld * esz) % 16 == 0 && (stride_elems * esz) % 16 == 0;
+    const int64_t blocks = (count * tiles + 3) / 4;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (in_dtype == MTQ_DTYPE_BF16)
+        hipLaunchKernelGGL(tile_stats_generic<uint16_t>, dim3((unsigned)blocks), dim3(256), 0, s, static_cast<const uint16_t *>(x), count,
+                           stride_elems, rows, cols, ld, (int)tw, tiles, fmt_mask, rec, stats, vec_ok);
+    else
+        hipLaunchKernelGGL(tile_stats_generic<float>, dim3((unsigned)blocks), dim3(256), 0, s, static_cast<const float *>(x), count,
+                           stride_elems, rows, cols, ld, (int)tw, tiles, fmt_mask, rec, stats, vec_ok);
+    return check_launch("mtq_tile_stats");
+}
+
+extern "C" int mtq_tile_stats(const void *x, int in_dtype, int64_t rows, int64_t cols, int64_t ld, uint32_t fmt_mask,
+                              double *stats, void *stream)
+{
+    return mtq_tile_stats_batched(x, in_dtype, 1, 0, rows, cols, ld, fmt_mask, stats, stream);
+}
+
+static int launch_quantize(const void *x, int in_dtype, int64_t rows, int64_t cols, int64_t ld, int fmt, const int8_t *map,
+                           float *y, int64_t ldy, void *stream, const char *what)
+{
+    if (int rc = check_matrix(x, in_dtype, rows, cols, ld)) return rc;
+    if (!y) return fail(MTQ_ERR_INVALID, "y is null");
+    if (ldy < cols) return fail(MTQ_ERR_INVALID, "ldy < cols");
+    if (int rc = require_device()) return rc;
+    const int64_t gw = (cols + kGroup - 1) / kGroup, tw = (cols + kTile - 1) / kTile;
+    const int64_t groups = rows * gw;
+    if (gw > INT32_MAX || groups > ((int64_t)1 << 38)) return fail(MTQ_ERR_INVALID, "matrix too large for one launch");
+    const int64_t esz = in_dtype == MTQ_DTYPE_BF16 ? 2 : 4;
+    const int vec_ok = aligned16(x) && (ld * esz) % 16 == 0;
+    const int vec_ok_y = aligned16(y) && (ldy * 4) % 16 == 0;
+    const int64_t blocks = (groups + 255) / 256;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (in_dtype == MTQ_DTYPE_BF16)
+        hipLaunchKernelGGL(quantize_groups<uint16_t>, dim3((unsigned)blocks), dim3(256), 0, s, static_cast<const uint16_t *>(x), rows, cols,
+                           ld, (int)gw, (int)tw, fmt, map, y, ldy, vec_ok, vec_ok_y);
+    else
+        hipLaunchKernelGGL(quantize_groups<float>, dim3((unsigned)blocks), dim3(256), 0, s, static_cast<const float *>(x), rows, cols, ld,
+                           (int)gw, (int)tw, fmt, map, y, ldy, vec_ok, vec_ok_y);
+    return check_launch(what);
+}
+
+extern "C" int mtq_quantize(const void *x, int in_dtype, int64_t rows, int64_t cols, int64_t ld, int fmt, float *y,
+                            int64_t ldy, void *stream)
+{
+    if (fmt < MTQ_FMT_BF16 || fmt > MTQ_FMT_FP0) return fail(MTQ_ERR_UNSUPPORTED, "format code must be 0..4 (bf16,bfp8,bfp4,bfp2,fp0)");
+    return launch_quantize(x, in_dtype, rows, cols, ld, fmt, nullptr, y, ldy, stream, "mtq_quantize");
+}
+
+extern "C" int mtq_apply_assignment(const void *x, int in_dtype, int64_t rows, int64_t cols, int64_t ld, const int8_t *map,
+                                    float *y, int64_t ldy, void *stream)
+{
+    if (!map) return fail(MTQ_ERR_INVALID, "map is null");
+    return launch_quantize(x, in_dtype, rows, cols, ld, -1, map, y, ldy, stream, "mtq_apply_assignment");
+}

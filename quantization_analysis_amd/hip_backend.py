@@ -1,0 +1,320 @@
+"""ctypes binding of libmtq_hip.so (include/mtq.h) for PyTorch-ROCm tensors.
+
+This module is the ONLY place the package talks to the GPU.  There is no CPU fallback: if the
+shared library is missing, or no HIP device is visible, device entry points raise MtqError.
+PyTorch is used for device memory and streams only (tensor.data_ptr(), current stream).
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from pathlib import Path
+
+import numpy as np
+
+_PKG = Path(__file__).resolve().parent
+LIB_PATH = _PKG / "libmtq_hip.so"
+
+MIXED_TILE_FORMATS = ["bf16", "bfp8", "bfp4", "bfp2"]
+FMT_CODE = {"bf16": 0, "bfp8": 1, "bfp4": 2, "bfp2": 3, "fp0": 4}
+METRIC_CODE = {"pcc": 0, "mae": 1, "atol": 2}
+DTYPE_BF16, DTYPE_F32 = 0, 1
+TILE = 32
+
+# every symbol include/mtq.h declares (tests check the library exports exactly these)
+EXPORTS = [
+    "mtq_version", "mtq_last_error", "mtq_device_count", "mtq_stats_record_doubles",
+    "mtq_tile_stats", "mtq_tile_stats_batched", "mtq_quantize", "mtq_apply_assignment",
+    "mtq_greedy_create", "mtq_greedy_pass", "mtq_greedy_assignment", "mtq_greedy_fixed",
+    "mtq_greedy_counts", "mtq_greedy_value", "mtq_greedy_destroy",
+    "mtq_tile_scores", "mtq_threshold_assign", "mtq_columns_from_stats",
+]
+
+
+class MtqError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def build(force: bool = False) -> Path:
+    """Compile libmtq_hip.so for gfx950 with hipcc (csrc/Makefile).  Cross-compiles without a GPU."""
+    import subprocess
+
+    srcs = list((_PKG / "csrc").glob("*")) + [_PKG.parent / "include" / "mtq.h"]
+    stale = not LIB_PATH.exists() or any(p.stat().st_mtime > LIB_PATH.stat().st_mtime for p in srcs)
+    if force or stale:
+        subprocess.check_call(["make", "-C", str(_PKG / "csrc"), "-s"])
+    return LIB_PATH
+
+
+def lib() -> ctypes.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise MtqError(
+            f"{LIB_PATH} is missing: build it with `make -C {_PKG / 'csrc'}` (hipcc --offload-arch=gfx950). "
+            "The hip backend has no CPU fallback."
+        )
+    L = ctypes.CDLL(str(LIB_PATH))
+    vp, i64, u32, ci, dbl = ctypes.c_void_p, ctypes.c_int64, ctypes.c_uint32, ctypes.c_int, ctypes.c_double
+    L.mtq_version.restype = ci
+    L.mtq_last_error.restype = ctypes.c_char_p
+    L.mtq_device_count.argtypes = [ctypes.POINTER(ci)]
+    L.mtq_stats_record_doubles.argtypes = [u32]
+    L.mtq_stats_record_doubles.restype = ctypes.c_size_t
+    L.mtq_tile_stats.argtypes = [vp, ci, i64, i64, i64, u32, vp, vp]
+    L.mtq_tile_stats_batched.argtypes = [vp, ci, i64, i64, i64, i64, i64, u32, vp, vp]
+    L.mtq_quantize.argtypes = [vp, ci, i64, i64, i64, ci, vp, i64, vp]
+    L.mtq_apply_assignment.argtypes = [vp, ci, i64, i64, i64, vp, vp, i64, vp]
+    L.mtq_greedy_create.argtypes = [ctypes.POINTER(vp), vp, i64, u32, ci, dbl, dbl, ci]
+    L.mtq_greedy_pass.argtypes = [vp, ci, vp, i64]
+    L.mtq_greedy_assignment.argtypes = [vp, vp]
+    L.mtq_greedy_fixed.argtypes = [vp, vp]
+    L.mtq_greedy_counts.argtypes = [vp, vp]
+    L.mtq_greedy_value.argtypes = [vp, ctypes.POINTER(dbl)]
+    L.mtq_greedy_destroy.argtypes = [vp]
+    L.mtq_greedy_destroy.restype = None
+    L.mtq_tile_scores.argtypes = [vp, i64, u32, ci, vp]
+    L.mtq_threshold_assign.argtypes = [vp, i64, u32, vp, ci, ci, dbl, dbl, vp, vp, i64, ctypes.POINTER(i64)]
+    L.mtq_columns_from_stats.argtypes = [vp, i64, u32, vp, dbl, vp]
+    if L.mtq_version() < 100:
+        raise MtqError("libmtq_hip.so is older than this package")
+    _lib = L
+    return L
+
+
+def check(rc: int) -> None:
+    if rc != 0:
+        raise MtqError(f"libmtq_hip error {rc}: {lib().mtq_last_error().decode()}")
+
+
+def fmt_mask(formats) -> int:
+    m = 0
+    for f in formats:
+        m |= 1 << MIXED_TILE_FORMATS.index(f)
+    return m
+
+
+def mask_formats(mask: int) -> list[str]:
+    return [f for i, f in enumerate(MIXED_TILE_FORMATS) if mask & (1 << i)]
+
+
+def record_doubles(mask: int) -> int:
+    return 2 + 5 * bin(mask & 0xF).count("1")
+
+
+def tiles_hw(rows: int, cols: int) -> tuple[int, int]:
+    return -(-rows // TILE), -(-cols // TILE)
+
+
+# ----------------------------------------------------------------------------- device helpers
+
+def _torch():
+    import torch
+
+    return torch
+
+
+def require_gpu() -> None:
+    torch = _torch()
+    if not torch.cuda.is_available():
+        raise MtqError("backend 'hip' needs a visible MI355X (torch.cuda.is_available() is False); there is no CPU fallback")
+    n = ctypes.c_int(0)
+    check(lib().mtq_device_count(ctypes.byref(n)))
+
+
+def _dtype_code(t) -> int:
+    torch = _torch()
+    if t.dtype == torch.bfloat16:
+        return DTYPE_BF16
+    if t.dtype == torch.float32:
+        return DTYPE_F32
+    raise MtqError(f"hip backend takes bfloat16 or float32 tensors, got {t.dtype}")
+
+
+def _stream_ptr() -> int:
+    return _torch().cuda.current_stream().cuda_stream
+
+
+def _as_device_matrix(t):
+    """2-D, last-dim-contiguous device tensor → (tensor, rows, cols, ld)."""
+    if t.dim() != 2 or not t.is_cuda:
+        raise MtqError("expected a 2-D device tensor (use to_device_2d for host / N-D input)")
+    if t.stride(1) != 1:
+        t = t.contiguous()
+    return t, t.shape[0], t.shape[1], t.stride(0) if t.shape[0] > 1 else max(t.stride(0), t.shape[1])
+
+
+def to_device_2d(x, device=None):
+    """Host ndarray / torch tensor of any rank → (2-D device tensor, shape_info) following the 2-D
+    flatten of compression_algorithms/tile_utils.py:91-107.  bf16 stays bf16, everything else → fp32."""
+    torch = _torch()
+    device = device or torch.device("cuda", torch.cuda.current_device())
+    if isinstance(x, np.ndarray) or np.isscalar(x):
+        t = torch.from_numpy(np.ascontiguousarray(np.asarray(x, dtype=np.float32)))
+        if np.ndim(x) == 0:
+            t = t.reshape(())
+    else:
+        t = x
+        if t.dtype not in (torch.bfloat16, torch.float32):
+            t = t.to(torch.float32)
+    t = t.to(device, non_blocking=True)
+    if t.dim() == 0:
+        return t.reshape(1, 1), ("scalar", tuple(t.shape))
+    if t.dim() == 1:
+        n = t.shape[0]
+        h = -(-n // TILE)
+        d = torch.zeros((h, TILE), dtype=t.dtype, device=device)
+        d.view(-1)[:n] = t
+        return d, ("vector", n)
+    shape = tuple(t.shape)
+    return t.reshape(-1, shape[-1]).contiguous(), ("nd", shape)
+
+
+def unflatten(y2d, shape_info):
+    """Inverse of to_device_2d's flatten (tile_utils.py:123-131) for torch or numpy 2-D arrays."""
+    kind, v = shape_info
+    if kind == "scalar":
+        return y2d.reshape(())
+    if kind == "vector":
+        return y2d.reshape(-1)[:v]
+    return y2d.reshape(v)
+
+
+def tile_stats(x2d, mask: int, out=None):
+    """K1 on a 2-D device tensor → device float64 [tiles, 2+5F] (async on the current stream)."""
+    torch = _torch()
+    require_gpu()
+    x2d, rows, cols, ld = _as_device_matrix(x2d)
+    th, tw = tiles_hw(rows, cols)
+    rec = record_doubles(mask)
+    if out is None:
+        out = torch.empty((th * tw, rec), dtype=torch.float64, device=x2d.device)
+    check(lib().mtq_tile_stats(x2d.data_ptr(), _dtype_code(x2d), rows, cols, ld, mask, out.data_ptr(), _stream_ptr()))
+    return out
+
+
+def tile_stats_batched(x3d, mask: int, out=None):
+    """K1 over a (count, rows, cols) contiguous device tensor in one launch → [count, tiles, rec]."""
+    torch = _torch()
+    require_gpu()
+    if x3d.dim() != 3 or not x3d.is_cuda or not x3d.is_contiguous():
+        raise MtqError("expected a contiguous (count, rows, cols) device tensor")
+    count, rows, cols = x3d.shape
+    th, tw = tiles_hw(rows, cols)
+    rec = record_doubles(mask)
+    if out is None:
+        out = torch.empty((count, th * tw, rec), dtype=torch.float64, device=x3d.device)
+    check(lib().mtq_tile_stats_batched(x3d.data_ptr(), _dtype_code(x3d), count, rows * cols, rows, cols, cols, mask,
+                                       out.data_ptr(), _stream_ptr()))
+    return out
+
+
+def quantize(x2d, fmt: str, out=None):
+    """K2 on a 2-D device tensor → device float32 (rows, cols)."""
+    torch = _torch()
+    require_gpu()
+    if fmt not in FMT_CODE:
+        raise ValueError(f"Unsupported weight format: {fmt}")
+    x2d, rows, cols, ld = _as_device_matrix(x2d)
+    if out is None:
+        out = torch.empty((rows, cols), dtype=torch.float32, device=x2d.device)
+    check(lib().mtq_quantize(x2d.data_ptr(), _dtype_code(x2d), rows, cols, ld, FMT_CODE[fmt], out.data_ptr(), out.stride(0), _stream_ptr()))
+    return out
+
+
+def apply_assignment(x2d, assignment, out=None):
+    """K3: assignment is an int8 (tiles_h, tiles_w) numpy array or device tensor."""
+    torch = _torch()
+    require_gpu()
+    x2d, rows, cols, ld = _as_device_matrix(x2d)
+    th, tw = tiles_hw(rows, cols)
+    if isinstance(assignment, np.ndarray):
+        assignment = torch.from_numpy(np.ascontiguousarray(assignment, dtype=np.int8)).to(x2d.device)
+    a = assignment.to(torch.int8).contiguous()
+    if a.numel() != th * tw:
+        raise MtqError(f"assignment has {a.numel()} entries, tensor has {th}x{tw} tiles")
+    if out is None:
+        out = torch.empty((rows, cols), dtype=torch.float32, device=x2d.device)
+    check(lib().mtq_apply_assignment(x2d.data_ptr(), _dtype_code(x2d), rows, cols, ld, a.data_ptr(), out.data_ptr(), out.stride(0), _stream_ptr()))
+    return out
+
+
+# ----------------------------------------------------------------------------- host decisions
+
+class GreedyScan:
+    """H1: the sequential scan of mixed_tile_greedy.py:133-346 on a host copy of the stats."""
+
+    def __init__(self, stats: np.ndarray, mask: int, metric: str, threshold: float, elem_count: float, base_fmt: str):
+        self.stats = np.ascontiguousarray(stats, dtype=np.float64)  # kept alive: the handle reads it
+        self.T = self.stats.shape[0]
+        self._h = ctypes.c_void_p()
+        check(lib().mtq_greedy_create(ctypes.byref(self._h), self.stats.ctypes.data, self.T, mask, METRIC_CODE[metric],
+                                      float(threshold), float(elem_count), MIXED_TILE_FORMATS.index(base_fmt)))
+
+    def run_pass(self, fmt: str, order: np.ndarray) -> None:
+        order = np.ascontiguousarray(order, dtype=np.int64)
+        check(lib().mtq_greedy_pass(self._h, MIXED_TILE_FORMATS.index(fmt), order.ctypes.data, order.size))
+
+    def fixed(self) -> np.ndarray:
+        out = np.empty(self.T, dtype=np.uint8)
+        check(lib().mtq_greedy_fixed(self._h, out.ctypes.data))
+        return out
+
+    def assignment(self) -> np.ndarray:
+        out = np.empty(self.T, dtype=np.int8)
+        check(lib().mtq_greedy_assignment(self._h, out.ctypes.data))
+        return out
+
+    def counts(self) -> dict[str, int]:
+        c = (ctypes.c_int64 * 4)()
+        check(lib().mtq_greedy_counts(self._h, c))
+        return {f: int(c[i]) for i, f in enumerate(MIXED_TILE_FORMATS)}
+
+    def value(self) -> float:
+        v = ctypes.c_double()
+        check(lib().mtq_greedy_value(self._h, ctypes.byref(v)))
+        return v.value
+
+    def close(self) -> None:
+        if self._h:
+            lib().mtq_greedy_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def tile_scores(stats: np.ndarray, mask: int, metric: str) -> np.ndarray:
+    stats = np.ascontiguousarray(stats, dtype=np.float64)
+    T = stats.shape[0]
+    out = np.empty((bin(mask & 0xF).count("1"), T), dtype=np.float64)
+    check(lib().mtq_tile_scores(stats.ctypes.data, T, mask, METRIC_CODE[metric], out.ctypes.data))
+    return out
+
+
+def threshold_assign(stats: np.ndarray, mask: int, formats, metric: str, threshold: float, band: float = 2e-6):
+    """K4 on host stats → (int8[T] map, knife-edge tile ids)."""
+    stats = np.ascontiguousarray(stats, dtype=np.float64)
+    T = stats.shape[0]
+    fm = (ctypes.c_int * len(formats))(*[MIXED_TILE_FORMATS.index(f) for f in formats])
+    amap = np.empty(T, dtype=np.int8)
+    knife = np.empty(T, dtype=np.int64)
+    nk = ctypes.c_int64(0)
+    check(lib().mtq_threshold_assign(stats.ctypes.data, T, mask, fm, len(formats), METRIC_CODE[metric], float(threshold), float(band),
+                                     amap.ctypes.data, knife.ctypes.data, T, ctypes.byref(nk)))
+    return amap, knife[: min(nk.value, T)].copy()
+
+
+def columns_from_stats(stats: np.ndarray, mask: int, assignment: np.ndarray, elem_count: float) -> dict:
+    stats = np.ascontiguousarray(stats, dtype=np.float64)
+    a = np.ascontiguousarray(assignment, dtype=np.int8).reshape(-1)
+    out = (ctypes.c_double * 9)()
+    check(lib().mtq_columns_from_stats(stats.ctypes.data, stats.shape[0], mask, a.ctypes.data, float(elem_count), out))
+    return {"pcc": out[0], "mae": out[1], "atol": out[2], "sums": tuple(out[3:9])}

@@ -1,0 +1,118 @@
+"""CPU-only: the C-ABI library loads, exports every symbol include/mtq.h declares, refuses device work
+without a GPU, and its HOST decision functions (greedy scan, threshold assign, columns) agree with the
+oracle when fed the oracle's stats records."""
+import ctypes
+import json
+import re
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from oracle import mtq_oracle as orc
+from quantization_analysis_amd import hip_backend as hb
+from tests.inputs import gen
+
+ROOT = Path(__file__).resolve().parent.parent
+ALL = ["bf16", "bfp8", "bfp4", "bfp2"]
+
+
+def test_header_symbols_exported():
+    hdr = (ROOT / "include" / "mtq.h").read_text()
+    declared = set(re.findall(r"\b(mtq_[a-z_0-9]+)\s*\(", hdr))
+    assert declared == set(hb.EXPORTS), declared ^ set(hb.EXPORTS)
+    L = hb.lib()
+    for name in declared:
+        assert hasattr(L, name), name
+    assert L.mtq_version() == 100
+    assert L.mtq_stats_record_doubles(0xF) == 22 and L.mtq_stats_record_doubles(0b0110) == 12
+
+
+def test_argument_errors_are_reported():
+    L = hb.lib()
+    assert L.mtq_tile_stats(None, 0, 32, 32, 32, 0xF, None, None) == -1
+    assert b"null" in L.mtq_last_error()
+    buf = np.zeros(4, dtype=np.float64)
+    assert L.mtq_tile_stats(buf.ctypes.data, 7, 32, 32, 32, 0xF, buf.ctypes.data, None) == -1
+    assert L.mtq_tile_stats(buf.ctypes.data, 0, 32, 32, 16, 0xF, buf.ctypes.data, None) == -1  # ld < cols
+    assert L.mtq_quantize(buf.ctypes.data, 0, 32, 32, 32, 9, buf.ctypes.data, 32, None) == -4
+    h = ctypes.c_void_p()
+    assert L.mtq_greedy_create(ctypes.byref(h), buf.ctypes.data, 1, 0b0010, 0, 0.9, 1.0, 0) == -1  # base not in mask
+
+
+def test_no_gpu_means_error_not_fallback():
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(hb.MtqError):
+        hb.require_gpu()
+    buf = np.zeros(64, dtype=np.float64)
+    rc = hb.lib().mtq_tile_stats(buf.ctypes.data, 1, 32, 32, 32, 0xF, buf.ctypes.data, None)
+    assert rc == -3 and b"no CPU fallback" in hb.lib().mtq_last_error()
+
+
+def _host_greedy(x, formats, metric, thr, seed):
+    x2d, _ = orc.flatten_2d(x)
+    fm = [f for f in ALL if f in formats]
+    mask = hb.fmt_mask(fm)
+    stats = orc.tile_stats(x2d, fm)
+    scan = hb.GreedyScan(stats, mask, metric, thr, float(x.size), formats[0])
+    rng = np.random.default_rng(seed)
+    for fmt in formats:
+        cand = np.where(scan.fixed() == 0)[0]
+        if cand.size == 0:
+            break
+        scan.run_pass(fmt, rng.permutation(cand))
+    return scan.assignment(), scan.counts(), scan.value(), stats, mask
+
+
+def test_host_greedy_scan_matches_golden_maps(golden_dir):
+    d = np.load(golden_dir / "f4_greedy.npz")
+    meta = json.loads((golden_dir / "golden_meta.json").read_text())["f4"]
+    for name, m in meta.items():
+        x = gen(m["kind"], m["seed"], tuple(m["shape"]))
+        a, counts, value, stats, mask = _host_greedy(x, m["formats"], m["metric"], m["threshold"], m["algo_seed"])
+        want = d[f"{name}_assign"]
+        assert np.array_equal(a.reshape(want.shape), want), name
+        assert [counts[f] for f in ALL] == list(d[f"{name}_counts"]), name
+        oa, _oc, ost = orc.greedy(x, m["formats"], m["metric"], m["threshold"], m["algo_seed"])
+        assert value == ost["value"], name  # same doubles, same order of operations
+        cols = hb.columns_from_stats(stats, mask, a, x.size)
+        slots = orc.mask_slots(mask)
+        pcc, mae, atol = orc.columns_from_stats(stats, slots, oa, x.size)
+        assert (cols["pcc"], cols["mae"], cols["atol"]) == (pcc, mae, atol), name
+
+
+def test_host_threshold_assign_matches_golden_maps(golden_dir):
+    d = np.load(golden_dir / "f5_threshold.npz")
+    meta = json.loads((golden_dir / "golden_meta.json").read_text())["f5"]
+    total_knife = 0
+    for name, m in meta.items():
+        x = d[f"{name}_x"]
+        x2d, _ = orc.flatten_2d(x)
+        fm = [f for f in ALL if f in m["formats"]]
+        mask = hb.fmt_mask(fm)
+        stats = orc.tile_stats(x2d, fm)
+        amap, knife = hb.threshold_assign(stats, mask, m["formats"], m["metric"], m["threshold"], band=2e-6)
+        want = d[f"{name}_assign"].reshape(-1)
+        # outside the knife-edge band the float64-moment decision IS the reference's float32 decision
+        off = np.setdiff1d(np.where(amap != want)[0], knife)
+        assert off.size == 0, (name, off)
+        total_knife += knife.size
+        # scores agree with the reference's float32 scores within the band
+        sc = hb.tile_scores(stats, mask, m["metric"])
+        for i, f in enumerate(fm):
+            assert np.max(np.abs(sc[i] - d[f"{name}_score_{f}"].astype(np.float64))) <= 1e-6, (name, f)
+    assert total_knife > 0  # the knife-edge fixtures must exercise the band
+
+
+def test_threshold_best_precision_and_order():
+    # all tiles fail → highest-bytes format among the requested ones (mixed_tile_threshold.py:115-117)
+    x = gen("heavy_f32", 3, (64, 64))
+    x2d, _ = orc.flatten_2d(x)
+    stats = orc.tile_stats(x2d, ["bfp8", "bfp4", "bfp2"])
+    amap, _ = hb.threshold_assign(stats, 0b1110, ["bfp2", "bfp8", "bfp4"], "pcc", 1.5)
+    assert set(amap.tolist()) == {1}
+    amap, _ = hb.threshold_assign(stats, 0b1110, ["bfp2", "bfp4"], "pcc", -1.0)
+    assert set(amap.tolist()) == {3}
