@@ -1,0 +1,172 @@
+#!/usr/bin/env python3
+"""bench.py — mixed-tile-greedy (bf16 → BFP{8,4,2}) throughput on MI355X.
+
+Step  = one pass of the hot path (K1 tile_stats on the GPU + stats D2H + host greedy scan → per-tile
+        assignment maps + pcc/mae/atol) over a batch of `--tensors` synthetic 4096x4096 bf16 tensors
+        (BASELINE.json configs[1], streamed; the batch is > 256 MiB so the Infinity Cache cannot hold it).
+value = tiles/s, whole job, inputs resident in HBM when the timed region starts.
+roofline = the K1 kernel alone: algorithmic 2048 B read per tile / HIP-event launch duration vs 8 TB/s.
+cpu_baseline = the C oracle (oracle/, a port of the reference's CPU path) on rank 0's host, 1 thread,
+        on a bounded sample of the same tensors.
+
+  python bench.py --gpus 1 --steps 5 --warmup 1
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+import numpy as np
+import torch
+
+ROWS = COLS = 4096
+FORMATS = ["bf16", "bfp8", "bfp4", "bfp2"]
+METRIC, THRESHOLD, SEED = "pcc", 0.999, 123
+HBM_PEAK_GBS = 8000.0          # MI355X spec, /opt/skills/guides/MI355X_MICROARCH.md
+BYTES_PER_TILE_READ = 2048     # 32*32 bf16, SURVEY §8(d)
+
+
+def make_batch(n: int, rank: int, device) -> torch.Tensor:
+    """N(0, 0.02²) rounded to bf16, one seed per tensor (generated on the device)."""
+    g = torch.Generator(device=device)
+    out = torch.empty((n, ROWS, COLS), dtype=torch.bfloat16, device=device)
+    for i in range(n):
+        g.manual_seed(1000 * rank + i)
+        out[i] = (torch.randn((ROWS, COLS), generator=g, device=device, dtype=torch.float32) * 0.02).to(torch.bfloat16)
+    return out
+
+
+def cpu_baseline(sample: torch.Tensor) -> dict:
+    """The CPU port (oracle) timed like wq:680-682 times algo.run: perf_counter around the whole search."""
+    from oracle import mtq_oracle as orc
+
+    xs = [sample[i].float().cpu().numpy() for i in range(sample.shape[0])]
+    orc.lib()
+    t0 = time.perf_counter()
+    tiles = 0
+    for x in xs:
+        a, _c, _s = orc.greedy(x, FORMATS, METRIC, THRESHOLD, SEED)
+        tiles += a.size
+    dt = time.perf_counter() - t0
+    return {"value": tiles / dt, "unit": "tiles/s", "cores": 1, "kind": "port",
+            "sample": f"{len(xs)} of the step's 4096x4096 bf16 tensors, oracle/mtq_oracle.c greedy (1 thread), {dt:.1f} s"}
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--tensors", type=int, default=32, help="4096x4096 bf16 tensors per step per GPU (32 = 1 GiB)")
+    ap.add_argument("--chunk", type=int, default=8, help="tensors per K1 launch")
+    ap.add_argument("--workers", type=int, default=int(os.environ.get("MTQ_SCAN_WORKERS", "12")), help="host scan threads per rank")
+    ap.add_argument("--cpu-sample", type=int, default=12, help="tensors timed on the CPU port (0 = skip)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X; there is no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)  # nccl == RCCL on ROCm
+
+    from quantization_analysis_amd import hip_backend as hb
+    from quantization_analysis_amd.pipeline import GreedyPipeline
+
+    hb.require_gpu()
+    batch = make_batch(args.tensors, rank, device)
+    pipe = GreedyPipeline(FORMATS, METRIC, THRESHOLD, SEED, chunk=args.chunk, workers=args.workers)
+    tiles_per_step = args.tensors * (ROWS // 32) * (COLS // 32)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        res = pipe.run(batch)
+    pipe.timing.drain()
+    pipe.timing.__init__()
+
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = pipe.run(batch)
+    barrier()
+    dt = time.perf_counter() - t0
+    pipe.timing.drain()
+
+    # the only data-path collective: per-tensor summary rows to rank 0; outside the timed steps
+    # the rows of the LAST step are gathered so the multi-GPU path is exercised end to end.
+    rows = torch.tensor([[r.index, ROWS * COLS, r.pcc, r.mae, r.atol, r.tile_bytes, r.counts["bf16"], r.counts["bfp8"],
+                          r.counts["bfp4"], r.counts["bfp2"], 0.0] for r in res], dtype=torch.float64, device=device)
+    t_max = torch.tensor([dt], dtype=torch.float64, device=device)
+    if dist is not None:
+        gathered = [torch.empty_like(rows) for _ in range(world)] if rank == 0 else None
+        dist.gather(rows, gathered, dst=0)
+        dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
+        all_rows = torch.cat(gathered).cpu().numpy() if rank == 0 else None
+    else:
+        all_rows = rows.cpu().numpy()
+    dt = float(t_max.item())
+
+    if rank == 0:
+        kt = pipe.timing
+        k_ms = kt.kernel_ms / max(kt.launches, 1)
+        tiles_per_launch = kt.tiles / max(kt.launches, 1)
+        achieved = BYTES_PER_TILE_READ * tiles_per_launch / (k_ms * 1e-3) / 1e9
+        traffic = None
+        tfile = ROOT / "profiles" / "k1_traffic.json"  # HBM bytes per launch from a separate rocprofv3 --pmc pass
+        if tfile.exists():
+            try:
+                traffic = json.loads(tfile.read_text()).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "32x32 tiles/s for mixed-tile-greedy (bf16->BFP{8,4,2}); achieved HBM GB/s vs peak",
+            "value": world * args.steps * tiles_per_step / dt,
+            "unit": "tiles/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u32/f64", "data": "synthetic",
+            "config": {"workload": f"{args.tensors} x 4096x4096 bf16 N(0,0.02^2) per GPU per step, mixed-tile-greedy "
+                                   f"{{bf16,bfp8,bfp4,bfp2}} pcc>=0.999 seed 123 (BASELINE.json configs[1], streamed)",
+                       "tensors_per_step_per_gpu": args.tensors, "tiles_per_step_per_gpu": tiles_per_step,
+                       "k1_chunk": args.chunk, "scan_workers": args.workers, "sharding": f"tensors x{world}, RCCL gather of summary rows"},
+            "roofline": {"bound": "hbm", "kernel": "tile_stats (K1)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "launch_ms": k_ms, "tiles_per_launch": tiles_per_launch, "launches": kt.launches,
+                         "kernel_tiles_per_s": tiles_per_launch / (k_ms * 1e-3)},
+            "summary": {"tensors": int(all_rows.shape[0]), "mean_pcc": float(all_rows[:, 2].mean()),
+                        "counts_bf16_bfp8_bfp4_bfp2": [int(all_rows[:, 6 + i].sum()) for i in range(4)]},
+        }
+        if args.cpu_sample > 0:
+            out["cpu_baseline"] = cpu_baseline(batch[: min(args.cpu_sample, args.tensors)])
+        print(json.dumps(out), flush=True)
+    pipe.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,158 @@
+"""Shared core of the two mixed-tile search algorithms: per-tile raw sums ("stats records") for every
+candidate format, and reconstruction of y from an assignment map.
+
+The reference recomputes quantized tiles and per-tile sums inside each algorithm
+(mixed_tile_greedy.py:98,133-220,232-254; mixed_tile_threshold.py:97-109).  Here both algorithms
+consume one record per tile: [Σx, Σx², {Σy, Σy², Σxy, Σ|x−y|, max|x−y|} per format] in float64 — the
+layout of include/mtq.h — produced by
+
+  backend "hip":        K1 of libmtq_hip.so, one pass over HBM, y never materialised;
+  backend "emulation":  the NumPy code below on the host (same definition, same summation order).
+
+Sums run over the zero-padded 32x32 tile; pads are exact zeros in x and y, so they equal the reference's
+valid-region sums (mixed_tile_greedy.py:122-131) — SURVEY §8(c).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+
+import numpy as np
+
+from .quantizer import Quantizer
+from .tile_utils import MIXED_TILE_FORMATS, flatten_2d, unflatten_2d
+
+TILE = 32
+
+
+def fmt_mask(formats) -> int:
+    m = 0
+    for f in formats:
+        m |= 1 << MIXED_TILE_FORMATS.index(f)
+    return m
+
+
+def mask_formats(mask: int) -> list[str]:
+    return [f for i, f in enumerate(MIXED_TILE_FORMATS) if mask & (1 << i)]
+
+
+def slot_of(mask: int, fmt: str) -> int:
+    i = MIXED_TILE_FORMATS.index(fmt)
+    return bin(mask & ((1 << i) - 1)).count("1")
+
+
+@dataclass
+class TileStats:
+    stats: np.ndarray          # host float64 [tiles, 2+5F]
+    mask: int
+    tiles_h: int
+    tiles_w: int
+    numel: int                 # xf.size (elem_count of mixed_tile_greedy.py:134)
+    shape_info: tuple
+    x2d: object                # host ndarray (emulation) or device tensor (hip), the 2-D flatten of xf
+    backend: str
+    input_was_numpy: bool
+
+    @property
+    def tiles(self) -> int:
+        return self.tiles_h * self.tiles_w
+
+    def block(self, fmt: str) -> np.ndarray:
+        """[tiles, 5] view: Σy, Σy², Σxy, Σ|d|, max|d| of one format."""
+        s = 2 + 5 * slot_of(self.mask, fmt)
+        return self.stats[:, s:s + 5]
+
+
+def _is_torch(x) -> bool:
+    return type(x).__module__.startswith("torch")
+
+
+def host_tile_stats(x2d: np.ndarray, formats_in_mask_order: list[str], quantizer: Quantizer) -> np.ndarray:
+    """Host definition of the stats record (NumPy).  Terms are float32 expressions summed in float64:
+    sequentially over the 16 elements of a shared-exponent group, then by a balanced binary tree over
+    the 64 groups of a tile in (2*row + half) order — the order the HIP kernel uses."""
+    h, w = x2d.shape
+    th, tw = -(-h // TILE), -(-w // TILE)
+
+    def lanes(a2d: np.ndarray) -> np.ndarray:  # (h,w) → (T, 64, 16), lane = 2*row + half
+        p = np.zeros((th * TILE, tw * TILE), dtype=np.float32)
+        p[:h, :w] = a2d
+        return p.reshape(th, TILE, tw, 2, 16).transpose(0, 2, 1, 3, 4).reshape(th * tw, 64, 16)
+
+    def reduce_sum(term: np.ndarray) -> np.ndarray:
+        acc = np.zeros(term.shape[:2], dtype=np.float64)
+        for i in range(16):
+            acc = acc + term[:, :, i].astype(np.float64)
+        while acc.shape[1] > 1:
+            acc = acc[:, 0::2] + acc[:, 1::2]
+        return acc[:, 0]
+
+    xl = lanes(x2d)
+    cols = [reduce_sum(xl), reduce_sum(xl * xl)]
+    with np.errstate(all="ignore"):
+        for fmt in formats_in_mask_order:
+            yl = lanes(np.asarray(quantizer.quantize(x2d, fmt), dtype=np.float32))
+            d = np.abs(xl - yl)
+            cols += [reduce_sum(yl), reduce_sum(yl * yl), reduce_sum(xl * yl), reduce_sum(d),
+                     d.reshape(d.shape[0], -1).max(axis=1).astype(np.float64)]
+    return np.ascontiguousarray(np.stack(cols, axis=1))
+
+
+def compute_tile_stats(xf, formats: list[str], quantizer: Quantizer) -> TileStats:
+    """One stats record per 32x32 tile of xf for the given mixed-tile formats."""
+    mask = fmt_mask(formats)
+    fm = mask_formats(mask)
+    if quantizer.backend == "hip":
+        from .. import hip_backend as hb
+
+        was_np = not _is_torch(xf)
+        x2d, info = hb.to_device_2d(xf)
+        numel = int(np.asarray(xf).size) if was_np else int(xf.numel())
+        th, tw = hb.tiles_hw(*x2d.shape)
+        stats = hb.tile_stats(x2d, mask).cpu().numpy()
+        return TileStats(stats, mask, th, tw, numel, info, x2d, "hip", was_np)
+    if _is_torch(xf):
+        xf = xf.detach().to("cpu").float().numpy()
+    xf = np.asarray(xf, dtype=np.float32)
+    x2d, info = flatten_2d(xf)
+    th, tw = -(-x2d.shape[0] // TILE), -(-x2d.shape[1] // TILE)
+    stats = host_tile_stats(x2d, fm, quantizer)
+    return TileStats(stats, mask, th, tw, int(xf.size), info, x2d, quantizer.backend, True)
+
+
+def reconstruct(ts: TileStats, assignment: np.ndarray, quantizer: Quantizer):
+    """y whose tile t uses format MIXED_TILE_FORMATS[assignment[t]] (mixed_tile_threshold.py:125-132,
+    mixed_tile_greedy.py:273,348-352).  hip: K3 on the device."""
+    a = np.asarray(assignment, dtype=np.int8).reshape(ts.tiles_h, ts.tiles_w)
+    if ts.backend == "hip":
+        from .. import hip_backend as hb
+
+        y = hb.unflatten(hb.apply_assignment(ts.x2d, a), ts.shape_info)
+        return y.cpu().numpy() if ts.input_was_numpy else y
+    h, w = ts.x2d.shape
+    sel = np.repeat(np.repeat(a, TILE, axis=0), TILE, axis=1)[:h, :w]
+    y2d = np.array(ts.x2d, dtype=np.float32, copy=True)
+    for idx in np.unique(a):
+        yq = quantizer.quantize(ts.x2d, MIXED_TILE_FORMATS[int(idx)])
+        y2d = np.where(sel == idx, yq, y2d)
+    return unflatten_2d(y2d, ts.shape_info)
+
+
+def gather_tiles(ts: TileStats, tile_ids: np.ndarray) -> np.ndarray:
+    """Zero-padded (k,32,32) float32 host copies of the named tiles of x (for knife-edge re-scoring)."""
+    out = np.zeros((len(tile_ids), TILE, TILE), dtype=np.float32)
+    h, w = ts.x2d.shape
+    for k, t in enumerate(tile_ids):
+        tr, tc = divmod(int(t), ts.tiles_w)
+        r0, c0 = tr * TILE, tc * TILE
+        blk = ts.x2d[r0:min(r0 + TILE, h), c0:min(c0 + TILE, w)]
+        if ts.backend == "hip":
+            blk = blk.float().cpu().numpy()
+        out[k, : blk.shape[0], : blk.shape[1]] = blk
+    return out
+
+
+def columns_from_stats(ts: TileStats, assignment: np.ndarray) -> dict:
+    """Tensor-level pcc / mae / atol of the reconstruction, from the float64 raw sums."""
+    from .. import hip_backend as hb
+
+    return hb.columns_from_stats(ts.stats, ts.mask, np.asarray(assignment, dtype=np.int8).reshape(-1), float(ts.numel))

@@ -1,0 +1,93 @@
+"""compression_algorithms/tile_utils.py of the reference: constants, size model, 2-D flatten/pad,
+tile gather/scatter, per-tile metrics (:8-14, :32-37, :46-57, :91-132)."""
+from __future__ import annotations
+
+import numpy as np
+
+from .metrics import metric_value, pearson_corr
+
+MIXED_TILE_FORMATS = ["bf16", "bfp8", "bfp4", "bfp2"]
+MIXED_TILE_BYTES_PER_ELEM = {
+    "bf16": 2.0,
+    "bfp8": 1.088,
+    "bfp4": 0.50097,
+    "bfp2": 0.25097,
+}
+
+
+def assignment_to_array(assignment: np.ndarray) -> np.ndarray:
+    return np.asarray(assignment, dtype=np.int8)
+
+
+def mixed_tile_total_bytes(counts: dict[str, int], tile_hw: int = 32) -> float:
+    total = 0.0
+    elems_per_tile = float(tile_hw * tile_hw)
+    for fmt, count in counts.items():
+        total += float(count) * elems_per_tile * MIXED_TILE_BYTES_PER_ELEM.get(fmt, 0.0)
+    return total
+
+
+def format_tag(formats: list[str]) -> str:
+    return "+".join(formats) if formats else "none"
+
+
+def tile_metrics(ref_tiles: np.ndarray, q_tiles: np.ndarray, metric: str) -> np.ndarray:
+    if metric == "pcc":
+        return np.asarray([pearson_corr(ref_tiles[i], q_tiles[i]) for i in range(ref_tiles.shape[0])], dtype=np.float32)
+    diff = np.abs(ref_tiles - q_tiles)
+    if metric == "mae":
+        return diff.reshape(diff.shape[0], -1).mean(axis=1)
+    if metric == "atol":
+        return diff.reshape(diff.shape[0], -1).max(axis=1)
+    raise ValueError(f"Unsupported metric: {metric}")
+
+
+def flatten_2d(xf: np.ndarray) -> tuple[np.ndarray, tuple]:
+    """The 2-D view of reshape_to_2d_with_padding (:94-107) WITHOUT the padding copy."""
+    xf = np.asarray(xf, dtype=np.float32)
+    if xf.ndim == 0:
+        return xf.reshape(1, 1), ("scalar", xf.shape)
+    if xf.ndim == 1:
+        n = xf.shape[0]
+        h = int(np.ceil(n / 32.0))
+        data2d = np.zeros((h, 32), dtype=np.float32)
+        data2d.reshape(-1)[:n] = xf.reshape(-1)
+        return data2d, ("vector", n)
+    return xf.reshape(int(np.prod(xf.shape[:-1])), xf.shape[-1]), ("nd", xf.shape)
+
+
+def reshape_to_2d_with_padding(xf: np.ndarray) -> tuple[np.ndarray, tuple, tuple]:
+    data2d, shape_info = flatten_2d(xf)
+    h, w = data2d.shape
+    h_pad = int(np.ceil(h / 32.0)) * 32
+    w_pad = int(np.ceil(w / 32.0)) * 32
+    padded = np.zeros((h_pad, w_pad), dtype=np.float32)
+    padded[:h, :w] = data2d
+    return padded, shape_info, (h, w, h_pad, w_pad)
+
+
+def to_tiles(padded: np.ndarray, tile_hw: int = 32) -> np.ndarray:
+    """(h_pad, w_pad) → (T, 32, 32), tile id = tr*tiles_w + tc (mixed_tile_greedy.py:89-93)."""
+    th, tw = padded.shape[0] // tile_hw, padded.shape[1] // tile_hw
+    return padded.reshape(th, tile_hw, tw, tile_hw).transpose(0, 2, 1, 3).reshape(-1, tile_hw, tile_hw)
+
+
+def unflatten_2d(data2d: np.ndarray, shape_info: tuple) -> np.ndarray:
+    if shape_info[0] == "scalar":
+        return np.array(data2d[0, 0], dtype=np.float32)
+    if shape_info[0] == "vector":
+        return data2d.reshape(-1)[: shape_info[1]].astype(np.float32)
+    if shape_info[0] == "nd":
+        return data2d.reshape(shape_info[1]).astype(np.float32)
+    raise ValueError("Invalid shape_info")
+
+
+def reconstruct_from_tiles(tiles: np.ndarray, shape_info: tuple, pad_info: tuple, tile_hw: int = 32) -> np.ndarray:
+    h, w, h_pad, w_pad = pad_info
+    th, tw = h_pad // tile_hw, w_pad // tile_hw
+    padded = tiles.reshape(th, tw, tile_hw, tile_hw).transpose(0, 2, 1, 3).reshape(h_pad, w_pad)
+    return unflatten_2d(padded[:h, :w], shape_info)
+
+
+def global_metric(xf: np.ndarray, tiles: np.ndarray, shape_info: tuple, pad_info: tuple, metric: str) -> float:
+    return metric_value(xf, reconstruct_from_tiles(tiles, shape_info, pad_info), metric)

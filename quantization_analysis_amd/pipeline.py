@@ -1,0 +1,138 @@
+"""Streamed multi-tensor driver of the mixed-tile-greedy hot path on one GPU.
+
+A model's matched tensors are independent (reference wq:655 loop), so a rank streams its share:
+  K1 (batched launch over a chunk of equally shaped tensors, HIP stream A)
+    → stats D2H into pinned host memory (stream A, event)
+    → per-tensor sequential greedy scan on host worker threads (C++ in libmtq_hip.so, GIL released)
+while the next chunk's K1 is already running.  y is not materialised here (assignment maps + pcc/mae/atol
+are the outputs the north star names); use compression_algorithms.* for the drop-in run() that returns y.
+"""
+from __future__ import annotations
+
+import concurrent.futures as cf
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from . import hip_backend as hb
+from .compression_algorithms.tile_utils import MIXED_TILE_FORMATS, mixed_tile_total_bytes
+
+
+@dataclass
+class TensorResult:
+    index: int
+    assignment: np.ndarray  # int8 (tiles_h, tiles_w)
+    counts: dict
+    tile_bytes: float
+    pcc: float
+    mae: float
+    atol: float
+    metric_value: float
+
+
+@dataclass
+class KernelTiming:
+    launches: int = 0
+    kernel_ms: float = 0.0      # Σ of HIP-event durations around the K1 launches
+    tiles: int = 0              # Σ tiles processed by those launches
+    events: list = field(default_factory=list)
+
+    def drain(self) -> None:
+        for e0, e1, tiles in self.events:
+            e1.synchronize()
+            self.kernel_ms += e0.elapsed_time(e1)
+            self.tiles += tiles
+            self.launches += 1
+        self.events.clear()
+
+
+def _scan_one(index, stats, mask, tiles_hw, numel, tile_formats, metric, threshold, seed) -> TensorResult:
+    scan = hb.GreedyScan(stats, mask, metric, threshold, float(numel), tile_formats[0])
+    try:
+        rng = np.random.default_rng(seed)  # mixed_tile_greedy.py:225
+        for fmt in tile_formats:
+            cand = np.where(scan.fixed() == 0)[0]
+            if cand.size == 0:
+                break
+            scan.run_pass(fmt, rng.permutation(cand))
+        a = scan.assignment()
+        counts = scan.counts()
+        cols = hb.columns_from_stats(stats, mask, a, float(numel))
+        return TensorResult(index, a.reshape(tiles_hw), counts, mixed_tile_total_bytes(counts), cols["pcc"], cols["mae"],
+                            cols["atol"], scan.value())
+    finally:
+        scan.close()
+
+
+class GreedyPipeline:
+    """mixed-tile-greedy over a (count, rows, cols) device tensor of equally shaped bf16/fp32 matrices."""
+
+    def __init__(self, tile_formats=None, metric: str = "pcc", threshold: float = 0.999, seed: int = 123,
+                 chunk: int = 8, workers: int = 8):
+        import torch
+
+        hb.require_gpu()
+        self.torch = torch
+        self.tile_formats = list(tile_formats or MIXED_TILE_FORMATS)
+        self.mask = hb.fmt_mask(self.tile_formats)
+        self.metric, self.threshold, self.seed = metric, float(threshold), int(seed)
+        if self.seed == 0:
+            raise ValueError("seed 0 means 'draw a random seed' in the reference; pass a non-zero seed")
+        self.chunk = int(chunk)
+        self.pool = cf.ThreadPoolExecutor(max_workers=int(workers))
+        self.stream = torch.cuda.Stream()
+        self.timing = KernelTiming()
+        self._bufs = {}
+
+    def _buffers(self, slot: int, n: int, tiles: int, rec: int, device):
+        key = (slot, n, tiles, rec)
+        if key not in self._bufs:
+            torch = self.torch
+            dev = torch.empty((n, tiles, rec), dtype=torch.float64, device=device)
+            host = torch.empty((n, tiles, rec), dtype=torch.float64, pin_memory=True)
+            self._bufs[key] = (dev, host)
+        return self._bufs[key]
+
+    def run(self, x3d, seeds=None) -> list[TensorResult]:
+        torch = self.torch
+        count, rows, cols = x3d.shape
+        th, tw = hb.tiles_hw(rows, cols)
+        tiles, rec = th * tw, hb.record_doubles(self.mask)
+        numel = rows * cols
+        futures = []
+        pending = []  # (event, host_buffer, first_index, n)
+        self.stream.wait_stream(torch.cuda.current_stream())
+
+        def submit(evt, host, first, n):
+            evt.synchronize()
+            h = host.numpy()
+            for j in range(n):
+                seed = self.seed if seeds is None else int(seeds[first + j])
+                futures.append(self.pool.submit(_scan_one, first + j, h[j].copy(), self.mask, (th, tw), numel,
+                                                self.tile_formats, self.metric, self.threshold, seed))
+
+        with torch.cuda.stream(self.stream):
+            for ci, first in enumerate(range(0, count, self.chunk)):
+                n = min(self.chunk, count - first)
+                dev, host = self._buffers(ci % 2, n, tiles, rec, x3d.device)
+                if len(pending) >= 2:  # the buffers of chunk ci-2 are about to be reused
+                    submit(*pending.pop(0))
+                e0 = torch.cuda.Event(enable_timing=True)
+                e1 = torch.cuda.Event(enable_timing=True)
+                e0.record(self.stream)
+                hb.tile_stats_batched(x3d[first:first + n], self.mask, out=dev)
+                e1.record(self.stream)
+                self.timing.events.append((e0, e1, n * tiles))
+                host.copy_(dev, non_blocking=True)
+                done = torch.cuda.Event()
+                done.record(self.stream)
+                pending.append((done, host, first, n))
+        for p in pending:
+            submit(*p)
+        results = [f.result() for f in futures]
+        results.sort(key=lambda r: r.index)
+        torch.cuda.current_stream().wait_stream(self.stream)
+        return results
+
+    def close(self) -> None:
+        self.pool.shutdown(wait=True)

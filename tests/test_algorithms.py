@@ -1,0 +1,224 @@
+"""The reference's plugin surface for this path (registry, Quantizer, run() result contract) on the
+host `emulation` backend (CPU tests) and on the `hip` backend (GPU tests), against the golden vectors
+and the oracle."""
+import json
+import tempfile
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from oracle import mtq_oracle as orc
+from quantization_analysis_amd import quantization_formats as qf
+from quantization_analysis_amd.compression_algorithms import (ALGORITHM_REGISTRY, CompressionResult, create_algorithm,
+                                                              load_compression_config)
+from quantization_analysis_amd.compression_algorithms.cache import CacheContext
+from quantization_analysis_amd.compression_algorithms.quantizer import Quantizer
+from quantization_analysis_amd.compression_algorithms.tile_search import compute_tile_stats
+from quantization_analysis_amd.compression_algorithms.tile_utils import (MIXED_TILE_FORMATS, mixed_tile_total_bytes,
+                                                                         reconstruct_from_tiles, reshape_to_2d_with_padding,
+                                                                         to_tiles)
+from tests.inputs import gen
+
+ALL = ["bf16", "bfp8", "bfp4", "bfp2"]
+
+
+def ctx(backend="emulation"):
+    return CacheContext(Path(tempfile.mkdtemp()), "t", backend, True, "test")
+
+
+def load_meta(golden_dir):
+    return json.loads((golden_dir / "golden_meta.json").read_text())
+
+
+# ------------------------------------------------------------------------------------------ CPU
+
+def test_registry_and_errors():
+    assert set(ALGORITHM_REGISTRY) == {"none", "mixed-tile-greedy", "mixed-tile-threshold", "mixed-tile"}
+    assert ALGORITHM_REGISTRY["mixed-tile"] is ALGORITHM_REGISTRY["mixed-tile-greedy"]
+    with pytest.raises(ValueError, match="Unsupported compression algorithm"):
+        create_algorithm("nope")
+    with pytest.raises(ValueError, match="Unsupported metric"):
+        create_algorithm("mixed-tile-greedy", {"metric": "rmse"})
+    with pytest.raises(ValueError, match="Unsupported mixed-tile format"):
+        create_algorithm("mixed-tile-threshold", {"formats": "bf16,fp0"})
+    a = create_algorithm(" Mixed-Tile-Greedy ", {"formats": "bfp8, BFP4,bfp8"})
+    assert a.tile_formats == ["bfp8", "bfp4"] and a.expected_evals(ALL) == 1
+    with pytest.raises(ValueError, match="requires at least one of"):
+        create_algorithm("mixed-tile-greedy", {"seed": 1}).run(np.ones((4, 4), np.float32), ["fp0"], Quantizer("emulation"), ctx())
+    with pytest.raises(ValueError, match="Unsupported backend"):
+        Quantizer("cuda")
+    with pytest.raises(ValueError, match="Unsupported weight format"):
+        Quantizer("emulation").quantize(np.ones(4, np.float32), "mxfp9")
+
+
+def test_formats_host_mirror_matches_golden(golden_dir):
+    d = np.load(golden_dir / "f1_quantize_kat.npz")
+    x = d["x_bits"].view(np.float32)
+    with np.errstate(all="ignore"):
+        for fmt in ALL + ["fp0"]:
+            assert np.array_equal(qf.quantize_weight_values(x, fmt).view(np.uint32), d[f"y_{fmt}"]), fmt
+    d2 = np.load(golden_dir / "f2_layouts.npz")
+    for name in sorted({k[:-2] for k in d2.files if k.endswith("_x")}):
+        for fmt in ALL:
+            got = qf.quantize_weight_values(d2[f"{name}_x"], fmt)
+            assert got.shape == d2[f"{name}_y_{fmt}"].shape
+            assert np.array_equal(got.view(np.uint32), d2[f"{name}_y_{fmt}"].view(np.uint32)), (name, fmt)
+
+
+def test_tile_utils_roundtrip():
+    for shape in [(), (33,), (50, 70), (3, 40, 48)]:
+        x = np.asarray(gen("heavy_f32", 1, shape if shape else (1,))[0] if not shape else gen("heavy_f32", 1, shape))
+        padded, info, pad = reshape_to_2d_with_padding(x)
+        assert padded.shape[0] % 32 == 0 and padded.shape[1] % 32 == 0
+        back = reconstruct_from_tiles(to_tiles(padded), info, pad)
+        assert back.shape == x.shape and np.array_equal(back, x)
+    assert mixed_tile_total_bytes({"bf16": 0, "bfp8": 0, "bfp4": 128088, "bfp2": 936}) == 128088 * 1024 * 0.50097 + 936 * 1024 * 0.25097
+
+
+def test_host_stats_equal_oracle_stats():
+    q = Quantizer("emulation")
+    for kind, shape in (("normal_bf16", (96, 128)), ("heavy_f32", (50, 70)), ("heavy_f32", (1003,))):
+        x = gen(kind, 3, shape)
+        ts = compute_tile_stats(x, ALL, q)
+        want = orc.tile_stats(orc.flatten_2d(x)[0], ALL)
+        assert np.array_equal(ts.stats.view(np.uint64), want.view(np.uint64)), (kind, shape)
+
+
+def _run_greedy_cases(golden_dir, quantizer, to_input=lambda x: x):
+    d = np.load(golden_dir / "f4_greedy.npz")
+    for name, m in load_meta(golden_dir)["f4"].items():
+        x = gen(m["kind"], m["seed"], tuple(m["shape"]))
+        algo = create_algorithm("mixed-tile-greedy", {"metric": m["metric"], "threshold": m["threshold"],
+                                                      "seed": m["algo_seed"], "formats": m["formats"]})
+        res = algo.run(to_input(x), m["formats"], quantizer, ctx(quantizer.backend))
+        assert len(res) == 1 and isinstance(res[0], CompressionResult)
+        r = res[0]
+        assert r.fmt == "MIXED" and r.compression == "mixed-tile-greedy"
+        a = r.meta["assignment"]
+        assert a.dtype == np.int8 and np.array_equal(a, d[f"{name}_assign"]), name
+        assert [r.tile_counts[f] for f in ALL] == list(d[f"{name}_counts"]), name
+        cols = d[f"{name}_cols"]
+        assert r.tile_bytes == cols[3]
+        y = r.y.cpu().numpy() if hasattr(r.y, "cpu") else r.y
+        assert y.shape == x.shape and y.dtype == np.float32
+        if f"{name}_y" in d.files:
+            assert np.array_equal(y.view(np.uint32), d[f"{name}_y"].view(np.uint32)), name
+        assert orc.sha(y) == m["y_sha256"] if hasattr(orc, "sha") else True
+        tol = 1e-6 if x.size <= 65536 else 2e-5  # reference float32 pcc noise above 256x256
+        c = r.meta["columns"]
+        assert abs(c["pcc"] - cols[0]) <= tol and abs(c["mae"] - cols[1]) <= 1e-6 and abs(c["atol"] - cols[2]) <= 1e-6, name
+
+
+def _run_threshold_cases(golden_dir, quantizer, to_input=lambda x: x):
+    d = np.load(golden_dir / "f5_threshold.npz")
+    knife = 0
+    for name, m in load_meta(golden_dir)["f5"].items():
+        x = d[f"{name}_x"]
+        algo = create_algorithm("mixed-tile-threshold", {"metric": m["metric"], "threshold": m["threshold"], "formats": m["formats"]})
+        r = algo.run(to_input(x), m["formats"], quantizer, ctx(quantizer.backend))[0]
+        assert r.compression == "mixed-tile-threshold"
+        assert np.array_equal(r.meta["assignment"], d[f"{name}_assign"]), name
+        assert [r.tile_counts[f] for f in ALL] == list(d[f"{name}_counts"]), name
+        y = r.y.cpu().numpy() if hasattr(r.y, "cpu") else r.y
+        assert np.array_equal(y.view(np.uint32), d[f"{name}_y"].view(np.uint32)), name
+        cols = d[f"{name}_cols"]
+        c = r.meta["columns"]
+        assert r.tile_bytes == cols[3]
+        assert abs(c["pcc"] - cols[0]) <= 1e-6 and abs(c["mae"] - cols[1]) <= 1e-6 and abs(c["atol"] - cols[2]) <= 1e-6, name
+        knife += r.meta["knife_edge_tiles"]
+    assert knife >= 2
+
+
+def test_greedy_emulation_backend(golden_dir):
+    _run_greedy_cases(golden_dir, Quantizer("emulation"))
+
+
+def test_threshold_emulation_backend(golden_dir):
+    _run_threshold_cases(golden_dir, Quantizer("emulation"))
+
+
+def test_empty_and_degenerate_inputs():
+    q = Quantizer("emulation")
+    for name in ("mixed-tile-greedy", "mixed-tile-threshold"):
+        r = create_algorithm(name, {"seed": 5}).run(np.zeros((0, 8), np.float32), ALL, q, ctx())[0]
+        assert r.y.shape == (0, 8) and r.meta["assignment"].shape == (1, 1) and sum(r.tile_counts.values()) == 0
+        # all-zero tensor: denom == 0 and |x-y| == 0 → pcc 1.0 → everything demotes to the last format
+        r = create_algorithm(name, {"seed": 5, "threshold": 0.999}).run(np.zeros((40, 40), np.float32), ALL, q, ctx())[0]
+        assert r.tile_counts["bfp2"] == 4 and np.all(r.y == 0)
+        # constant tensor (layernorm-weight-like): denom == 0, error decides (metrics.py:14-15)
+        r = create_algorithm(name, {"seed": 5, "threshold": 0.999}).run(np.full((64,), 0.3, np.float32), ALL, q, ctx())[0]
+        ref_a, _c, _ = (orc.greedy if name.endswith("greedy") else orc.threshold)(np.full((64,), 0.3, np.float32), ALL, "pcc", 0.999, *((5,) if name.endswith("greedy") else ()))
+        assert np.array_equal(r.meta["assignment"], ref_a)
+
+
+def test_none_baseline_and_cache(tmp_path):
+    q = Quantizer("emulation")
+    x = gen("normal_f32", 1, (40, 48))
+    c = CacheContext(tmp_path, "model.layers.0.w", "emulation", False, "r")
+    res = create_algorithm("none").run(x, ["bf16", "bfp8", "fp0"], q, c)
+    assert [r.fmt for r in res] == ["BF16", "BFP8", "FP0"]
+    assert c.quant_path("none", "bfp8").exists() and "/none/emulation/bfp8/" in str(c.quant_path("none", "bfp8"))
+    res2 = create_algorithm("none").run(x, ["bfp8"], q, c)  # served from the cache
+    assert np.array_equal(res2[0].y, res[1].y)
+    assert np.array_equal(res[1].y, orc.quantize_weight_values(x, "bfp8"))
+
+
+def test_config_loader(tmp_path):
+    p = tmp_path / "c.json"
+    p.write_text(json.dumps({"algorithm": "Mixed-Tile-Greedy", "quantization_formats": ["bf16", "BFP8", ""], "seed": 0,
+                             "params": {"metric": "pcc", "threshold": 0.999}}))
+    cfg = load_compression_config(str(p))
+    assert cfg.algorithm == "mixed-tile-greedy" and cfg.quantization_formats == ["bf16", "bfp8"]
+    assert cfg.seed is None and cfg.random_seed is True
+    p.write_text(json.dumps({"algorithm": "mixed-tile-threshold", "seed": "random"}))
+    assert load_compression_config(str(p)).random_seed is True
+    p.write_text(json.dumps({"algorithm": "none", "seed": 17}))
+    cfg = load_compression_config(str(p))
+    assert cfg.seed == 17 and cfg.random_seed is False
+    assert load_compression_config(None).algorithm == "none"
+    with pytest.raises(FileNotFoundError):
+        load_compression_config(str(tmp_path / "missing.json"))
+    p.write_text("[1]")
+    with pytest.raises(ValueError):
+        load_compression_config(str(p))
+
+
+# ------------------------------------------------------------------------------------------ GPU
+
+@pytest.mark.gpu
+def test_greedy_hip_backend_numpy_in(golden_dir):
+    _run_greedy_cases(golden_dir, Quantizer("hip"))
+
+
+@pytest.mark.gpu
+def test_threshold_hip_backend_numpy_in(golden_dir):
+    _run_threshold_cases(golden_dir, Quantizer("hip"))
+
+
+@pytest.mark.gpu
+def test_hip_backend_device_tensor_in(golden_dir):
+    import torch
+
+    _run_threshold_cases(golden_dir, Quantizer("hip"), to_input=lambda x: torch.from_numpy(x).cuda())
+    # bf16 storage of bf16-valued data gives the same map as its fp32 view
+    x = gen("normal_bf16", 1, (256, 256))
+    q = Quantizer("hip")
+    p = {"metric": "pcc", "threshold": 0.999, "seed": 123}
+    a32 = create_algorithm("mixed-tile-greedy", p).run(x, ALL, q, ctx("hip"))[0]
+    a16 = create_algorithm("mixed-tile-greedy", p).run(torch.from_numpy(x).cuda().to(torch.bfloat16), ALL, q, ctx("hip"))[0]
+    assert np.array_equal(a32.meta["assignment"], a16.meta["assignment"])
+    assert np.array_equal(a16.y.cpu().numpy().view(np.uint32), a32.y.view(np.uint32))
+
+
+@pytest.mark.gpu
+def test_hip_quantizer_and_none(tmp_path):
+    q = Quantizer("hip")
+    x = gen("heavy_f32", 2, (3, 40, 48))
+    for fmt in ALL + ["fp0"]:
+        assert np.array_equal(q.quantize(x, fmt).view(np.uint32), orc.quantize_weight_values(x, fmt).view(np.uint32)), fmt
+    with pytest.raises(ValueError):
+        q.quantize(x, "mxfp4")
+    res = create_algorithm("none").run(x, ["bfp4"], q, CacheContext(tmp_path, "t", "hip", False, "r"))
+    assert "/none/hip/bfp4/" in str(CacheContext(tmp_path, "t", "hip", False, "r").quant_path("none", "bfp4"))
+    assert np.array_equal(res[0].y, orc.quantize_weight_values(x, "bfp4"))

@@ -6,7 +6,7 @@
 #include <vector>
 #include <string>
 
-#define ITER 2048
+#define ITER 8192
 typedef short v2s __attribute__((ext_vector_type(2)));
 typedef unsigned short v2us __attribute__((ext_vector_type(2)));
 
@@ -57,6 +57,42 @@ typedef unsigned short v2us __attribute__((ext_vector_type(2)));
 #define B_CVTF32U32(a) asm volatile("v_cvt_f32_u32 %0, %0" : "+v"(a));
 #define B_CMPSEL(a) asm volatile("v_cmp_gt_u32 vcc, %0, %1\n\tv_cndmask_b32 %0, %0, %1, vcc" : "+v"(a) : "v"(b) : "vcc");
 
+
+#define B_AND(a) asm volatile("v_and_b32 %0, %0, %1" : "+v"(a) : "v"(b));
+#define B_OR(a) asm volatile("v_or_b32 %0, %0, %1" : "+v"(a) : "v"(b));
+#define B_XOR(a) asm volatile("v_xor_b32 %0, %0, %1" : "+v"(a) : "v"(b));
+#define B_LSHL(a) asm volatile("v_lshlrev_b32 %0, 3, %0" : "+v"(a));
+#define B_LSHRV(a) asm volatile("v_lshrrev_b32 %0, %1, %0" : "+v"(a) : "v"(b));
+#define B_ASHR(a) asm volatile("v_ashrrev_i32 %0, 3, %0" : "+v"(a));
+#define B_SUB(a) asm volatile("v_sub_u32 %0, %0, %1" : "+v"(a) : "v"(b));
+#define B_MAXU(a) asm volatile("v_max_u32 %0, %0, %1" : "+v"(a) : "v"(b));
+#define B_MINI(a) asm volatile("v_min_i32 %0, %0, %1" : "+v"(a) : "v"(b));
+#define B_CNDMASK(a) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a) : "v"(b) : );
+#define B_MULF32(a) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(a) : "v"(b));
+#define B_FMACF32(a) asm volatile("v_fmac_f32 %0, %1, %1" : "+v"(a) : "v"(b));
+#define B_MAXF32(a) asm volatile("v_max_f32 %0, %0, %1" : "+v"(a) : "v"(b));
+#define B_MULU24(a) asm volatile("v_mul_u32_u24 %0, %0, %1" : "+v"(a) : "v"(b));
+#define B_DOT2C(a) asm volatile("v_dot2c_i32_i16 %0, %1, %1" : "+v"(a) : "v"(b));
+#define B_DOT4C(a) asm volatile("v_dot4c_i32_i8 %0, %1, %1" : "+v"(a) : "v"(b));
+#define B_PKFMAC16(a) asm volatile("v_pk_fmac_f16 %0, %1, %1" : "+v"(a) : "v"(b));
+#define B_ADDSDWA(a) asm volatile("v_add_u32_sdwa %0, %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "+v"(a) : "v"(b));
+#define B_ADDU16(a) asm volatile("v_add_u16 %0, %0, %1" : "+v"(a) : "v"(b));
+#define B_MAX3(a) asm volatile("v_max3_u32 %0, %0, %1, %2" : "+v"(a) : "v"(b), "v"(c));
+#define B_LSHLOR(a) asm volatile("v_lshl_or_b32 %0, %0, 3, %1" : "+v"(a) : "v"(b));
+#define B_LSHLADD(a) asm volatile("v_lshl_add_u32 %0, %0, 3, %1" : "+v"(a) : "v"(b));
+#define B_BFI(a) asm volatile("v_bfi_b32 %0, %1, %0, %2" : "+v"(a) : "v"(b), "v"(c));
+#define B_ALIGNBIT(a) asm volatile("v_alignbit_b32 %0, %0, %1, 7" : "+v"(a) : "v"(b));
+#define B_FFBH(a) asm volatile("v_ffbh_u32 %0, %0" : "+v"(a));
+#define B_MOV(a) asm volatile("v_mov_b32 %0, %1" : "=v"(a) : "v"(b));
+#define B_CVTF32BF(a) asm volatile("v_cvt_pk_bf16_f32 %0, %0, %1" : "+v"(a) : "v"(b));
+#define B_ADDDPPSHR(a) asm volatile("v_add_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(a));
+#define B_PKADDF32(a) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(a) : "v"(b));
+#define B_PKMULF32(a) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(a) : "v"(b));
+#define B_PKSUBI16(a) asm volatile("v_pk_sub_i16 %0, %0, %1" : "+v"(a) : "v"(b));
+#define B_PKASHR(a) asm volatile("v_pk_ashrrev_i16 %0, 3, %0" : "+v"(a));
+#define B_PKMIN(a) asm volatile("v_pk_min_u16 %0, %0, %1" : "+v"(a) : "v"(b));
+#define B_DOT2F32BF16(a) asm volatile("v_dot2_f32_bf16 %0, %1, %1, %0" : "+v"(a) : "v"(b));
+#define B_SWAP32(a) asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
 KERNEL(add_u32, uint32_t, , B_ADDU32)
 KERNEL(pk_add_u16, uint32_t, , B_PKADD)
 KERNEL(pk_lshrrev_b16, uint32_t, , B_PKSHR)
@@ -91,6 +127,20 @@ KERNEL(cvt_f64_u32, double, int ib = (int)threadIdx.x, B_CVTF64U32)
 KERNEL(cvt_f64_f32, double, float ib = (float)threadIdx.x, B_CVTF64F32)
 KERNEL(mad_u64_u32, uint64_t, uint32_t ib = threadIdx.x, B_MADU64)
 KERNEL(lshlrev_b64, uint64_t, uint32_t ib = threadIdx.x & 1, B_LSHL64)
+
+
+KERNEL(and_b32, uint32_t, , B_AND) KERNEL(or_b32, uint32_t, , B_OR) KERNEL(xor_b32, uint32_t, , B_XOR)
+KERNEL(lshlrev_b32_imm, uint32_t, , B_LSHL) KERNEL(lshrrev_b32_v, uint32_t, , B_LSHRV) KERNEL(ashrrev_i32, uint32_t, , B_ASHR)
+KERNEL(sub_u32, uint32_t, , B_SUB) KERNEL(max_u32, uint32_t, , B_MAXU) KERNEL(min_i32, uint32_t, , B_MINI)
+KERNEL(cndmask, uint32_t, , B_CNDMASK) KERNEL(mul_f32, float, , B_MULF32) KERNEL(fmac_f32, float, , B_FMACF32)
+KERNEL(max_f32, float, , B_MAXF32) KERNEL(mul_u32_u24, uint32_t, , B_MULU24) KERNEL(dot2c_i32_i16, uint32_t, , B_DOT2C)
+KERNEL(dot4c_i32_i8, uint32_t, , B_DOT4C) KERNEL(pk_fmac_f16, uint32_t, , B_PKFMAC16) KERNEL(add_u32_sdwa, uint32_t, , B_ADDSDWA)
+KERNEL(add_u16, uint32_t, , B_ADDU16) KERNEL(max3_u32, uint32_t, uint32_t c = b * 7u, B_MAX3) KERNEL(lshl_or_b32, uint32_t, , B_LSHLOR)
+KERNEL(lshl_add_u32, uint32_t, , B_LSHLADD) KERNEL(bfi_b32, uint32_t, uint32_t c = b * 7u, B_BFI) KERNEL(alignbit_b32, uint32_t, , B_ALIGNBIT)
+KERNEL(ffbh_u32, uint32_t, , B_FFBH) KERNEL(mov_b32, uint32_t, , B_MOV) KERNEL(cvt_pk_bf16_f32, float, , B_CVTF32BF)
+KERNEL(add_f32_dpp, float, , B_ADDDPPSHR) KERNEL(pk_add_f32, double, , B_PKADDF32) KERNEL(pk_mul_f32, double, , B_PKMULF32)
+KERNEL(pk_sub_i16, uint32_t, , B_PKSUBI16) KERNEL(pk_ashrrev_i16, uint32_t, , B_PKASHR) KERNEL(pk_min_u16, uint32_t, , B_PKMIN)
+KERNEL(dot2_f32_bf16, float, , B_DOT2F32BF16) KERNEL(permlane32_swap, uint32_t, , B_SWAP32)
 
 template <typename T, typename K>
 static void run(const char *name, K kern, int waves_per_simd, int insts_per_body = 1)
@@ -135,5 +185,12 @@ int main()
     RUN2(add_f32, float) RUN2(fma_f32, float) RUN2(pk_fma_f32, double)
     RUN(add_f64, double) RUN2(fma_f64, double) RUN2(mul_f64, double) RUN2(ldexp_f64, double)
     RUN2(cvt_f64_i32, double) RUN2(cvt_f64_u32, double) RUN2(cvt_f64_f32, double) RUN2(mad_u64_u32, uint64_t) RUN2(lshlrev_b64, uint64_t)
+    RUN2(and_b32, uint32_t) RUN2(or_b32, uint32_t) RUN2(xor_b32, uint32_t) RUN2(lshlrev_b32_imm, uint32_t) RUN2(lshrrev_b32_v, uint32_t)
+    RUN2(ashrrev_i32, uint32_t) RUN2(sub_u32, uint32_t) RUN2(max_u32, uint32_t) RUN2(min_i32, uint32_t) RUN2(cndmask, uint32_t)
+    RUN2(mul_f32, float) RUN2(fmac_f32, float) RUN2(max_f32, float) RUN2(mul_u32_u24, uint32_t) RUN2(dot2c_i32_i16, uint32_t)
+    RUN2(dot4c_i32_i8, uint32_t) RUN2(pk_fmac_f16, uint32_t) RUN2(add_u32_sdwa, uint32_t) RUN2(add_u16, uint32_t) RUN2(max3_u32, uint32_t)
+    RUN2(lshl_or_b32, uint32_t) RUN2(lshl_add_u32, uint32_t) RUN2(bfi_b32, uint32_t) RUN2(alignbit_b32, uint32_t) RUN2(ffbh_u32, uint32_t)
+    RUN2(mov_b32, uint32_t) RUN2(cvt_pk_bf16_f32, float) RUN2(add_f32_dpp, float) RUN2(pk_add_f32, double) RUN2(pk_mul_f32, double)
+    RUN2(pk_sub_i16, uint32_t) RUN2(pk_ashrrev_i16, uint32_t) RUN2(pk_min_u16, uint32_t) RUN2(dot2_f32_bf16, float) RUN2(permlane32_swap, uint32_t)
     return 0;
 }
