@@ -58,6 +58,10 @@ def lib() -> ctypes.CDLL:
             f"{LIB_PATH} is missing: build it with `make -C {_PKG / 'csrc'}` (hipcc --offload-arch=gfx950). "
             "The hip backend has no CPU fallback."
         )
+    # PyTorch-ROCm bundles its own libamdhip64; it must be the ONE HIP runtime of the process, so torch is
+    # imported before libmtq_hip.so resolves its libamdhip64.so dependency (two runtimes → "no usable device").
+    import torch  # noqa: F401
+
     L = ctypes.CDLL(str(LIB_PATH))
     vp, i64, u32, ci, dbl = ctypes.c_void_p, ctypes.c_int64, ctypes.c_uint32, ctypes.c_int, ctypes.c_double
     L.mtq_version.restype = ci
