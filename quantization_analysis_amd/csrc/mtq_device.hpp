@@ -106,4 +106,43 @@ __device__ __forceinline__ uint32_t group_shared_exp(const uint32_t u[kGroup])
     return m >> 23;
 }
 
+
+// Stats terms of ONE shared-exponent group by the literal route: uint32 quantisation per format,
+// float32 terms (x*x, y*y, x*y, |x-y|) summed sequentially in float64.  t[0..1] = Σx, Σx²;
+// t[2+5f .. 6+5f] = Σy, Σy², Σxy, Σ|x−y|, max|x−y| of format f (bf16, bfp8, bfp4, bfp2); formats
+// outside fmt_mask are left 0.  Reference: mixed_tile_greedy.py:158-164,250-254 (terms),
+// quantization_formats.py:84-164 (y).  Shared by the generic kernel and by the fast kernel's fallback.
+__device__ __forceinline__ void group_terms_literal(const uint32_t u[kGroup], uint32_t fmt_mask, double t[2 + 5 * kNumFmt])
+{
+    const uint32_t shared = group_shared_exp(u);
+    double sx = 0.0, sx2 = 0.0;
+#pragma unroll
+    for (int i = 0; i < kGroup; ++i) {
+        const float xv = __uint_as_float(u[i]);
+        const float p = xv * xv;
+        sx += (double)xv;
+        sx2 += (double)p;
+    }
+    t[0] = sx;
+    t[1] = sx2;
+#pragma unroll
+    for (int f = 0; f < kNumFmt; ++f) {
+        double sy = 0.0, sy2 = 0.0, sxy = 0.0, sab = 0.0, mx = 0.0;
+        if (fmt_mask & (1u << f)) { // wave-uniform
+#pragma unroll
+            for (int i = 0; i < kGroup; ++i) {
+                const float xv = __uint_as_float(u[i]);
+                const float yv = __uint_as_float(quant_elem_bits(f, u[i], shared));
+                const float p2 = yv * yv, pxy = xv * yv, df = fabsf(xv - yv);
+                sy += (double)yv;
+                sy2 += (double)p2;
+                sxy += (double)pxy;
+                sab += (double)df;
+                mx = nanmax(mx, (double)df);
+            }
+        }
+        t[2 + 5 * f] = sy; t[3 + 5 * f] = sy2; t[4 + 5 * f] = sxy; t[5 + 5 * f] = sab; t[6 + 5 * f] = mx;
+    }
+}
+
 } // namespace mtq

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 
 #include "../../include/mtq.h"
 #include "mtq_device.hpp"
@@ -33,40 +34,8 @@ __global__ __launch_bounds__(256) void tile_stats_generic(const T *__restrict__ 
 
     uint32_t u[kGroup];
     Loader<T>::group(xb, tr * kTile + (lane >> 1), tc * kTile + (lane & 1) * kGroup, rows, cols, ld, vec_ok != 0, u);
-    const uint32_t shared = group_shared_exp(u);
-
-    double acc[2 + 5 * kNumFmt];
-    {
-        double sx = 0.0, sx2 = 0.0;
-#pragma unroll
-        for (int i = 0; i < kGroup; ++i) {
-            const float xv = __uint_as_float(u[i]);
-            const float p = xv * xv;
-            sx += (double)xv;
-            sx2 += (double)p;
-        }
-        acc[0] = sx;
-        acc[1] = sx2;
-    }
-#pragma unroll
-    for (int f = 0; f < kNumFmt; ++f) {
-        double sy = 0.0, sy2 = 0.0, sxy = 0.0, sab = 0.0, mx = 0.0;
-        if (fmt_mask & (1u << f)) { // wave-uniform
-#pragma unroll
-            for (int i = 0; i < kGroup; ++i) {
-                const float xv = __uint_as_float(u[i]);
-                const float yv = __uint_as_float(quant_elem_bits(f, u[i], shared));
-                const float p2 = yv * yv, pxy = xv * yv, df = fabsf(xv - yv);
-                sy += (double)yv;
-                sy2 += (double)p2;
-                sxy += (double)pxy;
-                sab += (double)df;
-                mx = nanmax(mx, (double)df);
-            }
-        }
-        // registers are indexed by FORMAT (static); the record is compacted when it is written
-        acc[2 + 5 * f] = sy; acc[3 + 5 * f] = sy2; acc[4 + 5 * f] = sxy; acc[5 + 5 * f] = sab; acc[6 + 5 * f] = mx;
-    }
+    double acc[2 + 5 * kNumFmt]; // registers are indexed by FORMAT (static); the record is compacted when written
+    group_terms_literal(u, fmt_mask, acc);
 
 #pragma unroll
     for (int k = 0; k < 2 + 5 * kNumFmt; ++k) {
@@ -146,6 +115,17 @@ static int check_matrix(const void *x, int in_dtype, int64_t rows, int64_t cols,
 
 using namespace mtq;
 
+extern "C" int mtq_launch_tile_stats_bf16_fast(const void *x, int64_t count, int64_t stride_elems, int64_t rows, int64_t cols,
+                                               int64_t ld, uint32_t fmt_mask, double *stats, void *stream);
+
+// MTQ_FORCE_GENERIC=1 routes every input through tile_stats_generic (A/B checks of the fast kernel).
+static bool force_generic()
+{
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("MTQ_FORCE_GENERIC"); v = (e && e[0] == '1') ? 1 : 0; }
+    return v == 1;
+}
+
 extern "C" size_t mtq_stats_record_doubles(uint32_t fmt_mask) { return 2 + 5 * (size_t)__builtin_popcount(fmt_mask & MTQ_MASK_ALL); }
 
 extern "C" int mtq_tile_stats_batched(const void *x, int in_dtype, int64_t count, int64_t stride_elems, int64_t rows,
@@ -161,6 +141,9 @@ extern "C" int mtq_tile_stats_batched(const void *x, int in_dtype, int64_t count
     const int rec = (int)mtq_stats_record_doubles(fmt_mask);
     const int64_t esz = in_dtype == MTQ_DTYPE_BF16 ? 2 : 4;
     const int vec_ok = aligned16(x) && (ld * esz) % 16 == 0 && (stride_elems * esz) % 16 == 0;
+    // bf16 storage, whole 32x128 units, 16-byte aligned rows, at least one BFP format → exact-integer fast kernel
+    if (in_dtype == MTQ_DTYPE_BF16 && vec_ok && rows % kTile == 0 && cols % 128 == 0 && (fmt_mask & 0xEu) != 0 && !force_generic())
+        return mtq_launch_tile_stats_bf16_fast(x, count, stride_elems, rows, cols, ld, fmt_mask, stats, stream);
     const int64_t blocks = (count * tiles + 3) / 4;
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (in_dtype == MTQ_DTYPE_BF16)

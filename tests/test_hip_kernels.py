@@ -17,8 +17,9 @@ ALL = ["bf16", "bfp8", "bfp4", "bfp2"]
 
 
 def dev(x: np.ndarray, bf16: bool = False):
-    t = torch.from_numpy(np.ascontiguousarray(x)).cuda()
-    return t.to(torch.bfloat16) if bf16 else t
+    """Upload x; bf16=True converts ON THE HOST first (the device cast canonicalises NaN signs/payloads)."""
+    t = torch.from_numpy(np.ascontiguousarray(x))
+    return t.to(torch.bfloat16).cuda() if bf16 else t.cuda()
 
 
 def bits(t) -> np.ndarray:
@@ -131,3 +132,50 @@ def test_greedy_maps_from_gpu_stats_match_golden(golden_dir):
         ref = d[f"{name}_cols"]
         tol = 1e-6 if x.size <= 65536 else 2e-5  # the reference's float32 pcc is noisy above 256x256
         assert abs(cols["pcc"] - ref[0]) <= tol and abs(cols["mae"] - ref[1]) <= 1e-6 and abs(cols["atol"] - ref[2]) <= 1e-6, name
+
+
+@pytest.mark.parametrize("kind,shape,scale", [
+    ("normal_bf16", (32, 128), 1.0), ("heavy_bf16", (96, 256), 1.0), ("heavy_bf16", (64, 384), 2.0 ** 30),
+    ("heavy_bf16", (64, 128), 2.0 ** -60), ("normal_bf16", (128, 4096), 1.0), ("heavy_bf16", (32, 128), 2.0 ** 70),
+])
+def test_fast_bf16_kernel_bit_exact(kind, shape, scale):
+    """bf16 storage with whole 32x128 units takes tile_stats_bf16_fast (exact-integer route); its records
+    must equal the oracle's literal float32-term / float64-sum records bit for bit, for every mask."""
+    x = (gen(kind, 77, shape) * np.float32(scale)).astype(np.float32)
+    xb = dev(x, bf16=True)
+    for fm in (ALL, ["bfp8", "bfp4", "bfp2"], ["bf16", "bfp4"], ["bfp2"]):
+        want = orc.tile_stats(x, fm)
+        got = hb.tile_stats(xb, hb.fmt_mask(fm)).cpu().numpy()
+        assert np.array_equal(got.view(np.uint64), want.view(np.uint64)), (kind, shape, scale, fm)
+
+
+def test_fast_bf16_kernel_fallback_groups():
+    """Groups the exact-integer route cannot take (zeros, values > 15 binades below the group maximum,
+    denormals, Inf/NaN, huge/tiny exponents) must come out identical through the literal fallback."""
+    rng = np.random.default_rng(3)
+    x = gen("heavy_bf16", 5, (64, 256)).copy()
+    x[0, :16] = 0.0                                    # all-zero group
+    x[1, 3] = 0.0                                      # one exact zero
+    x[2, 16:32] = x[2, 16:32] * np.float32(2.0 ** -20) # tiny group next to a normal one
+    x[3, 5] = np.float32(2.0 ** -40)                   # element 16+ binades below the maximum
+    x[4, :16] = np.float32(1e-40)                      # bf16 denormals
+    x[5, 7] = np.inf
+    x[6, 9] = np.nan
+    x[7, :16] = np.float32(3.0e38)
+    x[8, :16] = np.float32(2.0 ** -100)
+    x[9, 16:32] = np.where(rng.random(16) < 0.5, 0.0, x[9, 16:32])
+    x[40:, 128:] = 0.0                                 # zero tile block
+    xb = torch.from_numpy(x).to(torch.bfloat16)       # host cast; the oracle sees exactly these bf16 values
+    x = xb.float().numpy()
+    with np.errstate(all="ignore"):
+        want = orc.tile_stats(x, ALL)
+    got = hb.tile_stats(xb.cuda(), 0xF).cpu().numpy()
+    both_nan = np.isnan(want) & np.isnan(got)
+    assert np.array_equal(np.where(both_nan, 0, got.view(np.uint64)), np.where(both_nan, 0, want.view(np.uint64)))
+
+
+def test_fast_and_generic_kernels_agree_batched():
+    xs = np.stack([gen("normal_bf16", s, (64, 256)) for s in range(6)])
+    got = hb.tile_stats_batched(dev(xs, bf16=True), 0xF).cpu().numpy()
+    for i in range(6):
+        assert np.array_equal(got[i].view(np.uint64), orc.tile_stats(xs[i], ALL).view(np.uint64)), i
