@@ -125,9 +125,9 @@ static inline double orc_nanmax(double m, double d) { return (d > m || d != d) ?
  * Every term is a float32 expression (x*x, y*y, x*y, |x−y| rounded to float32) summed in
  * float64, as `np.sum(x_view * y_view, dtype=np.float64)` does (mixed_tile_greedy.py:158-164).
  * SUMMATION ORDER (ours; numpy's pairwise order is not reproduced — SURVEY §7.3-3): within one
- * 16-element group sequentially; the 64 groups of a tile (lane = 2*row + half) are combined by a
- * balanced binary tree over lane index (adjacent lanes first), which is what a wave64 xor-butterfly
- * computes.  The HIP kernel follows the same order, so stats compare bit-for-bit.
+ * 16-element group sequentially; the four groups of a row pair (rows 2j, 2j+1; row-major) sequentially;
+ * the 16 row-pair sums of a tile by a balanced binary tree over j (adjacent pairs first).
+ * The HIP kernels follow the same order, so stats compare bit-for-bit.
  */
 void orc_tile_stats(const float *x, int64_t rows, int64_t cols, uint32_t fmt_mask, double *stats)
 {
@@ -163,7 +163,19 @@ void orc_tile_stats(const float *x, int64_t rows, int64_t cols, uint32_t fmt_mas
                 b[0] = sy; b[1] = sy2; b[2] = sxy; b[3] = sab; b[4] = mx;
             }
         }
-        for (int step = 1; step < 64; step <<= 1)
+        /* lanes 4j..4j+3 = the four groups of rows 2j, 2j+1: summed sequentially into lane 4j */
+        for (int l = 0; l < 64; l += 4)
+            for (int g = 1; g < 4; ++g) {
+                double *a = lane[l], *b = lane[l + g];
+                a[0] += b[0]; a[1] += b[1];
+                for (int k = 0; k < nf; ++k) {
+                    double *p = a + 2 + 5 * k, *q = b + 2 + 5 * k;
+                    p[0] += q[0]; p[1] += q[1]; p[2] += q[2]; p[3] += q[3];
+                    p[4] = orc_nanmax(p[4], q[4]);
+                }
+            }
+        /* balanced binary tree over the 16 row pairs */
+        for (int step = 4; step < 64; step <<= 1)
             for (int l = 0; l < 64; l += 2 * step) {
                 double *a = lane[l], *b = lane[l + step];
                 a[0] += b[0]; a[1] += b[1];

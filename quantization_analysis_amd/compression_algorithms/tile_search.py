@@ -68,8 +68,8 @@ def _is_torch(x) -> bool:
 
 def host_tile_stats(x2d: np.ndarray, formats_in_mask_order: list[str], quantizer: Quantizer) -> np.ndarray:
     """Host definition of the stats record (NumPy).  Terms are float32 expressions summed in float64:
-    sequentially over the 16 elements of a shared-exponent group, then by a balanced binary tree over
-    the 64 groups of a tile in (2*row + half) order — the order the HIP kernel uses."""
+    sequentially over the 16 elements of a shared-exponent group, sequentially over the 4 groups of a row
+    pair (rows 2j, 2j+1), then by a balanced binary tree over the 16 row pairs — the order the HIP kernels use."""
     h, w = x2d.shape
     th, tw = -(-h // TILE), -(-w // TILE)
 
@@ -82,7 +82,8 @@ def host_tile_stats(x2d: np.ndarray, formats_in_mask_order: list[str], quantizer
         acc = np.zeros(term.shape[:2], dtype=np.float64)
         for i in range(16):
             acc = acc + term[:, :, i].astype(np.float64)
-        while acc.shape[1] > 1:
+        acc = ((acc[:, 0::4] + acc[:, 1::4]) + acc[:, 2::4]) + acc[:, 3::4]  # the 4 groups of a row pair, sequentially
+        while acc.shape[1] > 1:                                               # 16 row pairs: balanced tree
             acc = acc[:, 0::2] + acc[:, 1::2]
         return acc[:, 0]
 

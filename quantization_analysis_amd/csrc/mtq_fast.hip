@@ -12,15 +12,17 @@
 //     Σx = (256·Σ±a + Σ±b) · 2^(E−149)            Σx² = (65536·Σa² + Σb²) · 2^(2E−298)
 // An exact integer times a power of two is exactly the float64 the literal route (sequential float64 sum
 // of the float32 terms) produces, so the records are bit-identical to tile_stats_generic / the oracle.
-// Groups outside the preconditions (E ∉ [80,180], an element more than 15 binades below the maximum —
-// that includes exact zeros — or Σb ≥ 2^16) take group_terms_literal() instead; rare in real weights.
+// A group outside the preconditions (E ∉ [80,180], an element more than 15 binades below the maximum —
+// that includes exact zeros — or Σb ≥ 2^16) marks its tile; the marked tiles (rare in real weights) are
+// recomputed by the literal route in a follow-up launch (tile_stats_redo_flagged, mtq_kernels.hip).
 //
 // Mapping: a wave owns a 32-row × 128-column unit (4 tiles, 8 KiB).  8 LDS-DMA instructions
 // (global_load_lds_dwordx4, 1 KiB each, 256-B contiguous row segments) fill a wave-private LDS image;
 // 16 lanes serve one tile, lane j takes rows 2j, 2j+1 (4 groups, 8 × ds_read_b128, XOR-swizzled so the
 // reads are bank-conflict free).  The next unit's DMA is issued as soon as the reads have returned and
-// lands during the arithmetic.  Per-lane float64 partials meet in an LDS scratch (14 sums per tile,
-// balanced tree over the 16 lanes = balanced tree over 2*row+half); the three maxima go through DPP/permute.
+// lands during the arithmetic.  A lane sums its 4 groups sequentially; the per-lane float64 partials meet in
+// an LDS scratch (14 sums per tile, balanced tree over the 16 lanes); the three maxima go through lane
+// permutes.  The 4 finished records of a unit leave as two coalesced wave-stores.
 // No MFMA, no block barrier: waves never share data.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -28,6 +30,20 @@
 #include "../../include/mtq.h"
 #include "mtq_device.hpp"
 #include "mtq_error.hpp"
+
+#ifndef MTQ_FAST_WAVES_PER_SIMD
+#define MTQ_FAST_WAVES_PER_SIMD 3
+#endif
+#ifdef MTQ_PAIR_SCHED_BARRIER
+#define MTQ_PAIR_BARRIER __builtin_amdgcn_sched_barrier(0)
+#else
+#define MTQ_PAIR_BARRIER
+#endif
+#ifndef MTQ_NO_SCHED_BARRIER
+#define MTQ_SCHED_BARRIER __builtin_amdgcn_sched_barrier(0)
+#else
+#define MTQ_SCHED_BARRIER
+#endif
 
 namespace mtq {
 
@@ -43,10 +59,14 @@ constexpr int kFastWaves = 4;                        // waves per block
 constexpr int kUnitTiles = 4;                        // tiles per wave unit
 constexpr int kUnitCols = kUnitTiles * kTile;        // 128
 constexpr int kInBytes = kTile * kUnitCols * 2;      // 8192 B of bf16 per unit
+// Σx of a tile the exact route could not take is overwritten with this NaN pattern (low mantissa bits set: no
+// float32-derived NaN can carry it); tile_stats_redo_flagged recomputes exactly those tiles by the literal route.
+constexpr unsigned long long kRedoMagic = 0x7FF8C0DE5EED0001ull;
 constexpr int kSums = 14;                            // Σx, Σx², 3 × (Σy, Σy², Σxy, Σ|d|)
 constexpr int kScratchStride = 17;                   // 16 lanes + 1 pad (doubles)
-constexpr int kScratchBytes = kUnitTiles * kSums * kScratchStride * 8; // 7616 B
-constexpr int kWaveLds = kInBytes + kScratchBytes;   // 15808 B per wave
+constexpr int kScratchDoubles = kUnitTiles * 7 * kScratchStride;        // one pass of 7 statistics: 476 doubles
+constexpr int kRecDoubles = kUnitTiles * (2 + 5 * kNumFmt);             // 4 records of up to 22 doubles
+constexpr int kWaveLds = kInBytes + (kScratchDoubles + kRecDoubles) * 8; // 8192 + 3808 + 704 = 12704 B per wave
 
 // bijection on 4 bits with bit0 = bit2^bit3: makes the XOR swizzle conflict-free for the lane groups
 // ds_read_b128 is serviced in ({0-3,12-15,20-27}, ...; MI355X_MICROARCH.md §LDS).
@@ -96,20 +116,11 @@ __device__ __forceinline__ uint32_t pk_lshr(uint32_t v, uint32_t sh)
 
 __device__ __forceinline__ double pow2_f64(uint32_t biased_hi) { return __hiloint2double((int)biased_hi, 0); }
 
-// Literal route for one group held as packed bf16 pairs (rare).  t[0..21] as group_terms_literal.
-__device__ __noinline__ void fallback_group(const uint32_t w[8], double t[2 + 5 * kNumFmt])
-{
-    uint32_t u[kGroup];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) { u[2 * i] = w[i] << 16; u[2 * i + 1] = w[i] & 0xFFFF0000u; }
-    group_terms_literal(u, 0xEu, t);
-}
-
 // Per-group result handed to the tree: the 14 float64 terms of the group and its 3 float32 maxima.
 struct GroupOut {
     double term[kSums];
     float mx[3];
-    bool nan_max;
+    bool bad;   // outside the exact route's preconditions: the tile is redone by the literal fix-up kernel
 };
 
 __device__ __forceinline__ void fast_group(const uint32_t w[8], GroupOut &G)
@@ -144,30 +155,16 @@ __device__ __forceinline__ void fast_group(const uint32_t w[8], GroupOut &G)
         fmt_step<Fmt8>(a, sgn, A8);
         fmt_step<Fmt4>(a, sgn, A4);
         fmt_step<Fmt2>(a, sgn, A2);
+        MTQ_PAIR_BARRIER;
     }
-    // preconditions of the exact route (file header)
-    const bool ok = ((dor & 0xFFF0FFF0u) == 0u) & (E >= 80u) & (E <= 180u) & (sbs < 65536u);
-    if (__builtin_expect(!ok, 0)) {
-        double t[2 + 5 * kNumFmt];
-        fallback_group(w, t);
-        G.term[0] = t[0]; G.term[1] = t[1];
-        bool nn = false;
-#pragma unroll
-        for (int f = 0; f < 3; ++f) {
-            G.term[2 + 4 * f] = t[7 + 5 * f]; G.term[3 + 4 * f] = t[8 + 5 * f]; G.term[4 + 4 * f] = t[9 + 5 * f]; G.term[5 + 4 * f] = t[10 + 5 * f];
-            const double m = t[11 + 5 * f];
-            nn |= (m != m);
-            G.mx[f] = (float)m;                                 // a float32 value by construction
-        }
-        G.nan_max = nn;
-        return;
-    }
+    // preconditions of the exact route (file header); a group outside them only marks its tile
+    G.bad = !(((dor & 0xFFF0FFF0u) == 0u) & (E >= 80u) & (E <= 180u) & (sbs < 65536u));
     const uint32_t bmax = max(bmaxp & 0xFFFFu, bmaxp >> 16);
     const int e1 = (int)E - 149, e2 = 2 * (int)E - 298;         // 2^(E−149), 2^(2E−298)
     G.term[0] = __builtin_ldexp((double)(sxa * 256 + sxb), e1);
     const double a2 = ((double)sa2[0] + (double)sa2[1]) + ((double)sa2[2] + (double)sa2[3]);  // exact (< 2^35)
     G.term[1] = __builtin_ldexp(__builtin_fma(a2, 65536.0, (double)sb2), e2);                  // exact (< 2^51)
-    const float sf = __uint_as_float((E - 22u) << 23);          // 2^(E−149) as float32
+    const float sf = __uint_as_float(((E - 22u) & 0xFFu) << 23); // 2^(E−149) as float32 (garbage-safe when the group is bad)
     const FmtAcc *A[3] = {&A8, &A4, &A2};
     const int mbs[3] = {7, 3, 1};
 #pragma unroll
@@ -178,10 +175,9 @@ __device__ __forceinline__ void fast_group(const uint32_t w[8], GroupOut &G)
         G.term[5 + 4 * f] = __builtin_ldexp((double)((A[f]->sad << 8) + sbs), e1);            // (256·Σ|a−y| + Σb) · 2^(E−149)
         G.mx[f] = (float)max(fmt_maxabs(*A[f]) << 8, bmax) * sf; // integer < 2^24: exact
     }
-    G.nan_max = false;
 }
 
-__global__ __launch_bounds__(kFastWaves * 64, 2) void tile_stats_bf16_fast(const uint16_t *__restrict__ x, int64_t stride,
+__global__ __launch_bounds__(kFastWaves * 64, MTQ_FAST_WAVES_PER_SIMD) void tile_stats_bf16_fast(const uint16_t *__restrict__ x, int64_t stride,
                                                                             int64_t ld, int tiles_w, int64_t tiles, int units_w,
                                                                             int units_per_tensor, int total_units,
                                                                             uint32_t fmt_mask, int rec, double *__restrict__ stats)
@@ -227,96 +223,125 @@ __global__ __launch_bounds__(kFastWaves * 64, 2) void tile_stats_bf16_fast(const
                                              (__attribute__((address_space(3))) void *)(in + i * 1024), 16, 0, 0);
     };
 
+    // output: the 4 records of a unit are contiguous in `stats` (tiles uc*4 .. uc*4+3); they are assembled in
+    // LDS and leave as kRecStores coalesced wave-stores, so the loop-top wait can be a COUNTED vmcnt that
+    // retires the LDS-DMA of this unit without waiting for the previous unit's stores.
+    const int o_bf16 = 2, o8 = 2 + 5 * __builtin_popcount(fmt_mask & 1u), o4 = 2 + 5 * __builtin_popcount(fmt_mask & 3u),
+              o2 = 2 + 5 * __builtin_popcount(fmt_mask & 7u);
+    double *recbuf = scratch + kScratchDoubles;                 // [4 tiles][rec] doubles
+
+    auto read_rows = [&](int kh, uint32_t w0[8], uint32_t w1[8]) {
+        const uint4 a0 = *reinterpret_cast<const uint4 *>(in + rd_base + kh * 256u + rd_slot[0]);
+        const uint4 a1 = *reinterpret_cast<const uint4 *>(in + rd_base + kh * 256u + rd_slot[1]);
+        const uint4 b0 = *reinterpret_cast<const uint4 *>(in + rd_base + kh * 256u + rd_slot[2]);
+        const uint4 b1 = *reinterpret_cast<const uint4 *>(in + rd_base + kh * 256u + rd_slot[3]);
+        w0[0] = a0.x; w0[1] = a0.y; w0[2] = a0.z; w0[3] = a0.w; w0[4] = a1.x; w0[5] = a1.y; w0[6] = a1.z; w0[7] = a1.w;
+        w1[0] = b0.x; w1[1] = b0.y; w1[2] = b0.z; w1[3] = b0.w; w1[4] = b1.x; w1[5] = b1.y; w1[6] = b1.z; w1[7] = b1.w;
+    };
+
     int u = wave_global;
     if (u < total_units) issue_dma(u);
+    bool first = true;
     for (; u < total_units; u += wave_count) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this unit's image has landed (and older stores retired)
-        uint32_t w[4][8];
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int kh = g >> 1, hf = g & 1;
-            const uint4 lo = *reinterpret_cast<const uint4 *>(in + rd_base + kh * 256u + rd_slot[2 * hf]);
-            const uint4 hi = *reinterpret_cast<const uint4 *>(in + rd_base + kh * 256u + rd_slot[2 * hf + 1]);
-            w[g][0] = lo.x; w[g][1] = lo.y; w[g][2] = lo.z; w[g][3] = lo.w;
-            w[g][4] = hi.x; w[g][5] = hi.y; w[g][6] = hi.z; w[g][7] = hi.w;
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // registers hold the unit: the image may be overwritten
-        if (u + wave_count < total_units) issue_dma(u + wave_count);
+        // in-order VM counter: [DMA(u) x8] [stores(u-1) x kRecStores]; leave only the stores in flight
+        if (first) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        first = false;
 
-        // balanced tree over the lane's 4 groups: (g0 + g1) + (g2 + g3); the lane total goes straight to the scratch
+        // the lane's 4 groups, summed sequentially: ((g0 + g1) + g2) + g3  (rows 2j then 2j+1)
+        double acc[kSums];
         float mx[3];
-        bool nan_max;
+        bool bad;
         {
             GroupOut G;
-            double p01[kSums], t2[kSums];
-            fast_group(w[0], G);
+            uint32_t w0[8], w1[8];
+            read_rows(0, w0, w1);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            fast_group(w0, G);
 #pragma unroll
-            for (int s = 0; s < kSums; ++s) p01[s] = G.term[s];
-            mx[0] = G.mx[0]; mx[1] = G.mx[1]; mx[2] = G.mx[2]; nan_max = G.nan_max;
-            __builtin_amdgcn_sched_barrier(0);
-            fast_group(w[1], G);
+            for (int s = 0; s < kSums; ++s) acc[s] = G.term[s];
+            mx[0] = G.mx[0]; mx[1] = G.mx[1]; mx[2] = G.mx[2]; bad = G.bad;
+            MTQ_SCHED_BARRIER;
+            fast_group(w1, G);
 #pragma unroll
-            for (int s = 0; s < kSums; ++s) p01[s] = p01[s] + G.term[s];
-            mx[0] = fmaxf(mx[0], G.mx[0]); mx[1] = fmaxf(mx[1], G.mx[1]); mx[2] = fmaxf(mx[2], G.mx[2]); nan_max |= G.nan_max;
-            __builtin_amdgcn_sched_barrier(0);
-            fast_group(w[2], G);
+            for (int s = 0; s < kSums; ++s) acc[s] = acc[s] + G.term[s];
+            mx[0] = fmaxf(mx[0], G.mx[0]); mx[1] = fmaxf(mx[1], G.mx[1]); mx[2] = fmaxf(mx[2], G.mx[2]); bad |= G.bad;
+            MTQ_SCHED_BARRIER;
+            read_rows(1, w0, w1);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // the registers hold the rest of the unit: the image may be overwritten
+            if (u + wave_count < total_units) issue_dma(u + wave_count);
+            fast_group(w0, G);
 #pragma unroll
-            for (int s = 0; s < kSums; ++s) t2[s] = G.term[s];
-            mx[0] = fmaxf(mx[0], G.mx[0]); mx[1] = fmaxf(mx[1], G.mx[1]); mx[2] = fmaxf(mx[2], G.mx[2]); nan_max |= G.nan_max;
-            __builtin_amdgcn_sched_barrier(0);
-            fast_group(w[3], G);
+            for (int s = 0; s < kSums; ++s) acc[s] = acc[s] + G.term[s];
+            mx[0] = fmaxf(mx[0], G.mx[0]); mx[1] = fmaxf(mx[1], G.mx[1]); mx[2] = fmaxf(mx[2], G.mx[2]); bad |= G.bad;
+            MTQ_SCHED_BARRIER;
+            fast_group(w1, G);
 #pragma unroll
-            for (int s = 0; s < kSums; ++s) scratch[(t * kSums + s) * kScratchStride + j] = p01[s] + (t2[s] + G.term[s]);
-            mx[0] = fmaxf(mx[0], G.mx[0]); mx[1] = fmaxf(mx[1], G.mx[1]); mx[2] = fmaxf(mx[2], G.mx[2]); nan_max |= G.nan_max;
+            for (int s = 0; s < kSums; ++s) acc[s] = acc[s] + G.term[s];
+            mx[0] = fmaxf(mx[0], G.mx[0]); mx[1] = fmaxf(mx[1], G.mx[1]); mx[2] = fmaxf(mx[2], G.mx[2]); bad |= G.bad;
         }
 
-        // cross-lane: sums through the LDS scratch (lane j reduces statistic j), maxima through lane permutes
+        // maxima: lane permutes inside the 16-lane row
 #pragma unroll
         for (int f = 0; f < 3; ++f) {
 #pragma unroll
             for (int sft = 1; sft < 16; sft <<= 1) mx[f] = fmaxf(mx[f], __shfl_xor(mx[f], sft, 16));
         }
-        const unsigned long long nan_lanes = __ballot(nan_max);
-        const bool tile_nan = ((nan_lanes >> (16 * t)) & 0xFFFFull) != 0ull;
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        double r = 0.0;
-        if (j < kSums) {
-            const double *row = scratch + (t * kSums + j) * kScratchStride;
-            double v[16];
-#pragma unroll
-            for (int k = 0; k < 16; ++k) v[k] = row[k];
-#pragma unroll
-            for (int stp = 1; stp < 16; stp <<= 1)
-#pragma unroll
-                for (int k = 0; k < 16; k += 2 * stp) v[k] = v[k] + v[k + stp];
-            r = v[0];
-        }
+        const unsigned long long bad_lanes = __ballot(bad);
+        const bool tile_bad = ((bad_lanes >> (16 * t)) & 0xFFFFull) != 0ull;
 
-        // write the record (compacted to fmt_mask): lane j < 14 holds sum j, every lane holds the maxima
+        // sums: two passes of 7 statistics through the LDS scratch; lane j (< 7) reduces statistic 7*pass + j
+        // over the 16 row pairs by a balanced tree and drops it into the record image
+        double *rec_t = recbuf + t * rec;
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+            for (int s = 0; s < 7; ++s) scratch[(t * 7 + s) * kScratchStride + j] = acc[7 * pass + s];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (j < 7) {
+                const double *row = scratch + (t * 7 + j) * kScratchStride;
+                double v[16];
+#pragma unroll
+                for (int k = 0; k < 16; ++k) v[k] = row[k];
+#pragma unroll
+                for (int stp = 1; stp < 16; stp <<= 1)
+#pragma unroll
+                    for (int k = 0; k < 16; k += 2 * stp) v[k] = v[k] + v[k + stp];
+                const double r = v[0];
+                const int sidx = 7 * pass + (int)j;
+                if (sidx == 0) {
+                    rec_t[0] = r;
+                    if (fmt_mask & 1u) { // bf16 of bf16 data: y = x, so |x−y| is +0 — or NaN when the tile holds Inf/NaN (inf − inf)
+                        const double z = __builtin_fabs(r) * 0.0;
+                        rec_t[o_bf16] = r; rec_t[o_bf16 + 3] = z; rec_t[o_bf16 + 4] = z;
+                    }
+                } else if (sidx == 1) {
+                    rec_t[1] = r;
+                    if (fmt_mask & 1u) { rec_t[o_bf16 + 1] = r; rec_t[o_bf16 + 2] = r; }
+                } else {
+                    const int f = (sidx - 2) >> 2, k = (sidx - 2) & 3;
+                    const int o = f == 0 ? o8 : (f == 1 ? o4 : o2);
+                    if (fmt_mask & (2u << f)) rec_t[o + k] = r;
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // pass 0's reads are done before pass 1 overwrites the scratch
+        }
+        if (j == 15) {
+            if (fmt_mask & 2u) rec_t[o8 + 4] = (double)mx[0];
+            if (fmt_mask & 4u) rec_t[o4 + 4] = (double)mx[1];
+            if (fmt_mask & 8u) rec_t[o2 + 4] = (double)mx[2];
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (tile_bad && j == 0) rec_t[0] = __longlong_as_double((long long)kRedoMagic); // after the reducers' own write of rec_t[0]
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+
+        // 4 records = 4*rec contiguous doubles: exactly kRecStores wave-stores (masked lanes keep the count fixed)
         int b, tr, uc;
         unit_base(u, b, tr, uc);
-        double *out = stats + ((int64_t)b * tiles + (int64_t)tr * tiles_w + uc * kUnitTiles + t) * rec;
-        const int o_bf16 = 2, o8 = 2 + 5 * __builtin_popcount(fmt_mask & 1u), o4 = 2 + 5 * __builtin_popcount(fmt_mask & 3u),
-                  o2 = 2 + 5 * __builtin_popcount(fmt_mask & 7u);
-        if (j == 0) {
-            out[0] = r;
-            if (fmt_mask & 1u) { // bf16 of bf16 data: y = x, so |x−y| is +0 — or NaN when the tile holds Inf/NaN (inf − inf)
-                const double z = __builtin_fabs(r) * 0.0;
-                out[o_bf16] = r; out[o_bf16 + 3] = z; out[o_bf16 + 4] = z;
-            }
-        } else if (j == 1) {
-            out[1] = r;
-            if (fmt_mask & 1u) { out[o_bf16 + 1] = r; out[o_bf16 + 2] = r; }
-        } else if (j < kSums) {
-            const int f = (j - 2) >> 2, k = (j - 2) & 3;
-            const int o = f == 0 ? o8 : (f == 1 ? o4 : o2);
-            if (fmt_mask & (2u << f)) out[o + k] = r;
-        } else if (j == 14) {
-            const double q = __builtin_nan("");
-            if (fmt_mask & 2u) out[o8 + 4] = tile_nan ? q : (double)mx[0];
-            if (fmt_mask & 4u) out[o4 + 4] = tile_nan ? q : (double)mx[1];
-            if (fmt_mask & 8u) out[o2 + 4] = tile_nan ? q : (double)mx[2];
-        }
+        double *out = stats + ((int64_t)b * tiles + (int64_t)tr * tiles_w + uc * kUnitTiles) * rec;
+        const int nrec = kUnitTiles * rec;                      // ≤ 88
+        if (lane < nrec) out[lane] = recbuf[lane];
+        if (lane + 64 < nrec) out[lane + 64] = recbuf[lane + 64];
     }
 }
 
@@ -339,7 +364,7 @@ extern "C" int mtq_launch_tile_stats_bf16_fast(const void *x, int64_t count, int
         if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess) return fail(MTQ_ERR_HIP, "hipGetDeviceProperties failed");
         cus = p.multiProcessorCount;
     }
-    const int64_t max_blocks = (int64_t)cus * 2;               // 2 blocks of 4 waves per CU (LDS-bound residency)
+    const int64_t max_blocks = (int64_t)cus * MTQ_FAST_WAVES_PER_SIMD; // blocks of 4 waves per CU (one wave of each per SIMD)
     const int64_t need = (total + kFastWaves - 1) / kFastWaves;
     const unsigned blocks = (unsigned)(need < max_blocks ? need : max_blocks);
     hipLaunchKernelGGL(tile_stats_bf16_fast, dim3(blocks), dim3(kFastWaves * 64), kFastWaves * kWaveLds, static_cast<hipStream_t>(stream),

@@ -14,20 +14,17 @@ namespace mtq {
 // ---------------------------------------------------------------------------------------------
 // K1 (generic form): one wave64 per 32×32 tile, lane ℓ owns the shared-exponent group
 // (row = ℓ>>1, half = ℓ&1).  Literal uint32 quantisation per candidate format, float32 terms,
-// float64 accumulation; lane-sequential over the 16 elements, xor-butterfly over the 64 lanes
-// (= balanced tree over 2*row+half, the order include/mtq.h documents).  Handles every input
+// float64 accumulation; lane-sequential over the 16 elements, sequential over the 4 lanes of a row pair,
+// xor-butterfly over the 16 row pairs (the order include/mtq.h documents).  Handles every input
 // (fp32 or bf16 storage, specials, ragged edges); the bf16 fast kernel defers to the same
 // arithmetic for groups it cannot take.
 // ---------------------------------------------------------------------------------------------
 template <typename T>
-__global__ __launch_bounds__(256) void tile_stats_generic(const T *__restrict__ x, int64_t count, int64_t stride,
-                                                          int64_t rows, int64_t cols, int64_t ld, int tiles_w,
-                                                          int64_t tiles, uint32_t fmt_mask, int rec,
-                                                          double *__restrict__ stats, int vec_ok)
+__device__ __forceinline__ void tile_stats_one(const T *__restrict__ x, int64_t gt, int64_t stride, int64_t rows, int64_t cols,
+                                               int64_t ld, int tiles_w, int64_t tiles, uint32_t fmt_mask, int rec,
+                                               double *__restrict__ stats, int vec_ok)
 {
     const int lane = threadIdx.x & 63;
-    const int64_t gt = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); // global tile over the batch
-    if (gt >= count * tiles) return;                                   // wave-uniform
     const int64_t b = gt / tiles, t = gt - b * tiles;
     const int64_t tr = t / tiles_w, tc = t - tr * tiles_w;
     const T *xb = x + b * stride;
@@ -43,8 +40,13 @@ __global__ __launch_bounds__(256) void tile_stats_generic(const T *__restrict__ 
         if (live) {
             const bool is_max = k >= 2 && ((k - 2) % 5) == 4;
             double v = acc[k];
+            {   // the 4 groups of a row pair (lanes 4j..4j+3) sequentially, identically in every lane of the quad
+                const int q0 = lane & ~3;
+                const double a = __shfl(v, q0, 64), b = __shfl(v, q0 + 1, 64), c = __shfl(v, q0 + 2, 64), d = __shfl(v, q0 + 3, 64);
+                v = is_max ? nanmax(nanmax(nanmax(a, b), c), d) : ((a + b) + c) + d;
+            }
 #pragma unroll
-            for (int s = 1; s < 64; s <<= 1) {
+            for (int s = 4; s < 64; s <<= 1) { // 16 row pairs: balanced tree
                 const double o = __shfl_xor(v, s, 64);
                 v = is_max ? nanmax(v, o) : v + o;
             }
@@ -63,6 +65,38 @@ __global__ __launch_bounds__(256) void tile_stats_generic(const T *__restrict__ 
                 for (int j = 0; j < 5; ++j) out[o + j] = acc[2 + 5 * f + j];
                 o += 5;
             }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void tile_stats_generic(const T *__restrict__ x, int64_t count, int64_t stride,
+                                                          int64_t rows, int64_t cols, int64_t ld, int tiles_w,
+                                                          int64_t tiles, uint32_t fmt_mask, int rec,
+                                                          double *__restrict__ stats, int vec_ok)
+{
+    const int64_t gt = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); // global tile over the batch, one wave per tile
+    if (gt >= count * tiles) return;                                   // wave-uniform
+    tile_stats_one<T>(x, gt, stride, rows, cols, ld, tiles_w, tiles, fmt_mask, rec, stats, vec_ok);
+}
+
+// Follow-up of tile_stats_bf16_fast: every wave inspects 64 records, and recomputes by the literal route the
+// tiles whose Σx carries kRedoMagic (groups outside the exact-integer route's preconditions).
+constexpr unsigned long long kRedoMagicGeneric = 0x7FF8C0DE5EED0001ull;
+__global__ __launch_bounds__(256) void tile_stats_redo_flagged(const uint16_t *__restrict__ x, int64_t count, int64_t stride,
+                                                               int64_t rows, int64_t cols, int64_t ld, int tiles_w,
+                                                               int64_t tiles, uint32_t fmt_mask, int rec,
+                                                               double *__restrict__ stats, int vec_ok)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t first = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 64;
+    const int64_t mine = first + lane;
+    bool flagged = false;
+    if (mine < count * tiles) flagged = (unsigned long long)__double_as_longlong(stats[mine * rec]) == kRedoMagicGeneric;
+    unsigned long long todo = __ballot(flagged);
+    while (todo) {                                                     // wave-uniform loop over the flagged tiles
+        const int k = __builtin_ctzll(todo);
+        todo &= todo - 1;
+        tile_stats_one<uint16_t>(x, first + k, stride, rows, cols, ld, tiles_w, tiles, fmt_mask, rec, stats, vec_ok);
     }
 }
 
@@ -142,8 +176,13 @@ extern "C" int mtq_tile_stats_batched(const void *x, int in_dtype, int64_t count
     const int64_t esz = in_dtype == MTQ_DTYPE_BF16 ? 2 : 4;
     const int vec_ok = aligned16(x) && (ld * esz) % 16 == 0 && (stride_elems * esz) % 16 == 0;
     // bf16 storage, whole 32x128 units, 16-byte aligned rows, at least one BFP format → exact-integer fast kernel
-    if (in_dtype == MTQ_DTYPE_BF16 && vec_ok && rows % kTile == 0 && cols % 128 == 0 && (fmt_mask & 0xEu) != 0 && !force_generic())
-        return mtq_launch_tile_stats_bf16_fast(x, count, stride_elems, rows, cols, ld, fmt_mask, stats, stream);
+    if (in_dtype == MTQ_DTYPE_BF16 && vec_ok && rows % kTile == 0 && cols % 128 == 0 && (fmt_mask & 0xEu) != 0 && !force_generic()) {
+        if (int rc = mtq_launch_tile_stats_bf16_fast(x, count, stride_elems, rows, cols, ld, fmt_mask, stats, stream)) return rc;
+        const int64_t waves = (count * tiles + 63) / 64;
+        hipLaunchKernelGGL(tile_stats_redo_flagged, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                           static_cast<const uint16_t *>(x), count, stride_elems, rows, cols, ld, (int)tw, tiles, fmt_mask, rec, stats, vec_ok);
+        return check_launch("mtq_tile_stats (redo flagged)");
+    }
     const int64_t blocks = (count * tiles + 3) / 4;
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (in_dtype == MTQ_DTYPE_BF16)

@@ -13,7 +13,8 @@ from pathlib import Path
 import numpy as np
 
 _PKG = Path(__file__).resolve().parent
-LIB_PATH = _PKG / "libmtq_hip.so"
+# MTQ_LIB selects another build of the same library (kernel A/B experiments); default is the in-tree build.
+LIB_PATH = Path(os.environ["MTQ_LIB"]).resolve() if os.environ.get("MTQ_LIB") else _PKG / "libmtq_hip.so"
 
 MIXED_TILE_FORMATS = ["bf16", "bfp8", "bfp4", "bfp2"]
 FMT_CODE = {"bf16": 0, "bfp8": 1, "bfp4": 2, "bfp2": 3, "fp0": 4}
