@@ -74,8 +74,9 @@ size_t mtq_stats_record_doubles(uint32_t fmt_mask);
  *
  * stats[tile][0..1] = Σx, Σx²; then for each bit set in fmt_mask (ascending: bf16, bfp8, bfp4, bfp2)
  * five doubles Σy, Σy², Σxy, Σ|x−y|, max|x−y|.  Every term is the float32 expression the reference
- * forms (x*x, y*y, x*y, |x−y|) summed in float64; summation order: 16 elements of a shared-exponent
- * group sequentially, the 4 groups of a row pair (rows 2j, 2j+1) sequentially, the 16 row pairs of a
+ * forms (x*x, y*y, x*y, |x−y|) summed in float64; summation order: inside a shared-exponent group the
+ * elements within 14 binades of the shared exponent sequentially, the others (zeros included) sequentially,
+ * then main + tail; the 4 groups of a row pair (rows 2j, 2j+1) sequentially, the 16 row pairs of a
  * tile by a balanced binary tree over j.
  * Sums run over the zero-padded 1024 elements (pads contribute exactly 0).
  */

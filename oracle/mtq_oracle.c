@@ -125,7 +125,8 @@ static inline double orc_nanmax(double m, double d) { return (d > m || d != d) ?
  * Every term is a float32 expression (x*x, y*y, x*y, |x−y| rounded to float32) summed in
  * float64, as `np.sum(x_view * y_view, dtype=np.float64)` does (mixed_tile_greedy.py:158-164).
  * SUMMATION ORDER (ours; numpy's pairwise order is not reproduced — SURVEY §7.3-3): within one
- * 16-element group sequentially; the four groups of a row pair (rows 2j, 2j+1; row-major) sequentially;
+ * 16-element group, the elements within 14 binades of the group's maximum exponent ("main") sequentially,
+ * the remaining ones ("tail", zeros included) sequentially, then main + tail; the four groups of a row pair (rows 2j, 2j+1; row-major) sequentially;
  * the 16 row-pair sums of a tile by a balanced binary tree over j (adjacent pairs first).
  * The HIP kernels follow the same order, so stats compare bit-for-bit.
  */
@@ -146,21 +147,29 @@ void orc_tile_stats(const float *x, int64_t rows, int64_t cols, uint32_t fmt_mas
                 in[i] = f2u(xv[i]);
             }
             double *a = lane[l];
-            double sx = 0.0, sx2 = 0.0;
-            for (int i = 0; i < GROUP; ++i) { float p = xv[i] * xv[i]; sx += (double)xv[i]; sx2 += (double)p; }
-            a[0] = sx; a[1] = sx2;
+            /* main class: elements within 14 binades of the group's maximum exponent; tail class: the rest
+             * (zeros and denormals included).  Each class is summed sequentially in index order, then
+             * S = S_main + S_tail. */
+            uint32_t E = 0;
+            for (int i = 0; i < GROUP; ++i) { uint32_t e = (in[i] >> 23) & 0xFFu; if (e > E) E = e; }
+            int tail[GROUP];
+            for (int i = 0; i < GROUP; ++i) tail[i] = (E - ((in[i] >> 23) & 0xFFu)) > 14u;
+            double sx[2] = {0.0, 0.0}, sx2[2] = {0.0, 0.0};
+            for (int i = 0; i < GROUP; ++i) { float p = xv[i] * xv[i]; sx[tail[i]] += (double)xv[i]; sx2[tail[i]] += (double)p; }
+            a[0] = sx[0] + sx[1]; a[1] = sx2[0] + sx2[1];
             for (int k = 0; k < nf; ++k) {
                 if (fmts[k] == 0) for (int i = 0; i < GROUP; ++i) out[i] = orc_bf16_bits(in[i]);
                 else orc_bfp_group(in, orc_mant_bits(fmts[k]), out);
-                double sy = 0.0, sy2 = 0.0, sxy = 0.0, sab = 0.0, mx = 0.0;
+                double sy[2] = {0.0, 0.0}, sy2[2] = {0.0, 0.0}, sxy[2] = {0.0, 0.0}, sab[2] = {0.0, 0.0}, mx = 0.0;
                 for (int i = 0; i < GROUP; ++i) {
                     float yv = u2f(out[i]);
                     float p2 = yv * yv, pxy = xv[i] * yv, df = fabsf(xv[i] - yv);
-                    sy += (double)yv; sy2 += (double)p2; sxy += (double)pxy; sab += (double)df;
+                    const int c = tail[i];
+                    sy[c] += (double)yv; sy2[c] += (double)p2; sxy[c] += (double)pxy; sab[c] += (double)df;
                     mx = orc_nanmax(mx, (double)df);
                 }
                 double *b = a + 2 + 5 * k;
-                b[0] = sy; b[1] = sy2; b[2] = sxy; b[3] = sab; b[4] = mx;
+                b[0] = sy[0] + sy[1]; b[1] = sy2[0] + sy2[1]; b[2] = sxy[0] + sxy[1]; b[3] = sab[0] + sab[1]; b[4] = mx;
             }
         }
         /* lanes 4j..4j+3 = the four groups of rows 2j, 2j+1: summed sequentially into lane 4j */

@@ -68,8 +68,9 @@ def _is_torch(x) -> bool:
 
 def host_tile_stats(x2d: np.ndarray, formats_in_mask_order: list[str], quantizer: Quantizer) -> np.ndarray:
     """Host definition of the stats record (NumPy).  Terms are float32 expressions summed in float64:
-    sequentially over the 16 elements of a shared-exponent group, sequentially over the 4 groups of a row
-    pair (rows 2j, 2j+1), then by a balanced binary tree over the 16 row pairs — the order the HIP kernels use."""
+    inside a shared-exponent group the elements within 14 binades of the shared exponent sequentially, the
+    rest ("tail", zeros included) sequentially, main + tail; then sequentially over the 4 groups of a row pair
+    (rows 2j, 2j+1) and by a balanced binary tree over the 16 row pairs — the order the HIP kernels use."""
     h, w = x2d.shape
     th, tw = -(-h // TILE), -(-w // TILE)
 
@@ -79,15 +80,21 @@ def host_tile_stats(x2d: np.ndarray, formats_in_mask_order: list[str], quantizer
         return p.reshape(th, TILE, tw, 2, 16).transpose(0, 2, 1, 3, 4).reshape(th * tw, 64, 16)
 
     def reduce_sum(term: np.ndarray) -> np.ndarray:
-        acc = np.zeros(term.shape[:2], dtype=np.float64)
+        main = np.zeros(term.shape[:2], dtype=np.float64)
+        tail = np.zeros(term.shape[:2], dtype=np.float64)
         for i in range(16):
-            acc = acc + term[:, :, i].astype(np.float64)
+            v = term[:, :, i].astype(np.float64)
+            main = np.where(is_tail[:, :, i], main, main + v)
+            tail = np.where(is_tail[:, :, i], tail + v, tail)
+        acc = main + tail
         acc = ((acc[:, 0::4] + acc[:, 1::4]) + acc[:, 2::4]) + acc[:, 3::4]  # the 4 groups of a row pair, sequentially
         while acc.shape[1] > 1:                                               # 16 row pairs: balanced tree
             acc = acc[:, 0::2] + acc[:, 1::2]
         return acc[:, 0]
 
     xl = lanes(x2d)
+    ex = (xl.view(np.uint32) >> np.uint32(23)) & np.uint32(0xFF)
+    is_tail = (ex.max(axis=2, keepdims=True) - ex) > 14   # more than 14 binades below the group's shared exponent
     cols = [reduce_sum(xl), reduce_sum(xl * xl)]
     with np.errstate(all="ignore"):
         for fmt in formats_in_mask_order:

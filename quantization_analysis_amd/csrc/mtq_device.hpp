@@ -115,33 +115,36 @@ __device__ __forceinline__ uint32_t group_shared_exp(const uint32_t u[kGroup])
 __device__ __forceinline__ void group_terms_literal(const uint32_t u[kGroup], uint32_t fmt_mask, double t[2 + 5 * kNumFmt])
 {
     const uint32_t shared = group_shared_exp(u);
-    double sx = 0.0, sx2 = 0.0;
+    // main class: within 14 binades of the shared exponent; tail class: the rest (zeros/denormals included).
+    // Each class is summed sequentially in index order, then S = S_main + S_tail (include/mtq.h).
+    uint32_t tailmask = 0u;
+#pragma unroll
+    for (int i = 0; i < kGroup; ++i) tailmask |= ((shared - ((u[i] >> 23) & 0xFFu)) > 14u ? 1u : 0u) << i;
+    double sx = 0.0, sx2 = 0.0, tx = 0.0, tx2 = 0.0;
 #pragma unroll
     for (int i = 0; i < kGroup; ++i) {
         const float xv = __uint_as_float(u[i]);
         const float p = xv * xv;
-        sx += (double)xv;
-        sx2 += (double)p;
+        if (tailmask & (1u << i)) { tx += (double)xv; tx2 += (double)p; }
+        else { sx += (double)xv; sx2 += (double)p; }
     }
-    t[0] = sx;
-    t[1] = sx2;
+    t[0] = sx + tx;
+    t[1] = sx2 + tx2;
 #pragma unroll
     for (int f = 0; f < kNumFmt; ++f) {
-        double sy = 0.0, sy2 = 0.0, sxy = 0.0, sab = 0.0, mx = 0.0;
+        double sy = 0.0, sy2 = 0.0, sxy = 0.0, sab = 0.0, mx = 0.0, ty = 0.0, ty2 = 0.0, txy = 0.0, tab = 0.0;
         if (fmt_mask & (1u << f)) { // wave-uniform
 #pragma unroll
             for (int i = 0; i < kGroup; ++i) {
                 const float xv = __uint_as_float(u[i]);
                 const float yv = __uint_as_float(quant_elem_bits(f, u[i], shared));
                 const float p2 = yv * yv, pxy = xv * yv, df = fabsf(xv - yv);
-                sy += (double)yv;
-                sy2 += (double)p2;
-                sxy += (double)pxy;
-                sab += (double)df;
+                if (tailmask & (1u << i)) { ty += (double)yv; ty2 += (double)p2; txy += (double)pxy; tab += (double)df; }
+                else { sy += (double)yv; sy2 += (double)p2; sxy += (double)pxy; sab += (double)df; }
                 mx = nanmax(mx, (double)df);
             }
         }
-        t[2 + 5 * f] = sy; t[3 + 5 * f] = sy2; t[4 + 5 * f] = sxy; t[5 + 5 * f] = sab; t[6 + 5 * f] = mx;
+        t[2 + 5 * f] = sy + ty; t[3 + 5 * f] = sy2 + ty2; t[4 + 5 * f] = sxy + txy; t[5 + 5 * f] = sab + tab; t[6 + 5 * f] = mx;
     }
 }
 

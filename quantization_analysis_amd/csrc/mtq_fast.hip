@@ -2,25 +2,24 @@
 // integer arithmetic (gfx950 packed-16 VALU, v_dot2 / v_sad), staged through LDS by LDS-DMA.
 //
 // Why integers are exact here (DESIGN.md Â§K1): a bf16 value is Â±mÂ·2^(eâˆ’134) with an 8-bit m.  Inside a
-// shared-exponent group (max exponent E) every value within 15 binades of the maximum is an integer
-// multiple of 2^(Eâˆ’149):  x = Â±(256Â·a + b)Â·2^(Eâˆ’149),  a = mÂ·2^(7âˆ’d) for d = Eâˆ’e â‰¤ 7 (else 0),
-// b = mÂ·2^(15âˆ’d) for 8 â‰¤ d â‰¤ 15 (else 0).  All three BFP roundings act on `a` alone (values with d â‰¥ 8
-// quantise to 0 in every format), y = qÂ·2^(15âˆ’mb) in units of `a`, so every float32 term the reference
-// forms (x*x, y*y, x*y, |xâˆ’y|) is exact and the group sums are small integers:
+// shared-exponent group (max exponent E) every value within 14 binades of the maximum (the "main" class of
+// include/mtq.h's summation order) is an integer multiple of 2^(Eâˆ’148):  x = Â±(128Â·a + b)Â·2^(Eâˆ’148),
+// a = mÂ·2^(7âˆ’d) for d = Eâˆ’e â‰¤ 7 (else 0), b = mÂ·2^(14âˆ’d) for 8 â‰¤ d â‰¤ 14 (else 0).  All three BFP roundings
+// act on `a` alone (values with d â‰¥ 8 quantise to 0 in every format), y = qÂ·2^(15âˆ’mb) in units of `a`, so
+// every float32 term the reference forms (x*x, y*y, x*y, |xâˆ’y|) is exact and the group sums are small integers:
 //     Î£y = Î£Â±y Â· 2^(Eâˆ’141)            Î£yÂ² = Î£qÂ² Â· 2^(2(Eâˆ’126âˆ’mb))        Î£xy = Î£aÂ·q Â· 2^(2Eâˆ’267âˆ’mb)
-//     Î£|xâˆ’y| = (256Â·Î£|aâˆ’y| + Î£b) Â· 2^(Eâˆ’149)      max|xâˆ’y| = max(256Â·max|aâˆ’y|, max b) Â· 2^(Eâˆ’149)
-//     Î£x = (256Â·Î£Â±a + Î£Â±b) Â· 2^(Eâˆ’149)            Î£xÂ² = (65536Â·Î£aÂ² + Î£bÂ²) Â· 2^(2Eâˆ’298)
+//     Î£|xâˆ’y| = (128Â·Î£|aâˆ’y| + Î£b) Â· 2^(Eâˆ’148)      max|xâˆ’y| = max(128Â·max|aâˆ’y|, max b) Â· 2^(Eâˆ’148)
+//     Î£x = (128Â·Î£Â±a + Î£Â±b) Â· 2^(Eâˆ’148)            Î£xÂ² = (16384Â·Î£aÂ² + Î£bÂ²) Â· 2^(2Eâˆ’296)
 // An exact integer times a power of two is exactly the float64 the literal route (sequential float64 sum
-// of the float32 terms) produces, so the records are bit-identical to tile_stats_generic / the oracle.
-// A group outside the preconditions (E âˆ‰ [80,180], an element more than 15 binades below the maximum â€”
-// that includes exact zeros â€” or Î£b â‰¥ 2^16) marks its tile; the marked tiles (rare in real weights) are
-// recomputed by the literal route in a follow-up launch (tile_stats_redo_flagged, mtq_kernels.hip).
+// of the float32 terms) produces for the main class, so the records are bit-identical to tile_stats_generic
+// and the oracle.  Tail-class values (d â‰¥ 15; rare) are added in a short divergent loop.  A group whose E is
+// outside [80,180] (float32 products could under/overflow; also all-zero, Inf/NaN groups) marks its tile; marked
+// tiles are recomputed by the literal route in a follow-up launch (tile_stats_redo_flagged, mtq_kernels.hip).
 //
 // Mapping: a wave owns a 32-row Ã— 128-column unit (4 tiles, 8 KiB).  8 LDS-DMA instructions
 // (global_load_lds_dwordx4, 1 KiB each, 256-B contiguous row segments) fill a wave-private LDS image;
-// 16 lanes serve one tile, lane j takes rows 2j, 2j+1 (4 groups, 8 Ã— ds_read_b128, XOR-swizzled so the
-// reads are bank-conflict free).  The next unit's DMA is issued as soon as the reads have returned and
-// lands during the arithmetic.  A lane sums its 4 groups sequentially; the per-lane float64 partials meet in
+// 16 lanes serve one tile, lane j takes rows 2j, 2j+1 (4 groups, 2 Ã— ds_read_b128 each, XOR-swizzled so the
+// reads are bank-conflict free).  A lane sums its 4 groups sequentially; the per-lane float64 partials meet in
 // an LDS scratch (14 sums per tile, balanced tree over the 16 lanes); the three maxima go through lane
 // permutes.  The 4 finished records of a unit leave as two coalesced wave-stores.
 // No MFMA, no block barrier: waves never share data.
@@ -31,8 +30,8 @@
 #include "mtq_device.hpp"
 #include "mtq_error.hpp"
 
-#ifndef MTQ_FAST_WAVES_PER_SIMD
-#define MTQ_FAST_WAVES_PER_SIMD 3
+#ifndef MTQ_ROLLED_WAVES_PER_SIMD
+#define MTQ_ROLLED_WAVES_PER_SIMD 3
 #endif
 #ifdef MTQ_PAIR_SCHED_BARRIER
 #define MTQ_PAIR_BARRIER __builtin_amdgcn_sched_barrier(0)
@@ -66,7 +65,6 @@ constexpr int kSums = 14;                            // Î£x, Î£xÂ², 3 Ã— (Î£y, Î
 constexpr int kScratchStride = 17;                   // 16 lanes + 1 pad (doubles)
 constexpr int kScratchDoubles = kUnitTiles * 7 * kScratchStride;        // one pass of 7 statistics: 476 doubles
 constexpr int kRecDoubles = kUnitTiles * (2 + 5 * kNumFmt);             // 4 records of up to 22 doubles
-constexpr int kWaveLds = kInBytes + (kScratchDoubles + kRecDoubles) * 8; // 8192 + 3808 + 704 = 12704 B per wave
 
 // bijection on 4 bits with bit0 = bit2^bit3: makes the XOR swizzle conflict-free for the lane groups
 // ds_read_b128 is serviced in ({0-3,12-15,20-27}, ...; MI355X_MICROARCH.md Â§LDS).
@@ -94,9 +92,11 @@ __device__ __forceinline__ void fmt_step(uint32_t a, uint32_t sgn, FmtAcc &A)
     A.sq2 = __builtin_amdgcn_udot2(as_us2(q), as_us2(q), A.sq2, false);
     A.saq = __builtin_amdgcn_udot2(as_us2(a), as_us2(q), A.saq, false);
     A.sad = __builtin_amdgcn_sad_u16(a, y, A.sad);
+#ifndef MTQ_ABL_NOMAX
     const s2 dl = as_s2(a) - as_s2(y);
     A.dmax = as_u32(__builtin_elementwise_max(as_s2(A.dmax), dl));
     A.dmin = as_u32(__builtin_elementwise_min(as_s2(A.dmin), dl));
+#endif
 }
 
 __device__ __forceinline__ uint32_t fmt_maxabs(const FmtAcc &A)
@@ -123,7 +123,8 @@ struct GroupOut {
     bool bad;   // outside the exact route's preconditions: the tile is redone by the literal fix-up kernel
 };
 
-__device__ __forceinline__ void fast_group(const uint32_t w[8], GroupOut &G)
+template <typename Reload>
+__device__ __forceinline__ void fast_group(const uint32_t w[8], GroupOut &G, Reload reload)
 {
     uint32_t ab[8];
 #pragma unroll
@@ -140,57 +141,100 @@ __device__ __forceinline__ void fast_group(const uint32_t w[8], GroupOut &G)
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const uint32_t e = (ab[i] >> 7) & 0x00FF00FFu;
-        const uint32_t d = Ep - e;                              // per half, no borrow (E â‰¥ e)
-        dor |= d;
+        const uint32_t d = as_u32(__builtin_elementwise_min(as_us2(Ep - e), as_us2(0x000F000Fu))); // min(Eâˆ’e, 15) per half
+        dor |= d + 0x00010001u;                                 // bit 4 of a half set â‡” that element is in the tail class
         const uint32_t m = (ab[i] & 0x007F007Fu) | 0x00800080u;
         const uint32_t a = as_u32(as_us2(m) * as_us2(pk_lshr(0x00800080u, d)));                 // mÂ·2^(7âˆ’d), 0 for d â‰¥ 8
-        const uint32_t b = as_u32(as_us2(m) * as_us2(pk_lshr(0x80008000u, d) & 0x00FF00FFu));   // mÂ·2^(15âˆ’d), 8 â‰¤ d â‰¤ 15
+        const uint32_t b = as_u32(as_us2(m) * as_us2(pk_lshr(0x40004000u, d) & 0x007F007Fu));   // mÂ·2^(14âˆ’d), 8 â‰¤ d â‰¤ 14
         const uint32_t sgn = as_u32(as_s2(w[i]) >> (short)15) | 0x00010001u;                   // Â±1 per half
         sxa = __builtin_amdgcn_sdot2(as_s2(a), as_s2(sgn), sxa, false);
         sxb = __builtin_amdgcn_sdot2(as_s2(b), as_s2(sgn), sxb, false);
         sa2[i >> 1] = __builtin_amdgcn_udot2(as_us2(a), as_us2(a), sa2[i >> 1], false);        // â‰¤ 4 elements per u32
-        sb2 = __builtin_amdgcn_udot2(as_us2(b), as_us2(b), sb2, false);
+        sb2 = __builtin_amdgcn_udot2(as_us2(b), as_us2(b), sb2, false);                        // b â‰¤ 0x3FC0: 16 squares fit
         sbs = __builtin_amdgcn_udot2(as_us2(b), as_us2(0x00010001u), sbs, false);
         bmaxp = as_u32(__builtin_elementwise_max(as_us2(bmaxp), as_us2(b)));
         fmt_step<Fmt8>(a, sgn, A8);
+#ifndef MTQ_ABL_NOFMT4
         fmt_step<Fmt4>(a, sgn, A4);
+#endif
+#ifndef MTQ_ABL_NOFMT2
         fmt_step<Fmt2>(a, sgn, A2);
+#endif
         MTQ_PAIR_BARRIER;
     }
-    // preconditions of the exact route (file header); a group outside them only marks its tile
-    G.bad = !(((dor & 0xFFF0FFF0u) == 0u) & (E >= 80u) & (E <= 180u) & (sbs < 65536u));
+    // exact route needs every float32 term normal and finite: E in [80, 180]; anything else marks the tile
+    G.bad = !((E >= 80u) & (E <= 180u));
     const uint32_t bmax = max(bmaxp & 0xFFFFu, bmaxp >> 16);
-    const int e1 = (int)E - 149, e2 = 2 * (int)E - 298;         // 2^(Eâˆ’149), 2^(2Eâˆ’298)
-    G.term[0] = __builtin_ldexp((double)(sxa * 256 + sxb), e1);
+    const int e1 = (int)E - 148, e2 = 2 * (int)E - 296;         // 2^(Eâˆ’148), 2^(2Eâˆ’296)
+    G.term[0] = __builtin_ldexp((double)(sxa * 128 + sxb), e1);
     const double a2 = ((double)sa2[0] + (double)sa2[1]) + ((double)sa2[2] + (double)sa2[3]);  // exact (< 2^35)
-    G.term[1] = __builtin_ldexp(__builtin_fma(a2, 65536.0, (double)sb2), e2);                  // exact (< 2^51)
-    const float sf = __uint_as_float(((E - 22u) & 0xFFu) << 23); // 2^(Eâˆ’149) as float32 (garbage-safe when the group is bad)
+    G.term[1] = __builtin_ldexp(__builtin_fma(a2, 16384.0, (double)sb2), e2);                  // exact (< 2^49)
+    const float sf = __uint_as_float(((E - 21u) & 0xFFu) << 23); // 2^(Eâˆ’148) as float32 (masked: garbage-safe when bad)
     const FmtAcc *A[3] = {&A8, &A4, &A2};
     const int mbs[3] = {7, 3, 1};
 #pragma unroll
     for (int f = 0; f < 3; ++f) {
-        G.term[2 + 4 * f] = __builtin_ldexp((double)A[f]->ssy, e1 + 8);                       // Î£Â±y Â· 2^(Eâˆ’141)
+        G.term[2 + 4 * f] = __builtin_ldexp((double)A[f]->ssy, e1 + 7);                       // Î£Â±y Â· 2^(Eâˆ’141)
         G.term[3 + 4 * f] = __builtin_ldexp((double)A[f]->sq2, 2 * ((int)E - 126 - mbs[f]));  // Î£qÂ² Â· 2^(2(Eâˆ’126âˆ’mb))
         G.term[4 + 4 * f] = __builtin_ldexp((double)A[f]->saq, 2 * (int)E - 267 - mbs[f]);    // Î£aÂ·q Â· 2^(2Eâˆ’267âˆ’mb)
-        G.term[5 + 4 * f] = __builtin_ldexp((double)((A[f]->sad << 8) + sbs), e1);            // (256Â·Î£|aâˆ’y| + Î£b) Â· 2^(Eâˆ’149)
-        G.mx[f] = (float)max(fmt_maxabs(*A[f]) << 8, bmax) * sf; // integer < 2^24: exact
+        G.term[5 + 4 * f] = __builtin_ldexp((double)((A[f]->sad << 7) + sbs), e1);            // (128Â·Î£|aâˆ’y| + Î£b) Â· 2^(Eâˆ’148)
+        G.mx[f] = (float)max(fmt_maxabs(*A[f]) << 7, bmax) * sf; // integer < 2^23: exact
+    }
+    // tail class (more than 14 binades below the maximum; y = 0 in every BFP format): summed separately in
+    // index order and added once â€” S = S_main + S_tail (include/mtq.h).  Zeros contribute nothing and are skipped.
+    if (__builtin_expect((dor & 0x00100010u) != 0u, 0)) {
+        double tx = 0.0, tx2 = 0.0, tab = 0.0;
+        float tmx = 0.0f;
+        uint32_t w2[8];
+        reload(w2);                                             // the group again, from the LDS image (keeps w[] dead after the pair loop)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const uint32_t a2 = w2[i] & 0x7FFF7FFFu;
+            const uint32_t dd = Ep - ((a2 >> 7) & 0x00FF00FFu);
+            if ((dd & 0xFFFFu) > 14u && (a2 & 0xFFFFu) != 0u) {
+                const float xv = __uint_as_float(w2[i] << 16), p = xv * xv, av = fabsf(xv);
+                tx += (double)xv; tx2 += (double)p; tab += (double)av; tmx = fmaxf(tmx, av);
+            }
+            if ((dd >> 16) > 14u && (a2 >> 16) != 0u) {
+                const float xv = __uint_as_float(w2[i] & 0xFFFF0000u), p = xv * xv, av = fabsf(xv);
+                tx += (double)xv; tx2 += (double)p; tab += (double)av; tmx = fmaxf(tmx, av);
+            }
+        }
+        G.term[0] += tx;
+        G.term[1] += tx2;
+#pragma unroll
+        for (int f = 0; f < 3; ++f) { G.term[5 + 4 * f] += tab; G.mx[f] = fmaxf(G.mx[f], tmx); }
     }
 }
 
-__global__ __launch_bounds__(kFastWaves * 64, MTQ_FAST_WAVES_PER_SIMD) void tile_stats_bf16_fast(const uint16_t *__restrict__ x, int64_t stride,
-                                                                            int64_t ld, int tiles_w, int64_t tiles, int units_w,
-                                                                            int units_per_tensor, int total_units,
-                                                                            uint32_t fmt_mask, int rec, double *__restrict__ stats)
+// ---------------------------------------------------------------------------------------------
+// The kernel.  The 4 groups of a lane run in a ROLLED loop that reads each group from the LDS image just
+// before use (a fully unrolled, software-pipelined form needed 230 VGPRs and ran no faster: the kernel is
+// VALU-issue bound).  ~115 VGPRs â†’ 4 waves per SIMD; the reduce scratch and the record image
+// overlay the input image (8 KiB of LDS per wave) and the next unit's DMA is issued once the records sit in
+// registers.  Latency is hidden by occupancy instead of by a software pipeline.
+// ---------------------------------------------------------------------------------------------
+constexpr int kRolledWaveLds = kInBytes; // 8192 B: input image, then (scratch 3808 B | records 704 B)
+
+// LDS-DMA through inline asm (the compiler then does not drain vmcnt before unrelated LDS reads; waits are ours).
+__device__ __forceinline__ void glds16(const void *sbase, uint32_t voff, uint32_t lds_addr)
+{
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_addr) : "memory");
+}
+
+__global__ __launch_bounds__(kFastWaves * 64, MTQ_ROLLED_WAVES_PER_SIMD) void tile_stats_bf16_rolled(
+    const uint16_t *__restrict__ x, int64_t stride, int64_t ld, int tiles_w, int64_t tiles, int units_w, int units_per_tensor,
+    int total_units, uint32_t fmt_mask, int rec, double *__restrict__ stats)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: unit bookkeeping stays on the SALU
-    unsigned char *in = lds + wave * kWaveLds;
-    double *scratch = reinterpret_cast<double *>(in + kInBytes);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    unsigned char *in = lds + wave * kRolledWaveLds;
+    double *scratch = reinterpret_cast<double *>(in);                       // overlays the image after the reads
+    double *recbuf = scratch + kScratchDoubles;
+    const uint32_t in_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)in;
     const uint32_t t = lane >> 4, j = lane & 15;
 
-    // LDS-DMA source map: instruction i fills rows 4i..4i+3; lane l â†’ row 4i + (l>>4), 16-B chunk (l&15) ^ swz(2i + (l>>5)).
-    // Per-lane BYTE offsets from the unit's first element, one per instruction (loop-invariant).
     uint32_t dma_off[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -198,14 +242,13 @@ __global__ __launch_bounds__(kFastWaves * 64, MTQ_FAST_WAVES_PER_SIMD) void tile
         const uint32_t c = (lane & 15u) ^ swz(2u * i + (rho >> 1));
         dma_off[i] = (uint32_t)((4 * i + rho) * ld * 2) + c * 16u;
     }
-    // per-lane read offsets: block j>>1, row-in-block 2(j&1)+kh, chunk (4t+kl) ^ swz(j)
     const uint32_t rd_base = (j >> 1) * 1024u + (2u * (j & 1u)) * 256u;
-    uint32_t rd_slot[4];
-#pragma unroll
-    for (int kl = 0; kl < 4; ++kl) rd_slot[kl] = ((4u * t + kl) ^ swz(j)) * 16u;
+    const uint32_t c0 = (4u * t) ^ swz(j);                                    // chunk (4t+kl)^swz(j) = c0 ^ kl
 
     const int wave_global = (int)blockIdx.x * kFastWaves + wave;
     const int wave_count = (int)gridDim.x * kFastWaves;
+    const int o_bf16 = 2, o8 = 2 + 5 * __builtin_popcount(fmt_mask & 1u), o4 = 2 + 5 * __builtin_popcount(fmt_mask & 3u),
+              o2 = 2 + 5 * __builtin_popcount(fmt_mask & 7u);
 
     auto unit_base = [&](int u, int &b, int &tr, int &uc) {
         b = u / units_per_tensor;
@@ -218,70 +261,38 @@ __global__ __launch_bounds__(kFastWaves * 64, MTQ_FAST_WAVES_PER_SIMD) void tile
         unit_base(u, b, tr, uc);
         const unsigned char *base = reinterpret_cast<const unsigned char *>(x + (int64_t)b * stride + ((int64_t)tr * kTile) * ld + (int64_t)uc * kUnitCols);
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(base + dma_off[i]),
-                                             (__attribute__((address_space(3))) void *)(in + i * 1024), 16, 0, 0);
-    };
-
-    // output: the 4 records of a unit are contiguous in `stats` (tiles uc*4 .. uc*4+3); they are assembled in
-    // LDS and leave as kRecStores coalesced wave-stores, so the loop-top wait can be a COUNTED vmcnt that
-    // retires the LDS-DMA of this unit without waiting for the previous unit's stores.
-    const int o_bf16 = 2, o8 = 2 + 5 * __builtin_popcount(fmt_mask & 1u), o4 = 2 + 5 * __builtin_popcount(fmt_mask & 3u),
-              o2 = 2 + 5 * __builtin_popcount(fmt_mask & 7u);
-    double *recbuf = scratch + kScratchDoubles;                 // [4 tiles][rec] doubles
-
-    auto read_rows = [&](int kh, uint32_t w0[8], uint32_t w1[8]) {
-        const uint4 a0 = *reinterpret_cast<const uint4 *>(in + rd_base + kh * 256u + rd_slot[0]);
-        const uint4 a1 = *reinterpret_cast<const uint4 *>(in + rd_base + kh * 256u + rd_slot[1]);
-        const uint4 b0 = *reinterpret_cast<const uint4 *>(in + rd_base + kh * 256u + rd_slot[2]);
-        const uint4 b1 = *reinterpret_cast<const uint4 *>(in + rd_base + kh * 256u + rd_slot[3]);
-        w0[0] = a0.x; w0[1] = a0.y; w0[2] = a0.z; w0[3] = a0.w; w0[4] = a1.x; w0[5] = a1.y; w0[6] = a1.z; w0[7] = a1.w;
-        w1[0] = b0.x; w1[1] = b0.y; w1[2] = b0.z; w1[3] = b0.w; w1[4] = b1.x; w1[5] = b1.y; w1[6] = b1.z; w1[7] = b1.w;
+        for (int i = 0; i < 8; ++i) glds16(base, dma_off[i], in_addr + i * 1024);
     };
 
     int u = wave_global;
     if (u < total_units) issue_dma(u);
-    bool first = true;
     for (; u < total_units; u += wave_count) {
-        // in-order VM counter: [DMA(u) x8] [stores(u-1) x kRecStores]; leave only the stores in flight
-        if (first) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-        first = false;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                     // image landed (and the previous records retired)
 
-        // the lane's 4 groups, summed sequentially: ((g0 + g1) + g2) + g3  (rows 2j then 2j+1)
         double acc[kSums];
-        float mx[3];
-        bool bad;
-        {
+#pragma unroll
+        for (int s = 0; s < kSums; ++s) acc[s] = 0.0;
+        float mx[3] = {0.0f, 0.0f, 0.0f};
+        bool bad = false;
+#pragma nounroll
+        for (int g = 0; g < 4; ++g) {                                         // rows 2j (g = 0,1) then 2j+1 (g = 2,3)
+            const uint32_t kl = 2u * (g & 1);
+            const unsigned char *rowp = in + rd_base + (g >> 1) * 256u;
+            const uint4 lo = *reinterpret_cast<const uint4 *>(rowp + ((c0 ^ kl) << 4));
+            const uint4 hi = *reinterpret_cast<const uint4 *>(rowp + ((c0 ^ (kl | 1u)) << 4));
+            const uint32_t w[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
             GroupOut G;
-            uint32_t w0[8], w1[8];
-            read_rows(0, w0, w1);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            fast_group(w0, G);
+            fast_group(w, G, [&](uint32_t w2[8]) {
+                const uint4 l2 = *reinterpret_cast<const uint4 *>(rowp + ((c0 ^ kl) << 4));
+                const uint4 h2 = *reinterpret_cast<const uint4 *>(rowp + ((c0 ^ (kl | 1u)) << 4));
+                w2[0] = l2.x; w2[1] = l2.y; w2[2] = l2.z; w2[3] = l2.w; w2[4] = h2.x; w2[5] = h2.y; w2[6] = h2.z; w2[7] = h2.w;
+            });
 #pragma unroll
-            for (int s = 0; s < kSums; ++s) acc[s] = G.term[s];
-            mx[0] = G.mx[0]; mx[1] = G.mx[1]; mx[2] = G.mx[2]; bad = G.bad;
-            MTQ_SCHED_BARRIER;
-            fast_group(w1, G);
-#pragma unroll
-            for (int s = 0; s < kSums; ++s) acc[s] = acc[s] + G.term[s];
-            mx[0] = fmaxf(mx[0], G.mx[0]); mx[1] = fmaxf(mx[1], G.mx[1]); mx[2] = fmaxf(mx[2], G.mx[2]); bad |= G.bad;
-            MTQ_SCHED_BARRIER;
-            read_rows(1, w0, w1);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // the registers hold the rest of the unit: the image may be overwritten
-            if (u + wave_count < total_units) issue_dma(u + wave_count);
-            fast_group(w0, G);
-#pragma unroll
-            for (int s = 0; s < kSums; ++s) acc[s] = acc[s] + G.term[s];
-            mx[0] = fmaxf(mx[0], G.mx[0]); mx[1] = fmaxf(mx[1], G.mx[1]); mx[2] = fmaxf(mx[2], G.mx[2]); bad |= G.bad;
-            MTQ_SCHED_BARRIER;
-            fast_group(w1, G);
-#pragma unroll
-            for (int s = 0; s < kSums; ++s) acc[s] = acc[s] + G.term[s];
-            mx[0] = fmaxf(mx[0], G.mx[0]); mx[1] = fmaxf(mx[1], G.mx[1]); mx[2] = fmaxf(mx[2], G.mx[2]); bad |= G.bad;
+            for (int s = 0; s < kSums; ++s) acc[s] = acc[s] + G.term[s];   // 0.0 + t = t exactly: sequential ((g0+g1)+g2)+g3
+            mx[0] = fmaxf(mx[0], G.mx[0]); mx[1] = fmaxf(mx[1], G.mx[1]); mx[2] = fmaxf(mx[2], G.mx[2]);
+            bad |= G.bad;
         }
 
-        // maxima: lane permutes inside the 16-lane row
 #pragma unroll
         for (int f = 0; f < 3; ++f) {
 #pragma unroll
@@ -289,9 +300,8 @@ __global__ __launch_bounds__(kFastWaves * 64, MTQ_FAST_WAVES_PER_SIMD) void tile
         }
         const unsigned long long bad_lanes = __ballot(bad);
         const bool tile_bad = ((bad_lanes >> (16 * t)) & 0xFFFFull) != 0ull;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                   // every lane's image reads are done: overlay may begin
 
-        // sums: two passes of 7 statistics through the LDS scratch; lane j (< 7) reduces statistic 7*pass + j
-        // over the 16 row pairs by a balanced tree and drops it into the record image
         double *rec_t = recbuf + t * rec;
 #pragma unroll
         for (int pass = 0; pass < 2; ++pass) {
@@ -311,7 +321,7 @@ __global__ __launch_bounds__(kFastWaves * 64, MTQ_FAST_WAVES_PER_SIMD) void tile
                 const int sidx = 7 * pass + (int)j;
                 if (sidx == 0) {
                     rec_t[0] = r;
-                    if (fmt_mask & 1u) { // bf16 of bf16 data: y = x, so |xâˆ’y| is +0 â€” or NaN when the tile holds Inf/NaN (inf âˆ’ inf)
+                    if (fmt_mask & 1u) {
                         const double z = __builtin_fabs(r) * 0.0;
                         rec_t[o_bf16] = r; rec_t[o_bf16 + 3] = z; rec_t[o_bf16 + 4] = z;
                     }
@@ -324,7 +334,7 @@ __global__ __launch_bounds__(kFastWaves * 64, MTQ_FAST_WAVES_PER_SIMD) void tile
                     if (fmt_mask & (2u << f)) rec_t[o + k] = r;
                 }
             }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // pass 0's reads are done before pass 1 overwrites the scratch
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
         if (j == 15) {
             if (fmt_mask & 2u) rec_t[o8 + 4] = (double)mx[0];
@@ -332,16 +342,20 @@ __global__ __launch_bounds__(kFastWaves * 64, MTQ_FAST_WAVES_PER_SIMD) void tile
             if (fmt_mask & 8u) rec_t[o2 + 4] = (double)mx[2];
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (tile_bad && j == 0) rec_t[0] = __longlong_as_double((long long)kRedoMagic); // after the reducers' own write of rec_t[0]
+        if (tile_bad && j == 0) rec_t[0] = __longlong_as_double((long long)kRedoMagic);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 
-        // 4 records = 4*rec contiguous doubles: exactly kRecStores wave-stores (masked lanes keep the count fixed)
         int b, tr, uc;
         unit_base(u, b, tr, uc);
         double *out = stats + ((int64_t)b * tiles + (int64_t)tr * tiles_w + uc * kUnitTiles) * rec;
-        const int nrec = kUnitTiles * rec;                      // â‰¤ 88
-        if (lane < nrec) out[lane] = recbuf[lane];
-        if (lane + 64 < nrec) out[lane + 64] = recbuf[lane + 64];
+        const int nrec = kUnitTiles * rec;
+        double r0 = 0.0, r1 = 0.0;
+        if (lane < nrec) r0 = recbuf[lane];
+        if (lane + 64 < nrec) r1 = recbuf[lane + 64];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                   // records are in registers: the image may be refilled
+        if (u + wave_count < total_units) issue_dma(u + wave_count);
+        if (lane < nrec) out[lane] = r0;
+        if (lane + 64 < nrec) out[lane + 64] = r1;
     }
 }
 
@@ -364,10 +378,10 @@ extern "C" int mtq_launch_tile_stats_bf16_fast(const void *x, int64_t count, int
         if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess) return fail(MTQ_ERR_HIP, "hipGetDeviceProperties failed");
         cus = p.multiProcessorCount;
     }
-    const int64_t max_blocks = (int64_t)cus * MTQ_FAST_WAVES_PER_SIMD; // blocks of 4 waves per CU (one wave of each per SIMD)
     const int64_t need = (total + kFastWaves - 1) / kFastWaves;
+    const int64_t max_blocks = (int64_t)cus * MTQ_ROLLED_WAVES_PER_SIMD; // blocks of 4 waves per CU (one wave of each per SIMD)
     const unsigned blocks = (unsigned)(need < max_blocks ? need : max_blocks);
-    hipLaunchKernelGGL(tile_stats_bf16_fast, dim3(blocks), dim3(kFastWaves * 64), kFastWaves * kWaveLds, static_cast<hipStream_t>(stream),
+    hipLaunchKernelGGL(tile_stats_bf16_rolled, dim3(blocks), dim3(kFastWaves * 64), kFastWaves * kRolledWaveLds, static_cast<hipStream_t>(stream),
                        static_cast<const uint16_t *>(x), stride_elems, ld, (int)tw, tiles, (int)units_w, (int)upt, (int)total, fmt_mask, rec, stats);
     return check_launch("mtq_tile_stats (bf16 fast)");
 }
