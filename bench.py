@@ -66,8 +66,8 @@ def main() -> None:
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--tensors", type=int, default=32, help="4096x4096 bf16 tensors per step per GPU (32 = 1 GiB)")
-    ap.add_argument("--chunk", type=int, default=8, help="tensors per K1 launch")
-    ap.add_argument("--workers", type=int, default=int(os.environ.get("MTQ_SCAN_WORKERS", "12")), help="host scan threads per rank")
+    ap.add_argument("--chunk", type=int, default=16, help="tensors per K1 launch")
+    ap.add_argument("--workers", type=int, default=int(os.environ.get("MTQ_SCAN_WORKERS", str(max(2, min(32, (os.cpu_count() or 8) - 2))))), help="host scan threads per rank")
     ap.add_argument("--cpu-sample", type=int, default=12, help="tensors timed on the CPU port (0 = skip)")
     args = ap.parse_args()
 

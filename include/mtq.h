@@ -131,6 +131,26 @@ int mtq_greedy_value(const mtq_greedy *g, double *value);
 void mtq_greedy_destroy(mtq_greedy *g);
 
 /*
+ * NumPy-compatible generator for the visiting order: mtq_rng_create(seed) ≡ np.random.default_rng(seed),
+ * successive mtq_rng_permutation(n) ≡ successive rng.permutation(n) (SeedSequence → PCG64 → Fisher–Yates with
+ * masked rejection sampling, NumPy ≥ 1.17).  rng.permutation(a) == a[rng.permutation(len(a))].
+ */
+typedef struct mtq_rng mtq_rng; /* opaque */
+int mtq_rng_create(mtq_rng **out, uint64_t seed);
+int mtq_rng_permutation(mtq_rng *r, int64_t n, int64_t *out);
+void mtq_rng_destroy(mtq_rng *r);
+
+/*
+ * The whole greedy search of one tensor on host records (mixed_tile_greedy.py:95-346): passes in `formats`
+ * order (formats[0] is the base format), candidates = np.where(~fixed)[0], order = permutation(candidates) from
+ * default_rng(seed) (seed != 0).  map: int8[tiles]; counts: per MIXED_TILE_FORMATS entry; out[9] as
+ * mtq_columns_from_stats.  Thread-safe; the streamed driver calls it from worker threads.
+ */
+int mtq_greedy_run(const double *stats, int64_t tiles, uint32_t fmt_mask, const int *formats, int n_formats,
+                   int metric, double threshold, double elem_count, uint64_t seed, int8_t *map,
+                   int64_t counts[4], double out[9]);
+
+/*
  * Per-tile scores from the raw sums, n = 1024 (tile_utils.py:46-57 semantics on float64 moments):
  * pcc via the moment formula, mae = Σ|d|/1024, atol = max|d|.  scores is [popcount(mask)][tiles],
  * formats in ascending mask-bit order.

@@ -2,8 +2,8 @@
 
 Global-metric-constrained greedy demotion of tiles in seeded random order.  Decomposed as:
 per-tile stats records for every listed format (tile_search.compute_tile_stats: K1 on the GPU for
-backend "hip") + the literal sequential scan on the host (mtq_greedy_* of libmtq_hip.so, C++) driven by
-NumPy's own Generator for the visiting order (:222-231).  Bit-identical maps to the reference.
+backend "hip") + the literal sequential scan on the host (mtq_greedy_run of libmtq_hip.so, C++) with a
+NumPy-bit-compatible generator for the visiting order (:222-231).  Bit-identical maps to the reference.
 """
 from __future__ import annotations
 
@@ -38,11 +38,22 @@ def parse_tile_formats(value) -> list[str]:
 
 
 def greedy_scan(ts: TileStats, tile_formats: list[str], metric: str, threshold: float, seed: int):
-    """reference :95-103 (setup), :133-220 (initial sums), :222-346 (passes) on a TileStats."""
+    """reference :95-103 (setup), :133-220 (initial sums), :222-346 (passes) on a TileStats: one call into the
+    host C++ scan, whose visiting order is a bit-compatible restatement of np.random.default_rng(seed).permutation
+    (mtq_rng, pinned against NumPy in tests/test_capi_host.py)."""
     from .. import hip_backend as hb
 
     if seed == 0:
         seed = secrets.randbits(31)  # :223-224
+    amap, counts, cols = hb.greedy_run(ts.stats, ts.mask, tile_formats, metric, threshold, float(ts.numel), seed)
+    value = cols["pcc"] if metric == "pcc" else (cols["mae"] if metric == "mae" else cols["atol"])
+    return amap.reshape(ts.tiles_h, ts.tiles_w), counts, value
+
+
+def greedy_scan_numpy_rng(ts: TileStats, tile_formats: list[str], metric: str, threshold: float, seed: int):
+    """Same scan with NumPy's own Generator supplying every pass's order (the literal :225-231)."""
+    from .. import hip_backend as hb
+
     scan = hb.GreedyScan(ts.stats, ts.mask, metric, threshold, float(ts.numel), tile_formats[0])
     try:
         rng = np.random.default_rng(seed)  # :225

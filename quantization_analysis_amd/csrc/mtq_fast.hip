@@ -215,6 +215,7 @@ __device__ __forceinline__ void fast_group(const uint32_t w[8], GroupOut &G, Rel
 // registers.  Latency is hidden by occupancy instead of by a software pipeline.
 // ---------------------------------------------------------------------------------------------
 constexpr int kRolledWaveLds = kInBytes; // 8192 B: input image, then (scratch 3808 B | records 704 B)
+static_assert((kScratchDoubles + kRecDoubles) * 8 <= kInBytes, "reduce scratch + record image must fit in the input image");
 
 // LDS-DMA through inline asm (the compiler then does not drain vmcnt before unrelated LDS reads; waits are ours).
 __device__ __forceinline__ void glds16(const void *sbase, uint32_t voff, uint32_t lds_addr)

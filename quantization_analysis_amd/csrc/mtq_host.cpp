@@ -351,3 +351,145 @@ extern "C" int mtq_columns_from_stats(const double *stats, int64_t tiles, uint32
     out[3] = sx; out[4] = sx2; out[5] = sy; out[6] = sy2; out[7] = sxy; out[8] = sab;
     return MTQ_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// NumPy-compatible visiting order (mixed_tile_greedy.py:222-231 uses np.random.default_rng(seed) and
+// rng.permutation(candidates)).  Bit-compatible restatement of NumPy's published algorithms:
+// SeedSequence (numpy/random/bit_generator.pyx: hashmix/mix pool of 4 uint32) → PCG64 (128-bit LCG,
+// XSL-RR output, numpy/random/src/pcg64) → Generator.permutation = Fisher–Yates from the top with
+// random_interval's masked rejection sampling on 32-bit draws (numpy/random/_generator.pyx,
+// src/distributions/distributions.c).  Pinned against NumPy itself in tests/test_capi_host.py.
+// permutation(array) == array[permutation(len(array))] for the same generator state.
+// ------------------------------------------------------------------------------------------------
+struct mtq_rng {
+    unsigned __int128 state, inc;
+    bool has32;
+    uint32_t u32;
+};
+
+namespace {
+
+const unsigned __int128 kPcgMult = ((unsigned __int128)0x2360ED051FC65DA4ull << 64) | 0x4385DF649FCCF645ull;
+
+inline void pcg_step(mtq_rng *r) { r->state = r->state * kPcgMult + r->inc; }
+
+inline uint64_t pcg_next64(mtq_rng *r)
+{
+    pcg_step(r);
+    const uint64_t hi = (uint64_t)(r->state >> 64), lo = (uint64_t)r->state;
+    const uint64_t x = hi ^ lo;
+    const unsigned rot = (unsigned)(r->state >> 122);
+    return (x >> rot) | (x << ((64u - rot) & 63u));
+}
+
+inline uint32_t pcg_next32(mtq_rng *r)
+{
+    if (r->has32) { r->has32 = false; return r->u32; }
+    const uint64_t n = pcg_next64(r);
+    r->has32 = true;
+    r->u32 = (uint32_t)(n >> 32);
+    return (uint32_t)n;
+}
+
+inline uint64_t rng_interval(mtq_rng *r, uint64_t max)
+{
+    if (max == 0) return 0;
+    uint64_t mask = max;
+    mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16; mask |= mask >> 32;
+    uint64_t v;
+    if (max <= 0xFFFFFFFFull) { while ((v = (pcg_next32(r) & mask)) > max) {} }
+    else { while ((v = (pcg_next64(r) & mask)) > max) {} }
+    return v;
+}
+
+void rng_seed(mtq_rng *r, uint64_t seed)
+{
+    // SeedSequence(seed): entropy = little-endian uint32 words of the integer (at least one word)
+    uint32_t ent[2];
+    int n_ent = 1;
+    ent[0] = (uint32_t)seed;
+    if (seed >> 32) { ent[1] = (uint32_t)(seed >> 32); n_ent = 2; }
+    uint32_t hc = 0x43b0d7e5u; // INIT_A
+    auto hashmix = [&](uint32_t v) { v ^= hc; hc *= 0x931e8875u; v *= hc; v ^= v >> 16; return v; };
+    auto mix = [](uint32_t x, uint32_t y) { uint32_t t = 0xca01f9ddu * x - 0x4973f715u * y; t ^= t >> 16; return t; };
+    uint32_t pool[4];
+    for (int i = 0; i < 4; ++i) pool[i] = hashmix(i < n_ent ? ent[i] : 0u);
+    for (int s = 0; s < 4; ++s)
+        for (int d = 0; d < 4; ++d)
+            if (s != d) pool[d] = mix(pool[d], hashmix(pool[s]));
+    // generate_state(4, uint64) = 8 uint32 words
+    uint32_t hb = 0x8b51f9ddu, w[8];
+    for (int i = 0; i < 8; ++i) { uint32_t v = pool[i & 3]; v ^= hb; hb *= 0x58f38dedu; v *= hb; v ^= v >> 16; w[i] = v; }
+    const uint64_t u0 = w[0] | ((uint64_t)w[1] << 32), u1 = w[2] | ((uint64_t)w[3] << 32);
+    const uint64_t u2 = w[4] | ((uint64_t)w[5] << 32), u3 = w[6] | ((uint64_t)w[7] << 32);
+    const unsigned __int128 initstate = ((unsigned __int128)u0 << 64) | u1, initseq = ((unsigned __int128)u2 << 64) | u3;
+    r->state = 0;
+    r->inc = (initseq << 1) | 1u;
+    pcg_step(r);
+    r->state += initstate;
+    pcg_step(r);
+    r->has32 = false;
+    r->u32 = 0;
+}
+
+void rng_permutation(mtq_rng *r, int64_t n, int64_t *out)
+{
+    for (int64_t i = 0; i < n; ++i) out[i] = i;
+    for (int64_t i = n - 1; i >= 1; --i) {
+        const int64_t j = (int64_t)rng_interval(r, (uint64_t)i);
+        const int64_t t = out[i]; out[i] = out[j]; out[j] = t;
+    }
+}
+
+} // namespace
+
+extern "C" int mtq_rng_create(mtq_rng **out, uint64_t seed)
+{
+    if (!out) return fail(MTQ_ERR_INVALID, "null argument");
+    mtq_rng *r = new (std::nothrow) mtq_rng();
+    if (!r) return fail(MTQ_ERR_INVALID, "out of memory");
+    rng_seed(r, seed);
+    *out = r;
+    return MTQ_OK;
+}
+
+extern "C" int mtq_rng_permutation(mtq_rng *r, int64_t n, int64_t *out)
+{
+    if (!r || (!out && n > 0) || n < 0) return fail(MTQ_ERR_INVALID, "bad argument");
+    rng_permutation(r, n, out);
+    return MTQ_OK;
+}
+
+extern "C" void mtq_rng_destroy(mtq_rng *r) { delete r; }
+
+// The whole search of one tensor (mixed_tile_greedy.py:95-346) on host records: H1 passes in `formats`
+// order, visiting order from the NumPy-compatible generator above.
+extern "C" int mtq_greedy_run(const double *stats, int64_t tiles, uint32_t fmt_mask, const int *formats, int n_formats,
+                              int metric, double threshold, double elem_count, uint64_t seed, int8_t *map,
+                              int64_t counts[4], double out[9])
+{
+    if (!stats || !formats || !map) return fail(MTQ_ERR_INVALID, "null argument");
+    if (n_formats <= 0 || n_formats > MTQ_NUM_TILE_FORMATS) return fail(MTQ_ERR_INVALID, "n_formats must be 1..4");
+    if (seed == 0) return fail(MTQ_ERR_INVALID, "seed 0 means 'draw a random seed' in the reference; resolve it before calling");
+    mtq_greedy *g = nullptr;
+    if (int rc = mtq_greedy_create(&g, stats, tiles, fmt_mask, metric, threshold, elem_count, formats[0])) return rc;
+    mtq_rng rng;
+    rng_seed(&rng, seed);
+    std::vector<int64_t> cand((size_t)tiles), perm((size_t)tiles), order((size_t)tiles);
+    int rc = MTQ_OK;
+    for (int f = 0; f < n_formats && rc == MTQ_OK; ++f) {
+        int64_t n = 0;
+        for (int64_t t = 0; t < tiles; ++t) if (!g->fixed[(size_t)t]) cand[(size_t)n++] = t; // np.where(~fixed)[0], :228
+        if (n == 0) break;                                                                     // :229-230
+        rng_permutation(&rng, n, perm.data());                                                // :231
+        for (int64_t i = 0; i < n; ++i) order[(size_t)i] = cand[(size_t)perm[(size_t)i]];
+        rc = mtq_greedy_pass(g, formats[f], order.data(), n);
+    }
+    if (rc == MTQ_OK) {
+        std::memcpy(map, g->assign.data(), (size_t)tiles);
+        if (counts) for (int f = 0; f < MTQ_NUM_TILE_FORMATS; ++f) counts[f] = g->counts[f];
+        if (out) rc = mtq_columns_from_stats(stats, tiles, fmt_mask, map, elem_count, out);
+    }
+    mtq_greedy_destroy(g);
+    return rc;
+}

@@ -29,6 +29,7 @@ EXPORTS = [
     "mtq_greedy_create", "mtq_greedy_pass", "mtq_greedy_assignment", "mtq_greedy_fixed",
     "mtq_greedy_counts", "mtq_greedy_value", "mtq_greedy_destroy",
     "mtq_tile_scores", "mtq_threshold_assign", "mtq_columns_from_stats",
+    "mtq_rng_create", "mtq_rng_permutation", "mtq_rng_destroy", "mtq_greedy_run",
 ]
 
 
@@ -85,6 +86,11 @@ def lib() -> ctypes.CDLL:
     L.mtq_tile_scores.argtypes = [vp, i64, u32, ci, vp]
     L.mtq_threshold_assign.argtypes = [vp, i64, u32, vp, ci, ci, dbl, dbl, vp, vp, i64, ctypes.POINTER(i64)]
     L.mtq_columns_from_stats.argtypes = [vp, i64, u32, vp, dbl, vp]
+    L.mtq_rng_create.argtypes = [ctypes.POINTER(vp), ctypes.c_uint64]
+    L.mtq_rng_permutation.argtypes = [vp, i64, vp]
+    L.mtq_rng_destroy.argtypes = [vp]
+    L.mtq_rng_destroy.restype = None
+    L.mtq_greedy_run.argtypes = [vp, i64, u32, vp, ci, ci, dbl, dbl, ctypes.c_uint64, vp, vp, vp]
     if L.mtq_version() < 100:
         raise MtqError("libmtq_hip.so is older than this package")
     _lib = L
@@ -294,6 +300,39 @@ class GreedyScan:
             self.close()
         except Exception:
             pass
+
+
+class NumpyCompatRng:
+    """mtq_rng: bit-compatible with np.random.default_rng(seed).permutation(n) (tests pin it against NumPy)."""
+
+    def __init__(self, seed: int):
+        self._h = ctypes.c_void_p()
+        check(lib().mtq_rng_create(ctypes.byref(self._h), int(seed)))
+
+    def permutation(self, n: int) -> np.ndarray:
+        out = np.empty(int(n), dtype=np.int64)
+        check(lib().mtq_rng_permutation(self._h, int(n), out.ctypes.data))
+        return out
+
+    def __del__(self):
+        try:
+            if self._h:
+                lib().mtq_rng_destroy(self._h)
+        except Exception:
+            pass
+
+
+def greedy_run(stats: np.ndarray, mask: int, formats, metric: str, threshold: float, elem_count: float, seed: int):
+    """H1 end to end in one GIL-free call → (int8[T] map, counts dict, columns dict)."""
+    stats = np.ascontiguousarray(stats, dtype=np.float64)
+    T = stats.shape[0]
+    fm = (ctypes.c_int * len(formats))(*[MIXED_TILE_FORMATS.index(f) for f in formats])
+    amap = np.empty(T, dtype=np.int8)
+    counts = (ctypes.c_int64 * 4)()
+    out = (ctypes.c_double * 9)()
+    check(lib().mtq_greedy_run(stats.ctypes.data, T, mask, fm, len(formats), METRIC_CODE[metric], float(threshold),
+                               float(elem_count), int(seed), amap.ctypes.data, counts, out))
+    return amap, {f: int(counts[i]) for i, f in enumerate(MIXED_TILE_FORMATS)}, {"pcc": out[0], "mae": out[1], "atol": out[2], "sums": tuple(out[3:9])}
 
 
 def tile_scores(stats: np.ndarray, mask: int, metric: str) -> np.ndarray:

@@ -47,21 +47,10 @@ class KernelTiming:
 
 
 def _scan_one(index, stats, mask, tiles_hw, numel, tile_formats, metric, threshold, seed) -> TensorResult:
-    scan = hb.GreedyScan(stats, mask, metric, threshold, float(numel), tile_formats[0])
-    try:
-        rng = np.random.default_rng(seed)  # mixed_tile_greedy.py:225
-        for fmt in tile_formats:
-            cand = np.where(scan.fixed() == 0)[0]
-            if cand.size == 0:
-                break
-            scan.run_pass(fmt, rng.permutation(cand))
-        a = scan.assignment()
-        counts = scan.counts()
-        cols = hb.columns_from_stats(stats, mask, a, float(numel))
-        return TensorResult(index, a.reshape(tiles_hw), counts, mixed_tile_total_bytes(counts), cols["pcc"], cols["mae"],
-                            cols["atol"], scan.value())
-    finally:
-        scan.close()
+    """One tensor's whole search in a single GIL-free C call (mtq_greedy_run)."""
+    a, counts, cols = hb.greedy_run(stats, mask, tile_formats, metric, threshold, float(numel), seed)
+    return TensorResult(index, a.reshape(tiles_hw), counts, mixed_tile_total_bytes(counts), cols["pcc"], cols["mae"],
+                        cols["atol"], cols["pcc"] if metric == "pcc" else (cols["mae"] if metric == "mae" else cols["atol"]))
 
 
 class GreedyPipeline:
@@ -84,13 +73,14 @@ class GreedyPipeline:
         self.timing = KernelTiming()
         self._bufs = {}
 
-    def _buffers(self, slot: int, n: int, tiles: int, rec: int, device):
-        key = (slot, n, tiles, rec)
+    def _buffers(self, count: int, tiles: int, rec: int, device):
+        """Records of a whole batch: device buffer + pinned host mirror (scans read the pinned memory in place)."""
+        key = (count, tiles, rec)
         if key not in self._bufs:
             torch = self.torch
-            dev = torch.empty((n, tiles, rec), dtype=torch.float64, device=device)
-            host = torch.empty((n, tiles, rec), dtype=torch.float64, pin_memory=True)
-            self._bufs[key] = (dev, host)
+            dev = torch.empty((count, tiles, rec), dtype=torch.float64, device=device)
+            host = torch.empty((count, tiles, rec), dtype=torch.float64, pin_memory=True)
+            self._bufs = {key: (dev, host, host.numpy())}
         return self._bufs[key]
 
     def run(self, x3d, seeds=None) -> list[TensorResult]:
@@ -99,38 +89,30 @@ class GreedyPipeline:
         th, tw = hb.tiles_hw(rows, cols)
         tiles, rec = th * tw, hb.record_doubles(self.mask)
         numel = rows * cols
-        futures = []
-        pending = []  # (event, host_buffer, first_index, n)
+        dev, host, host_np = self._buffers(count, tiles, rec, x3d.device)
+        pending = []  # (event, first_index, n)
         self.stream.wait_stream(torch.cuda.current_stream())
-
-        def submit(evt, host, first, n):
-            evt.synchronize()
-            h = host.numpy()
-            for j in range(n):
-                seed = self.seed if seeds is None else int(seeds[first + j])
-                futures.append(self.pool.submit(_scan_one, first + j, h[j].copy(), self.mask, (th, tw), numel,
-                                                self.tile_formats, self.metric, self.threshold, seed))
-
         with torch.cuda.stream(self.stream):
-            for ci, first in enumerate(range(0, count, self.chunk)):
+            for first in range(0, count, self.chunk):
                 n = min(self.chunk, count - first)
-                dev, host = self._buffers(ci % 2, n, tiles, rec, x3d.device)
-                if len(pending) >= 2:  # the buffers of chunk ci-2 are about to be reused
-                    submit(*pending.pop(0))
                 e0 = torch.cuda.Event(enable_timing=True)
                 e1 = torch.cuda.Event(enable_timing=True)
                 e0.record(self.stream)
-                hb.tile_stats_batched(x3d[first:first + n], self.mask, out=dev)
+                hb.tile_stats_batched(x3d[first:first + n], self.mask, out=dev[first:first + n])
                 e1.record(self.stream)
                 self.timing.events.append((e0, e1, n * tiles))
-                host.copy_(dev, non_blocking=True)
+                host[first:first + n].copy_(dev[first:first + n], non_blocking=True)
                 done = torch.cuda.Event()
                 done.record(self.stream)
-                pending.append((done, host, first, n))
-        for p in pending:
-            submit(*p)
+                pending.append((done, first, n))
+        futures = []
+        for evt, first, n in pending:      # scans of chunk k start while chunks k+1.. are still on the GPU
+            evt.synchronize()
+            for j in range(first, first + n):
+                seed = self.seed if seeds is None else int(seeds[j])
+                futures.append(self.pool.submit(_scan_one, j, host_np[j], self.mask, (th, tw), numel, self.tile_formats,
+                                                self.metric, self.threshold, seed))
         results = [f.result() for f in futures]
-        results.sort(key=lambda r: r.index)
         torch.cuda.current_stream().wait_stream(self.stream)
         return results
 

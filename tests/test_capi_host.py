@@ -116,3 +116,28 @@ def test_threshold_best_precision_and_order():
     assert set(amap.tolist()) == {1}
     amap, _ = hb.threshold_assign(stats, 0b1110, ["bfp2", "bfp4"], "pcc", -1.0)
     assert set(amap.tolist()) == {3}
+
+
+def test_numpy_compatible_rng():
+    """mtq_rng must reproduce np.random.default_rng(seed).permutation(n) call for call (the greedy visiting order)."""
+    meta_rng = np.random.default_rng(2026)
+    seeds = [1, 5, 123, 2**31 - 1, 2**32 - 1, 2**32, 2**40 + 3, 2**63 + 11] + [int(s) for s in meta_rng.integers(1, 2**62, size=8)]
+    for seed in seeds:
+        mine, ref = hb.NumpyCompatRng(seed), np.random.default_rng(seed)
+        for n in (16384, 1, 0, 2, 3, 1000, 65537, 7, 129024 // 3):
+            assert np.array_equal(mine.permutation(n), ref.permutation(n)), (seed, n)
+    c = np.sort(meta_rng.choice(100000, 777, replace=False))
+    assert np.array_equal(np.random.default_rng(9).permutation(c), c[hb.NumpyCompatRng(9).permutation(c.size)])
+
+
+def test_greedy_run_equals_numpy_driven_scan(golden_dir):
+    d = np.load(golden_dir / "f4_greedy.npz")
+    meta = json.loads((golden_dir / "golden_meta.json").read_text())["f4"]
+    for name, m in meta.items():
+        x = gen(m["kind"], m["seed"], tuple(m["shape"]))
+        a_np, counts_np, value_np, stats, mask = _host_greedy(x, m["formats"], m["metric"], m["threshold"], m["algo_seed"])
+        a_c, counts_c, cols = hb.greedy_run(stats, mask, m["formats"], m["metric"], m["threshold"], float(x.size), m["algo_seed"])
+        assert np.array_equal(a_c, a_np) and counts_c == counts_np, name
+        assert np.array_equal(a_c.reshape(d[f"{name}_assign"].shape), d[f"{name}_assign"]), name
+    with pytest.raises(hb.MtqError):
+        hb.greedy_run(stats, mask, ["bf16"], "pcc", 0.9, 1.0, 0)  # seed 0 must be resolved by the caller
