@@ -1,0 +1,357 @@
+"""wq — weight quantization analyzer CLI (reference: `wq`, 888 lines) for the mixed-tile path.
+
+Same flags, seed rules, tables and result artifacts as the reference (`wq:37-79,553-586,629-647,753-848,881-882`),
+plus `--backend hip`.  Differences forced by the environment: the model comes from `model_source` (synthetic presets or a
+local safetensors directory, no Hub access), plots are not drawn, and when launched under
+`python -m torch.distributed.run` the matched tensors are sharded over the ranks (one process per GPU) with a single
+gather of fixed-width summary rows to rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import re
+import secrets
+import sys
+import time
+from datetime import datetime
+from pathlib import Path
+
+import numpy as np
+
+from .compression_algorithms import create_algorithm, load_compression_config
+from .compression_algorithms.cache import CacheContext
+from .compression_algorithms.metrics import pearson_corr
+from .compression_algorithms.quantizer import BACKENDS, Quantizer
+from .compression_algorithms.tile_utils import MIXED_TILE_FORMATS
+from .model_source import build_model_index, lpt_shards, resolve_format_list, resolve_selected_tensors, safe_repo_revision_key
+from .quantization_formats import SUPPORTED_FORMATS
+
+FORMAT_BYTES_PER_ELEM = {"bf16": 2.0, "bfp8": 1.088, "bfp4": 0.50097, "bfp2": 0.25097, "fp0": 0.0}  # wq:132-140
+MIXED_ALGOS = {"mixed-tile-greedy", "mixed-tile-threshold"}
+ROW_W = 16  # summary row: idx, comp, fmt, pcc, mae, atol, time, gb, tile_bytes, 4 counts, xmin, xmean, xmax
+
+
+def parse_args(argv=None) -> argparse.Namespace:
+    parser = argparse.ArgumentParser(prog="wq", description="Weight quantization analyzer (mixed-tile path, MI355X backend).")
+    parser.add_argument("repo_or_url", help="'synthetic:<preset>[:seed]' or a local directory of *.safetensors.")
+    parser.add_argument("filter_query", nargs="*", help="Optional filter: substring, or dotted torch-style prefix path.")
+    parser.add_argument("--revision", default="main", help="Revision label (default: main).")
+    parser.add_argument("--cache-dir", default="data/hf-cache", help="Kept for CLI compatibility (unused offline).")
+    parser.add_argument("--limit", type=int, default=None, help="Optional max matched tensors.")
+    parser.add_argument("--backend", choices=list(BACKENDS), default="emulation",
+                        help="Quantization backend for BFP formats (default: emulation; hip = MI355X kernels).")
+    parser.add_argument("--compression-config", type=str, default=None, help="Path to a JSON compression config file (default: none).")
+    parser.add_argument("--recompute", action="store_true", help="Recompute and overwrite cached quantized tensors.")
+    parser.add_argument("--summary", action="store_true", help="Print the aggregate summary (default: off).")
+    parser.add_argument("--results-dir", default="results", help="Root of the result artifacts (default: results).")
+    return parser.parse_args(argv)
+
+
+def _slug(s: str) -> str:
+    return re.sub(r"[^a-zA-Z0-9._-]+", "_", s).strip("_") or "tensor"  # wq:112-113
+
+
+def resolve_seed(config, algo_params: dict):
+    """wq:553-586 → (used_seed, seed_source); mutates algo_params['seed']."""
+    seed_source = None
+    used_seed = None
+    if config.seed is not None:
+        used_seed, seed_source = int(config.seed), "config"
+    elif config.random_seed:
+        used_seed, seed_source = secrets.randbits(31), "random"
+    if used_seed is not None:
+        algo_params["seed"] = used_seed
+    elif "seed" in algo_params:
+        try:
+            p = int(algo_params["seed"])
+        except (TypeError, ValueError):
+            used_seed, seed_source = algo_params["seed"], "params"
+        else:
+            if p == 0:
+                used_seed, seed_source = secrets.randbits(31), "random"
+            else:
+                used_seed, seed_source = p, "params"
+            algo_params["seed"] = used_seed
+    return used_seed, seed_source
+
+
+def write_assignment_outputs(out_dir: Path, tensor_name: str, assignment: np.ndarray, algo_dir: str) -> None:
+    """wq:295-316 (assignment.npy int8 + assignment_mapping.json); the PNG plots are not drawn."""
+    mt_dir = out_dir / algo_dir / _slug(tensor_name)
+    mt_dir.mkdir(parents=True, exist_ok=True)
+    np.save(mt_dir / "assignment.npy", assignment.astype(np.int8))
+    mapping = {
+        "tile_hw": 32,
+        "format_to_int": {fmt: idx for idx, fmt in enumerate(MIXED_TILE_FORMATS)},
+        "int_to_format": MIXED_TILE_FORMATS,
+        "assignment_shape": list(assignment.shape),
+    }
+    with (mt_dir / "assignment_mapping.json").open("w", encoding="utf-8") as f:
+        json.dump(mapping, f, indent=2)
+
+
+def _columns_emulation(xf: np.ndarray, y: np.ndarray):
+    diff = np.abs(xf - y)  # wq:684-687, literal float32
+    return pearson_corr(xf, y), float(np.mean(diff)), float(np.max(diff))
+
+
+def _none_rows_hip(x, formats, quantizer):
+    """`none` baseline on the hip backend: pcc/mae/atol of every pure mixed-tile format come from ONE
+    K1 pass (sum the per-tile records); fp0 from three device reductions.  y is not materialised or cached."""
+    from . import hip_backend as hb
+    from .compression_algorithms.tile_search import compute_tile_stats
+
+    out = {}
+    mixed = [f for f in formats if f in MIXED_TILE_FORMATS]
+    if mixed:
+        ts = compute_tile_stats(x, mixed, quantizer)
+        for f in mixed:
+            amap = np.full(ts.tiles, MIXED_TILE_FORMATS.index(f), dtype=np.int8)
+            c = hb.columns_from_stats(ts.stats, ts.mask, amap, float(ts.numel))
+            out[f] = (c["pcc"], c["mae"], c["atol"])
+    if "fp0" in formats:
+        ax = x.float().abs()
+        mx = float(ax.max()) if ax.numel() else 0.0
+        out["fp0"] = (1.0 if mx == 0.0 else 0.0, float(ax.mean()) if ax.numel() else 0.0, mx)  # metrics.py:14-15 with y = 0
+    return out
+
+
+def _evaluate_tensor(idx, name, index, algorithms, formats, quantizer, args, run_tag, processed_root, results_dir):
+    """One tensor through [none, selected] → list of summary rows (np.float64 [R, ROW_W])."""
+    hip = args.backend == "hip"
+    if hip:
+        import torch
+
+        x = index.load(name, device=torch.device("cuda", torch.cuda.current_device()))
+        xf32 = x.float()
+        meta = (float(xf32.min()), float(xf32.mean()), float(xf32.max())) if x.numel() else (0.0, 0.0, 0.0)
+        numel = int(x.numel())
+    else:
+        x = np.asarray(index.load(name).float().numpy(), dtype=np.float32)
+        meta = (float(np.min(x)), float(np.mean(x)), float(np.max(x))) if x.size else (0.0, 0.0, 0.0)
+        numel = int(x.size)
+    cache_ctx = CacheContext(root=processed_root, tensor_name=name, backend=args.backend, recompute=args.recompute, run_tag=run_tag)
+    rows = []
+    for ci, algo in enumerate(algorithms):
+        t0 = time.perf_counter()
+        if hip and algo.name == "none":
+            cols = _none_rows_hip(x, formats, quantizer)
+            elapsed = time.perf_counter() - t0
+            for f in formats:
+                pcc, mae, atol = cols[f]
+                rows.append([idx, ci, SUPPORTED_FORMATS.index(f), pcc, mae, atol, elapsed, numel * FORMAT_BYTES_PER_ELEM[f] / 1e9,
+                             np.nan, -1, -1, -1, -1, *meta])
+            continue
+        results = algo.run(xf=x, formats=formats, quantizer=quantizer, cache=cache_ctx)
+        if hip:
+            import torch
+
+            torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0  # wall time of run(), wq:680-682
+        for res in results:
+            if hip and res.meta and "columns" in res.meta:
+                c = res.meta["columns"]
+                pcc, mae, atol = c["pcc"], c["mae"], c["atol"]
+            else:
+                y = res.y.cpu().numpy() if hasattr(res.y, "cpu") else res.y
+                xh = x.float().cpu().numpy() if hip else x
+                pcc, mae, atol = _columns_emulation(xh, y)
+            fmt_l = res.fmt.lower()
+            gb = float(res.tile_bytes) / 1e9 if res.tile_bytes is not None else numel * FORMAT_BYTES_PER_ELEM.get(fmt_l, 0.0) / 1e9
+            counts = [res.tile_counts.get(k, 0) for k in MIXED_TILE_FORMATS] if res.tile_counts else [-1, -1, -1, -1]
+            fcode = -1 if res.fmt == "MIXED" else SUPPORTED_FORMATS.index(fmt_l)
+            rows.append([idx, ci, fcode, pcc, mae, atol, elapsed, gb, res.tile_bytes if res.tile_bytes is not None else np.nan,
+                         *counts, *meta])
+            if res.compression in MIXED_ALGOS and res.meta and isinstance(res.meta.get("assignment"), np.ndarray):
+                write_assignment_outputs(results_dir, name, res.meta["assignment"], res.compression.replace("-", "_"))
+    return np.asarray(rows, dtype=np.float64).reshape(-1, ROW_W)
+
+
+def _print_tables(names, rows, comp_names, shapes, table_lines, summary: bool, formats):
+    comp_w = max(len("COMP"), max(len(n) for n in comp_names))
+
+    def emit(line=""):
+        print(line)
+        table_lines.append(line)
+
+    by_tensor: dict[int, list] = {}
+    for r in rows:
+        by_tensor.setdefault(int(r[0]), []).append(r)
+    aggregate: dict[tuple, list] = {}
+    for ti, name in enumerate(names):
+        trs = by_tensor.get(ti, [])
+        if not trs:
+            continue
+        emit(name)
+        emit(f"  shape={shapes[ti]} min={trs[0][13]:.3e} mean={trs[0][14]:.3e} max={trs[0][15]:.3e}")  # wq:82-84
+        for ci, comp in enumerate(comp_names):
+            crs = [r for r in trs if int(r[1]) == ci]
+            if not crs:
+                continue
+            fmts = ["MIXED" if int(r[2]) < 0 else SUPPORTED_FORMATS[int(r[2])].upper() for r in crs]
+            fmt_w = max(len(f) for f in fmts)
+            mixed = comp in MIXED_ALGOS
+            pcc_w = max(len("PCC"), max(len(f"{r[3]: .5f}") for r in crs))
+            mae_w = max(len("MAE"), max(len(f"{r[4]:.3e}") for r in crs))
+            atol_w = max(len("ATOL"), max(len(f"{r[5]:.3e}") for r in crs))
+            time_w = max(len("TIME(s)"), max(len(f"{r[6]:.3f}") for r in crs))
+            gb_w = max(len("GB"), max(len(f"{r[7]:.3f}") for r in crs))
+            header = (f"  {'COMP'.ljust(comp_w)}  {'FORMAT'.ljust(fmt_w)}  {'PCC'.rjust(pcc_w)}  {'MAE'.rjust(mae_w)}  "
+                      f"{'ATOL'.rjust(atol_w)}  {'TIME(s)'.rjust(time_w)}  {'GB'.rjust(gb_w)}")
+            if mixed:  # wq:765-812
+                cw = {k: max(len(k.upper()), max(len(str(int(r[9 + i]))) for r in crs)) for i, k in enumerate(MIXED_TILE_FORMATS)}
+                bytes_w = max(len("BYTES"), max(len(f"{(0.0 if np.isnan(r[8]) else r[8]):,.0f}") for r in crs))
+                header += "  " + "  ".join(k.upper().rjust(cw[k]) for k in MIXED_TILE_FORMATS) + f"  {'BYTES'.rjust(bytes_w)}"
+            emit(header)
+            for r, f in zip(crs, fmts):
+                line = (f"  {comp.ljust(comp_w)}  {f.ljust(fmt_w)}  {f'{r[3]: .5f}'.rjust(pcc_w)}  {f'{r[4]:.3e}'.rjust(mae_w)}  "
+                        f"{f'{r[5]:.3e}'.rjust(atol_w)}  {f'{r[6]:.3f}'.rjust(time_w)}  {f'{r[7]:.3f}'.rjust(gb_w)}")
+                if mixed:
+                    line += "  " + "  ".join(str(int(r[9 + i])).rjust(cw[k]) for i, k in enumerate(MIXED_TILE_FORMATS))
+                    line += f"  {f'{(0.0 if np.isnan(r[8]) else r[8]):,.0f}'.rjust(bytes_w)}"
+                emit(line)
+                aggregate.setdefault((comp, f), []).append(r)
+            emit()
+    if summary:  # wq:851-879
+        emit("Summary (mean across matched tensors)")
+        for comp in comp_names:
+            for f in (["MIXED"] if comp in MIXED_ALGOS else [x.upper() for x in formats]):
+                rs = aggregate.get((comp, f), [])
+                if not rs:
+                    continue
+                pcc, mae, atol = (float(np.mean([r[k] for r in rs])) for k in (3, 4, 5))
+                bv = [r[8] for r in rs if not np.isnan(r[8])]
+                btxt = f"  bytes={float(np.mean(bv)):,.0f}" if bv else ""
+                emit(f"  {comp.ljust(comp_w)} {f:>5}  pcc={pcc: .5f}  mae={mae:.3e}  atol={atol:.3e}{btxt}")
+
+
+def run(argv=None) -> int:
+    args = parse_args(argv)
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if args.backend == "hip":
+        import torch
+
+        if torch.cuda.is_available():
+            torch.cuda.set_device(local_rank)
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if args.backend == "hip":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))  # RCCL
+        else:
+            dist.init_process_group("gloo")
+
+    try:
+        config = load_compression_config(args.compression_config)
+        algo_params = dict(config.params)
+        used_seed, seed_source = resolve_seed(config, algo_params)
+        run_tag = datetime.now().strftime("%Y%m%d-%H%M%S")
+        if dist is not None:  # one seed and one run tag for the whole job (rank 0 decides)
+            box = [used_seed, seed_source, run_tag]
+            dist.broadcast_object_list(box, src=0)
+            used_seed, seed_source, run_tag = box
+            if used_seed is not None:
+                algo_params["seed"] = used_seed
+
+        selected_algo = create_algorithm(config.algorithm, algo_params)
+        baseline = create_algorithm("none", {})
+        algorithms = [baseline] if selected_algo.name == "none" else [baseline, selected_algo]
+        filter_query = " ".join(args.filter_query).strip() or None
+        formats = resolve_format_list(config.quantization_formats, SUPPORTED_FORMATS)
+
+        index = build_model_index(args.repo_or_url, revision=args.revision)
+        try:
+            tensor_names = resolve_selected_tensors(index, filter_query)
+        except RuntimeError:
+            tensor_names = []
+        if args.limit is not None:
+            tensor_names = tensor_names[: max(0, args.limit)]
+        if not tensor_names:
+            print("No tensors matched.", file=sys.stderr)
+            return 1
+        try:
+            quantizer = Quantizer(backend=args.backend)
+            if args.backend == "ttnn":
+                raise RuntimeError("TTNN backend requires `ttnn` in the active Python environment.")  # wq:603-609
+        except Exception as exc:
+            print(f"error: {exc}", file=sys.stderr)
+            return 1
+
+        comp_names = [a.name for a in algorithms]
+        if rank == 0:
+            print(f"{index.repo_id} @{index.revision} - {len(tensor_names)} tensors")
+            print(f"formats: {', '.join(formats)}")
+            print(f"compression: {', '.join(comp_names)}")
+            print(f"backend: {args.backend}" + (f"  ranks: {world}" if world > 1 else ""))
+            if args.compression_config:
+                print(f"config: {args.compression_config}")
+            print()
+
+        results_dir = Path(args.results_dir) / index.repo_id.replace("/", "__") / selected_algo.name / run_tag  # wq:629-631
+        results_dir.mkdir(parents=True, exist_ok=True)
+        if rank == 0:
+            used_params = dict(algo_params)
+            if used_seed is not None:
+                used_params.pop("seed", None)
+            used_config = {"algorithm": config.algorithm, "quantization_formats": formats, "params": used_params}
+            if used_seed is not None:
+                used_config["seed"] = used_seed
+                if seed_source:
+                    used_config["seed_source"] = seed_source
+            with (results_dir / "compression_config.used.json").open("w", encoding="utf-8") as f:  # wq:636-647
+                json.dump(used_config, f, indent=2)
+        processed_root = Path("data/processed") / safe_repo_revision_key(index.repo_id, index.revision)
+
+        shards = lpt_shards(tensor_names, index.numel, world)
+        per_tensor_rows = len(formats) + (0 if selected_algo.name == "none" else 1)
+        my_rows = [
+            _evaluate_tensor(i, tensor_names[i], index, algorithms, formats, quantizer, args, run_tag, processed_root, results_dir)
+            for i in shards[rank]
+        ]
+        mine = np.concatenate(my_rows) if my_rows else np.zeros((0, ROW_W))
+
+        if dist is not None:  # the ONE data-path collective: fixed-width summary rows → rank 0
+            import torch
+
+            cap = max(len(s) for s in shards) * per_tensor_rows
+            dev = torch.device("cuda", local_rank) if args.backend == "hip" else torch.device("cpu")
+            buf = torch.full((cap, ROW_W), float("nan"), dtype=torch.float64, device=dev)
+            buf[: mine.shape[0]] = torch.from_numpy(mine).to(dev)
+            gathered = [torch.empty_like(buf) for _ in range(world)] if rank == 0 else None
+            dist.gather(buf, gathered, dst=0)
+            if rank == 0:
+                allr = torch.cat(gathered).cpu().numpy()
+                allr = allr[~np.isnan(allr[:, 0])]
+        else:
+            allr = mine
+
+        if rank == 0:
+            order = np.lexsort((np.arange(allr.shape[0]), allr[:, 1], allr[:, 0]))
+            allr = allr[order]
+            shapes = {}
+            for i, n in enumerate(tensor_names):
+                shapes[i] = tuple(index.specs[n].shape) if n in index.specs else "?"
+            table_lines: list[str] = []
+            _print_tables(tensor_names, allr, comp_names, shapes, table_lines, args.summary, formats)
+            (results_dir / "table.txt").write_text("\n".join(table_lines) + "\n", encoding="utf-8")  # wq:881-882
+            print(f"results: {results_dir}")
+        return 0
+    finally:
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+
+
+def main() -> None:
+    raise SystemExit(run())
+
+
+if __name__ == "__main__":
+    main()

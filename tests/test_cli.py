@@ -1,0 +1,145 @@
+"""wq CLI: BASELINE configs[0]-style plumbing on the host backend (CPU), the rank-sharded path with a
+world_size-2 gloo job on CPU, and the hip backend on the GPU."""
+import json
+import os
+import re
+import socket
+import subprocess
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from oracle import mtq_oracle as orc
+from quantization_analysis_amd import cli, model_source
+
+ROOT = Path(__file__).resolve().parent.parent
+ALL = ["bf16", "bfp8", "bfp4", "bfp2"]
+
+
+def write_cfg(tmp_path, algo="mixed-tile-greedy", seed=123, params=None):
+    p = tmp_path / "cfg.json"
+    cfg = {"algorithm": algo, "quantization_formats": ["bf16", "bfp8", "bfp4", "bfp2", "fp0"],
+           "params": params or {"metric": "pcc", "threshold": 0.999}}
+    if seed is not None:
+        cfg["seed"] = seed
+    p.write_text(json.dumps(cfg))
+    return str(p)
+
+
+def run_dir(results_root: Path) -> Path:
+    runs = sorted(results_root.glob("*/*/*"))
+    assert len(runs) == 1, runs
+    return runs[0]
+
+
+def strip_time(text: str) -> list[str]:
+    """Table text without the TIME(s) column values (wall times differ run to run)."""
+    out = []
+    for line in text.splitlines():
+        m = re.match(r"^(  \S+\s+\S+\s+\S+\s+\S+\s+\S+\s+)(\S+)(.*)$", line)
+        out.append((m.group(1) + "T" + m.group(3)) if m and not line.strip().startswith("COMP") else line)
+    return out
+
+
+def check_maps_against_oracle(rdir: Path, algo_dir: str, names, index, oracle_fn):
+    for name in names:
+        x = index.load(name).float().numpy()
+        a = np.load(rdir / algo_dir / cli._slug(name) / "assignment.npy")
+        want = oracle_fn(x)
+        assert a.dtype == np.int8 and np.array_equal(a, want), name
+        mapping = json.loads((rdir / algo_dir / cli._slug(name) / "assignment_mapping.json").read_text())
+        assert mapping["int_to_format"] == ALL and mapping["assignment_shape"] == list(a.shape) and mapping["tile_hw"] == 32
+
+
+def test_name_filters_and_sharding():
+    idx = model_source.build_model_index("synthetic:tiny")
+    names = model_source.resolve_selected_tensors(idx, None)
+    assert "model.layers.1.mlp.up.weight_scale_inv" not in names and "lm_head.bias" not in names  # weight-like only (:290-301)
+    assert model_source.resolve_selected_tensors(idx, "model.layers.1") == ["model.layers.1.attn.q.weight", "model.layers.1.mlp.up.weight"]
+    assert model_source.resolve_selected_tensors(idx, "NORM") == ["model.layers.0.norm.weight"]
+    assert model_source.resolve_selected_tensors(idx, "bias") == ["lm_head.bias"]  # falls back to all names
+    with pytest.raises(RuntimeError):
+        model_source.resolve_selected_tensors(idx, "nothing-matches")
+    assert model_source.resolve_format_list(["BFP8", "all"], ["bf16", "bfp8"]) == ["bfp8", "bf16"]
+    with pytest.raises(ValueError):
+        model_source.resolve_format_list(["mxfp4"], ["bf16", "bfp8"])
+    big = model_source.build_model_index("synthetic:llama3-8b")
+    names = model_source.resolve_selected_tensors(big, "model.layers")
+    assert len(names) == 224
+    shards = model_source.lpt_shards(names, big.numel, 8)
+    loads = [sum(big.numel(names[i]) for i in s) for s in shards]
+    assert sorted(i for s in shards for i in s) == list(range(224)) and max(loads) / min(loads) < 1.01
+
+
+def test_wq_emulation_single_process(tmp_path, monkeypatch):
+    monkeypatch.chdir(tmp_path)
+    rc = cli.run(["synthetic:tiny", "--compression-config", write_cfg(tmp_path), "--backend", "emulation", "--summary",
+                  "--results-dir", str(tmp_path / "results")])
+    assert rc == 0
+    rdir = run_dir(tmp_path / "results")
+    used = json.loads((rdir / "compression_config.used.json").read_text())
+    assert used["seed"] == 123 and used["seed_source"] == "config" and "seed" not in used["params"]
+    idx = model_source.build_model_index("synthetic:tiny")
+    names = model_source.resolve_selected_tensors(idx, None)
+    check_maps_against_oracle(rdir, "mixed_tile_greedy", names, idx, lambda x: orc.greedy(x, ALL, "pcc", 0.999, 123)[0])
+    table = (rdir / "table.txt").read_text()
+    assert "Summary (mean across matched tensors)" in table and table.count("mixed-tile-greedy  MIXED") == len(names)
+    # no match → exit code 1 (wq:599-601); unknown source → error
+    assert cli.run(["synthetic:tiny", "zzz", "--results-dir", str(tmp_path / "r2")]) == 1
+
+
+def test_wq_random_seed_is_recorded(tmp_path, monkeypatch):
+    monkeypatch.chdir(tmp_path)
+    assert cli.run(["synthetic:tiny", "norm", "--compression-config", write_cfg(tmp_path, seed=0), "--results-dir", str(tmp_path / "results")]) == 0
+    used = json.loads((run_dir(tmp_path / "results") / "compression_config.used.json").read_text())
+    assert used["seed_source"] == "random" and 0 < used["seed"] < 2**31
+
+
+def _free_port() -> int:
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_wq_two_ranks_gloo_matches_single_process(tmp_path):
+    cfg = write_cfg(tmp_path, algo="mixed-tile-threshold", seed=None, params={"metric": "pcc", "threshold": 0.99})
+    env = dict(os.environ, PYTHONPATH=str(ROOT), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    one = subprocess.run([sys.executable, str(ROOT / "wq"), "synthetic:tiny", "--compression-config", cfg, "--results-dir", str(tmp_path / "r1")],
+                         cwd=tmp_path, env=env, capture_output=True, text=True, timeout=600)
+    assert one.returncode == 0, one.stderr
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", str(_free_port()), str(ROOT / "wq"), "synthetic:tiny", "--compression-config", cfg,
+                          "--results-dir", str(tmp_path / "r2")], cwd=tmp_path, env=env, capture_output=True, text=True, timeout=600)
+    assert two.returncode == 0, two.stderr[-2000:]
+    d1, d2 = run_dir(tmp_path / "r1"), run_dir(tmp_path / "r2")
+    assert strip_time((d1 / "table.txt").read_text()) == strip_time((d2 / "table.txt").read_text())
+    f1 = sorted(p.relative_to(d1) for p in d1.rglob("assignment.npy"))
+    f2 = sorted(p.relative_to(d2) for p in d2.rglob("assignment.npy"))
+    assert f1 == f2 and len(f1) == 5
+    for rel in f1:
+        assert np.array_equal(np.load(d1 / rel), np.load(d2 / rel)), rel
+
+
+@pytest.mark.gpu
+def test_wq_hip_backend(tmp_path, monkeypatch):
+    monkeypatch.chdir(tmp_path)
+    rc = cli.run(["synthetic:tiny", "--compression-config", write_cfg(tmp_path), "--backend", "hip", "--results-dir", str(tmp_path / "results")])
+    assert rc == 0
+    rdir = run_dir(tmp_path / "results")
+    idx = model_source.build_model_index("synthetic:tiny")
+    names = model_source.resolve_selected_tensors(idx, None)
+    check_maps_against_oracle(rdir, "mixed_tile_greedy", names, idx, lambda x: orc.greedy(x, ALL, "pcc", 0.999, 123)[0])
+    # hip columns agree with the host backend's literal float32 columns to 1e-6 (small tensors)
+    rc = cli.run(["synthetic:tiny", "--compression-config", write_cfg(tmp_path), "--backend", "emulation", "--results-dir", str(tmp_path / "results_emu")])
+    assert rc == 0
+
+    def numbers(text):
+        return [float(v) for line in text.splitlines() if line.startswith("  none") or line.startswith("  mixed") for v in line.split()[2:5]]
+
+    a = numbers((rdir / "table.txt").read_text())
+    b = numbers((run_dir(tmp_path / "results_emu") / "table.txt").read_text())
+    assert len(a) == len(b) > 0 and max(abs(x - y) for x, y in zip(a, b)) <= 2e-5  # table prints 5 decimals / 3 significant digits
