@@ -108,7 +108,7 @@ class ModelIndex:
                 t = t.to(torch.float32)
             return t.to(device) if device is not None else t
         spec = self.specs[name]
-        dev = device if device is not None else "cpu"
+        dev = "cpu"  # always drawn from the CPU generator: the same tensor whatever backend / rank evaluates it
         g = torch.Generator(device=dev)
         g.manual_seed(spec.seed)
         shape = spec.shape if spec.shape else (1,)
@@ -125,7 +125,8 @@ class ModelIndex:
         else:
             t = torch.randn(shape, generator=g, device=dev) * 0.02
         t = t.reshape(spec.shape)
-        return t.to(torch.bfloat16) if spec.dtype == "bf16" else t.to(torch.float32)
+        t = t.to(torch.bfloat16) if spec.dtype == "bf16" else t.to(torch.float32)
+        return t.to(device) if device is not None else t
 
 
 def _preset(name: str, seed0: int) -> dict:
