@@ -137,7 +137,7 @@ def main() -> None:
         tfile = ROOT / "profiles" / "k1_traffic.json"  # HBM bytes per launch from a separate rocprofv3 --pmc pass
         if tfile.exists():
             try:
-                traffic = json.loads(tfile.read_text()).get("hbm_bytes_per_launch")
+                traffic = json.loads(tfile.read_text()).get("hbm_bytes_per_tile") * tiles_per_launch  # measured B/tile x tiles of this run's launches
             except Exception:
                 traffic = None
         out = {
