@@ -2,7 +2,7 @@
 """bench.py — mixed-tile-greedy (bf16 → BFP{8,4,2}) throughput on MI355X.
 
 Step  = one pass of the hot path (K1 tile_stats on the GPU + stats D2H + host greedy scan → per-tile
-        assignment maps + pcc/mae/atol) over a batch of `--tensors` synthetic 4096x4096 bf16 tensors
+        assignment maps + pcc/mae/atol) over a batch of `--tensors` (128) synthetic 4096x4096 bf16 tensors
         (BASELINE.json configs[1], streamed; the batch is > 256 MiB so the Infinity Cache cannot hold it).
 value = tiles/s, whole job, inputs resident in HBM when the timed region starts.
 roofline = the K1 kernel alone: algorithmic 2048 B read per tile / HIP-event launch duration vs 8 TB/s.
@@ -65,7 +65,7 @@ def main() -> None:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--tensors", type=int, default=32, help="4096x4096 bf16 tensors per step per GPU (32 = 1 GiB)")
+    ap.add_argument("--tensors", type=int, default=128, help="4096x4096 bf16 tensors per step per GPU (128 = 4 GiB, SURVEY §8(d) M1 stream)")
     ap.add_argument("--chunk", type=int, default=16, help="tensors per K1 launch")
     ap.add_argument("--workers", type=int, default=int(os.environ.get("MTQ_SCAN_WORKERS", str(max(2, min(32, (os.cpu_count() or 8) - 2))))), help="host scan threads per rank")
     ap.add_argument("--cpu-sample", type=int, default=12, help="tensors timed on the CPU port (0 = skip)")

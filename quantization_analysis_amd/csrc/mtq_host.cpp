@@ -86,6 +86,19 @@ static inline double pcc_from_moments(double n, double sx, double sx2, double sy
     return (sxy - n * mean_x * mean_y) / denom;
 }
 
+// pcc_value (:176-190) with the x-only subexpressions (mean_x, am2) taken from the handle: the same IEEE operations
+// in the same order, evaluated once instead of at every step.
+static inline double pcc_hoisted(double n, double mean_x, double am2, double sy, double sy2, double sxy, double sab)
+{
+    if (n == 0.0) return 1.0;
+    const double mean_y = sy / n;
+    double bm2 = sy2 - n * mean_y * mean_y;
+    if (bm2 < 0.0) bm2 = 0.0;
+    const double denom = std::sqrt(am2 * bm2);
+    if (denom == 0.0) return sab == 0.0 ? 1.0 : 0.0;
+    return (sxy - n * mean_x * mean_y) / denom;
+}
+
 } // namespace mtq
 
 using namespace mtq;
@@ -98,6 +111,7 @@ struct mtq_greedy {
     double thr, n;
     const double *stats; // caller-owned, must outlive the handle
     double sum_x, sum_x2, sum_y, sum_y2, sum_xy, sum_abs;
+    double mean_x, am2; // mean_x = sum_x / n and am2 = max(sum_x2 - n*mean_x*mean_x, 0): constant during the scan (:179,181,183)
     double max_abs;
     int64_t max_count;
     std::vector<double> cur; // per tile: sy, sy2, sxy, sab, max of the CURRENT format
@@ -156,6 +170,9 @@ extern "C" int mtq_greedy_create(mtq_greedy **out, const double *stats, int64_t 
         g->sum_abs += b[3];
         std::memcpy(&g->cur[(size_t)t * 5], b, 5 * sizeof(double));
     }
+    g->mean_x = elem_count != 0.0 ? g->sum_x / elem_count : 0.0;
+    g->am2 = g->sum_x2 - elem_count * g->mean_x * g->mean_x;
+    if (g->am2 < 0.0) g->am2 = 0.0;
     double m = g->cur[4]; // :219-220
     for (int64_t t = 1; t < tiles; ++t) m = nanmax(m, g->cur[(size_t)t * 5 + 4]);
     int64_t c = 0;
@@ -181,7 +198,7 @@ extern "C" int mtq_greedy_pass(mtq_greedy *g, int fmt, const int64_t *order, int
         bool accept;
         if (g->metric == MTQ_METRIC_PCC) {
             if (prev == fmt) { // :238-241
-                if (!is_good(pcc_from_moments(N, g->sum_x, g->sum_x2, g->sum_y, g->sum_y2, g->sum_xy, g->sum_abs), MTQ_METRIC_PCC, thr))
+                if (!is_good(pcc_hoisted(N, g->mean_x, g->am2, g->sum_y, g->sum_y2, g->sum_xy, g->sum_abs), MTQ_METRIC_PCC, thr))
                     g->fixed[(size_t)t] = 1;
                 continue;
             }
@@ -189,7 +206,7 @@ extern "C" int mtq_greedy_pass(mtq_greedy *g, int fmt, const int64_t *order, int
             const double cy2 = g->sum_y2 + (q[1] - cur[1]); // :260
             const double cxy = g->sum_xy + (q[2] - cur[2]); // :261
             const double cab = g->sum_abs + (q[3] - cur[3]); // :262
-            accept = is_good(pcc_from_moments(N, g->sum_x, g->sum_x2, cy, cy2, cxy, cab), MTQ_METRIC_PCC, thr);
+            accept = is_good(pcc_hoisted(N, g->mean_x, g->am2, cy, cy2, cxy, cab), MTQ_METRIC_PCC, thr);
             if (accept) { g->sum_y = cy; g->sum_y2 = cy2; g->sum_xy = cxy; g->sum_abs = cab; }
         } else if (g->metric == MTQ_METRIC_MAE) {
             if (prev == fmt) { // :280-284
