@@ -1,0 +1,112 @@
+#!/usr/bin/env python3
+"""Sweep mixed-tile-threshold over a range of metric thresholds (reference scripts/sweep_mixed_tile_threshold.py).
+Same flags; `--backend hip` added; tensors come from quantization_analysis_amd.model_source (offline).  Under
+torch.distributed.run the matched tensors are sharded over the ranks; every rank writes the CSVs of its tensors."""
+from __future__ import annotations
+
+import argparse
+import fnmatch
+import json
+import os
+import re
+import sys
+import time
+from pathlib import Path
+
+sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+
+from quantization_analysis_amd.compression_algorithms.mixed_tile_greedy import parse_tile_formats
+from quantization_analysis_amd.compression_algorithms.quantizer import BACKENDS, Quantizer
+from quantization_analysis_amd.model_source import build_model_index, filter_tensor_names, lpt_shards
+from quantization_analysis_amd.sweep import pareto_frontier, sweep_tensor, write_csv
+
+
+def parse_args(argv=None):
+    p = argparse.ArgumentParser(description="Sweep mixed-tile-threshold over a range of metric thresholds.")
+    p.add_argument("repo_or_url")
+    p.add_argument("tensor_name", help="Tensor name or filter (regex by default).")
+    p.add_argument("--regex", action="store_true", default=True)
+    p.add_argument("--no-regex", dest="regex", action="store_false")
+    p.add_argument("--list-matches", action="store_true")
+    p.add_argument("--revision", default="main")
+    p.add_argument("--cache-dir", default="data/hf-cache")
+    p.add_argument("--backend", choices=list(BACKENDS), default="emulation")
+    p.add_argument("--formats", default="bf16,bfp8,bfp4,bfp2")
+    p.add_argument("--metric", choices=["pcc", "mae", "atol"], default="pcc")
+    p.add_argument("--lowest-metric-val", type=float, default=0.9)
+    p.add_argument("--steps", type=int, default=50)
+    p.add_argument("--out-dir", default=None)
+    return p.parse_args(argv)
+
+
+def select_tensors(index, query: str, use_regex: bool) -> list[str]:
+    """reference :313-348."""
+    names = index.tensor_names
+    weight_like = [n for n in names if "weight" in n.lower() and not n.lower().endswith("_scale_inv")]
+    cands = weight_like if weight_like else names
+    if use_regex:
+        try:
+            pat = re.compile(query)
+        except re.error as exc:
+            raise RuntimeError(f"Invalid regex '{query}': {exc}") from exc
+        m = [n for n in cands if pat.search(n)]
+        if m:
+            return sorted(m)
+        raise RuntimeError("No tensors matched the regex query.")
+    if query in cands:
+        return [query]
+    if any(ch in query for ch in "*?[]"):
+        m = [n for n in cands if fnmatch.fnmatch(n, query)]
+        if m:
+            return sorted(m)
+    m = [n for n in cands if query.lower() in n.lower()] or filter_tensor_names(cands, query)
+    if m:
+        return sorted(m)
+    raise RuntimeError("No tensors matched the filter query.")
+
+
+def main(argv=None) -> int:
+    args = parse_args(argv)
+    formats = parse_tile_formats(args.formats)
+    world, rank, local_rank = (int(os.environ.get(k, d)) for k, d in (("WORLD_SIZE", "1"), ("RANK", "0"), ("LOCAL_RANK", "0")))
+    index = build_model_index(args.repo_or_url, revision=args.revision)
+    selected = select_tensors(index, args.tensor_name, args.regex)
+    if args.list_matches:
+        print(f"Matched {len(selected)} tensor(s):")
+        for n in selected:
+            print(f"  {n}")
+        return 0
+    device = None
+    if args.backend == "hip":
+        import torch
+
+        torch.cuda.set_device(local_rank)
+        device = torch.device("cuda", local_rank)
+    base_out = Path(args.out_dir) if args.out_dir else Path("results") / index.repo_id.replace("/", "__") / "mixed_tile_threshold_sweep" / time.strftime("%Y%m%d-%H%M%S")
+    detail = base_out / "details"
+    detail.mkdir(parents=True, exist_ok=True)
+    quantizer = Quantizer(args.backend)
+    for i in lpt_shards(selected, index.numel, world)[rank]:
+        name = selected[i]
+        x = index.load(name, device=device)
+        xf = x if device is not None else x.float().numpy()
+        try:
+            rows, baselines, _thr = sweep_tensor(xf, formats, args.metric, args.lowest_metric_val, args.steps, quantizer)
+        except ValueError as exc:
+            print(f"error: {exc}")
+            return 1
+        out = detail / name.replace("/", "_").replace(".", "_")
+        out.mkdir(parents=True, exist_ok=True)
+        (out / "sweep_config.json").write_text(json.dumps({
+            "repo_or_url": args.repo_or_url, "tensor_name": name, "revision": args.revision, "backend": args.backend,
+            "formats": formats, "metric": args.metric, "lowest_metric_val": args.lowest_metric_val, "steps": args.steps}, indent=2))
+        write_csv(out / "sweep_results.csv", rows, formats)
+        mixed = [{"label": f"t{r['step']}", "size": r["size_bytes"], "metric": r[args.metric], "kind": "mixed"} for r in rows]
+        front = pareto_frontier(baselines + mixed, args.metric)
+        (out / "pareto.json").write_text(json.dumps([{k: p[k] for k in ("label", "size", "metric", "kind")} for p in front], indent=1))
+        print(f"[rank {rank}] {name}: {len(rows)} steps, pareto {len(front)} points -> {out}")
+    return 0
+
+
+if __name__ == "__main__":
+    raise SystemExit(main())
