@@ -217,6 +217,53 @@ def main() -> None:
     np.savez_compressed(OUT / "f5_threshold.npz", **f5)
     meta["f5"] = f5_meta
 
+
+    # ---------------------------------------------------------------- F6: threshold sweep rows
+    # the reference's sweep is a script (scripts/sweep_mixed_tile_threshold.py:581-821); its selection and pareto
+    # helpers are loaded from the file and driven with the data flow of its main loop (:626-790)
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("ref_sweep", REF + "/scripts/sweep_mixed_tile_threshold.py")
+    ref_sweep = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ref_sweep)
+    from compression_algorithms.tile_utils import MIXED_TILE_BYTES_PER_ELEM, MIXED_TILE_FORMATS, reconstruct_from_tiles
+
+    f6 = {}
+    for tag, kind, shape, metric, lowest, steps in (("pcc", "normal_bf16", (256, 256), "pcc", 0.9, 10),
+                                                    ("mae", "heavy_f32", (160, 224), "mae", 0.02, 8),
+                                                    ("atol", "heavy_f32", (96, 128), "atol", 0.3, 6)):
+        xf = gen(kind, 61, shape)
+        padded_ref, shape_info, pad_info = reshape_to_2d_with_padding(xf)
+        th_, tw_ = pad_info[2] // 32, pad_info[3] // 32
+        tiles_ref = padded_ref.reshape(th_, 32, tw_, 32).transpose(0, 2, 1, 3).reshape(-1, 32, 32)
+        tiles_by_fmt, scores_by_fmt = {}, {}
+        for fmt in ALL:
+            pq, _, _ = reshape_to_2d_with_padding(q.quantize(xf, fmt))
+            tq = pq.reshape(th_, 32, tw_, 32).transpose(0, 2, 1, 3).reshape(-1, 32, 32)
+            tiles_by_fmt[fmt] = tq
+            scores_by_fmt[fmt] = tile_metrics(tiles_ref, tq, metric)
+        by_prec = sorted(ALL, key=lambda f: MIXED_TILE_BYTES_PER_ELEM.get(f, 0.0))
+        hi = max(by_prec, key=lambda f: MIXED_TILE_BYTES_PER_ELEM.get(f, 0.0))
+        fmt_order = {f: i for i, f in enumerate(by_prec)}
+        ss = np.stack([scores_by_fmt[f] for f in by_prec])
+        tstack = np.stack([tiles_by_fmt[f] for f in by_prec])
+        start = float(np.max(scores_by_fmt[hi])) if metric == "pcc" else float(np.min(scores_by_fmt[hi]))
+        rows = []
+        for k, t in enumerate(np.linspace(start, lowest, max(1, steps))):
+            a = ref_sweep._compute_assignment(ss, metric, float(t))
+            y = reconstruct_from_tiles(tstack[a, np.arange(a.size)], shape_info, pad_info)
+            diff = np.abs(xf - y)
+            raw = np.bincount(a, minlength=4)
+            counts = {f: 0 for f in MIXED_TILE_FORMATS}
+            for f, i in fmt_order.items():
+                counts[f] = int(raw[i])
+            rows.append([k, float(t), mixed_tile_total_bytes(counts), pearson_corr(xf, y), float(np.mean(diff)), float(np.max(diff)),
+                         *[counts[f] for f in ALL]])
+        f6[f"{tag}_rows"] = np.asarray(rows, dtype=np.float64)
+        col = 3 if metric == "pcc" else (4 if metric == "mae" else 5)
+        f6[f"{tag}_pareto"] = np.asarray(ref_sweep._pareto_mask([{"size": r[2], "metric": r[col]} for r in rows], metric))
+    np.savez_compressed(OUT / "f6_sweep.npz", **f6)
+
     # ---------------------------------------------------------------- F8: RNG drift + misc scalars
     f8 = {
         "perm_123_16384_head": np.random.default_rng(123).permutation(16384)[:32].astype(np.int64),
