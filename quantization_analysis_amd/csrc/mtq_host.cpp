@@ -111,6 +111,8 @@ struct mtq_greedy {
     double thr, n;
     const double *stats; // caller-owned, must outlive the handle
     double sum_x, sum_x2, sum_y, sum_y2, sum_xy, sum_abs;
+    bool cur_valid;     // cur_value below is the metric of the current sums (no accepted move since it was computed)
+    double cur_value;
     double mean_x, am2; // mean_x = sum_x / n and am2 = max(sum_x2 - n*mean_x*mean_x, 0): constant during the scan (:179,181,183)
     double max_abs;
     int64_t max_count;
@@ -170,6 +172,8 @@ extern "C" int mtq_greedy_create(mtq_greedy **out, const double *stats, int64_t 
         g->sum_abs += b[3];
         std::memcpy(&g->cur[(size_t)t * 5], b, 5 * sizeof(double));
     }
+    g->cur_valid = false;
+    g->cur_value = 0.0;
     g->mean_x = elem_count != 0.0 ? g->sum_x / elem_count : 0.0;
     g->am2 = g->sum_x2 - elem_count * g->mean_x * g->mean_x;
     if (g->am2 < 0.0) g->am2 = 0.0;
@@ -197,9 +201,12 @@ extern "C" int mtq_greedy_pass(mtq_greedy *g, int fmt, const int64_t *order, int
         const double *q = g->stats + t * g->rec + 2 + 5 * slot;
         bool accept;
         if (g->metric == MTQ_METRIC_PCC) {
-            if (prev == fmt) { // :238-241
-                if (!is_good(pcc_hoisted(N, g->mean_x, g->am2, g->sum_y, g->sum_y2, g->sum_xy, g->sum_abs), MTQ_METRIC_PCC, thr))
-                    g->fixed[(size_t)t] = 1;
+            if (prev == fmt) { // :237-241 — current_value is a pure function of the running sums: reuse it until a move is accepted
+                if (!g->cur_valid) {
+                    g->cur_value = pcc_hoisted(N, g->mean_x, g->am2, g->sum_y, g->sum_y2, g->sum_xy, g->sum_abs);
+                    g->cur_valid = true;
+                }
+                if (!is_good(g->cur_value, MTQ_METRIC_PCC, thr)) g->fixed[(size_t)t] = 1;
                 continue;
             }
             const double cy = g->sum_y + (q[0] - cur[0]);   // :259
@@ -207,7 +214,7 @@ extern "C" int mtq_greedy_pass(mtq_greedy *g, int fmt, const int64_t *order, int
             const double cxy = g->sum_xy + (q[2] - cur[2]); // :261
             const double cab = g->sum_abs + (q[3] - cur[3]); // :262
             accept = is_good(pcc_hoisted(N, g->mean_x, g->am2, cy, cy2, cxy, cab), MTQ_METRIC_PCC, thr);
-            if (accept) { g->sum_y = cy; g->sum_y2 = cy2; g->sum_xy = cxy; g->sum_abs = cab; }
+            if (accept) { g->sum_y = cy; g->sum_y2 = cy2; g->sum_xy = cxy; g->sum_abs = cab; g->cur_valid = false; }
         } else if (g->metric == MTQ_METRIC_MAE) {
             if (prev == fmt) { // :280-284
                 if (!is_good(N != 0.0 ? g->sum_abs / N : 0.0, MTQ_METRIC_MAE, thr)) g->fixed[(size_t)t] = 1;

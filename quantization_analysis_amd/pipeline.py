@@ -69,7 +69,8 @@ class GreedyPipeline:
             raise ValueError("seed 0 means 'draw a random seed' in the reference; pass a non-zero seed")
         self.chunk = int(chunk)
         self.pool = cf.ThreadPoolExecutor(max_workers=int(workers))
-        self.stream = torch.cuda.Stream()
+        self.stream = torch.cuda.Stream()        # K1 launches
+        self.copy_stream = torch.cuda.Stream()   # records D2H, overlapped with the next chunk's K1
         self.timing = KernelTiming()
         self._bufs = {}
 
@@ -101,9 +102,11 @@ class GreedyPipeline:
                 hb.tile_stats_batched(x3d[first:first + n], self.mask, out=dev[first:first + n])
                 e1.record(self.stream)
                 self.timing.events.append((e0, e1, n * tiles))
-                host[first:first + n].copy_(dev[first:first + n], non_blocking=True)
-                done = torch.cuda.Event()
-                done.record(self.stream)
+                self.copy_stream.wait_event(e1)
+                with torch.cuda.stream(self.copy_stream):
+                    host[first:first + n].copy_(dev[first:first + n], non_blocking=True)
+                    done = torch.cuda.Event()
+                    done.record(self.copy_stream)
                 pending.append((done, first, n))
         futures = []
         for evt, first, n in pending:      # scans of chunk k start while chunks k+1.. are still on the GPU
@@ -114,6 +117,7 @@ class GreedyPipeline:
                                                 self.metric, self.threshold, seed))
         results = [f.result() for f in futures]
         torch.cuda.current_stream().wait_stream(self.stream)
+        torch.cuda.current_stream().wait_stream(self.copy_stream)
         return results
 
     def close(self) -> None:
