@@ -67,7 +67,7 @@ def main() -> None:
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--tensors", type=int, default=128, help="4096x4096 bf16 tensors per step per GPU (128 = 4 GiB, SURVEY §8(d) M1 stream)")
     ap.add_argument("--chunk", type=int, default=16, help="tensors per K1 launch")
-    ap.add_argument("--workers", type=int, default=int(os.environ.get("MTQ_SCAN_WORKERS", str(max(2, min(32, (os.cpu_count() or 8) - 2))))), help="host scan threads per rank")
+    ap.add_argument("--workers", type=int, default=int(os.environ.get("MTQ_SCAN_WORKERS", str(max(4, min(32, (os.cpu_count() or 64) // 16))))), help="host scan threads per rank (default: 1/16 of the host's hardware threads, i.e. one physical core each when 8 ranks share a 2-way-SMT node)")
     ap.add_argument("--cpu-sample", type=int, default=12, help="tensors timed on the CPU port (0 = skip)")
     args = ap.parse_args()
 
