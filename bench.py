@@ -81,7 +81,7 @@ def main() -> None:
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    if "RANK" in os.environ:  # launched by torch.distributed.run (any N, also N = 1): one process per GPU over RCCL
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
