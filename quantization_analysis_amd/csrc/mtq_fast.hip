@@ -370,7 +370,7 @@ extern "C" int mtq_launch_tile_stats_bf16_fast(const void *x, int64_t count, int
 {
     const int64_t th = rows / kTile, tw = cols / kTile, tiles = th * tw;
     const int64_t units_w = cols / kUnitCols, upt = th * units_w, total = count * upt;
-    if (total > INT32_MAX / 2 || rows * ld * 2 > (int64_t)UINT32_MAX) return fail(MTQ_ERR_INVALID, "tensor batch too large for one fast launch");
+    if (total > INT32_MAX / 2 || 64 * ld > (int64_t)UINT32_MAX) return fail(MTQ_ERR_INVALID, "tensor batch too large for one fast launch");
     const int rec = 2 + 5 * __builtin_popcount(fmt_mask & MTQ_MASK_ALL);
     static int cus = 0;
     if (cus == 0) {

@@ -179,3 +179,46 @@ def test_fast_and_generic_kernels_agree_batched():
     got = hb.tile_stats_batched(dev(xs, bf16=True), 0xF).cpu().numpy()
     for i in range(6):
         assert np.array_equal(got[i].view(np.uint64), orc.tile_stats(xs[i], ALL).view(np.uint64)), i
+
+
+def test_full_size_parity_and_properties():
+    """BASELINE.json configs[1] size (4096x4096 bf16) and a Llama-3 MLP shape: records bit-identical to the oracle,
+    plus size-independent properties of the exact-integer route (power-of-two homogeneity, tile independence,
+    batched == single, checksum of checksums)."""
+    from quantization_analysis_amd.compression_algorithms import create_algorithm
+    from quantization_analysis_amd.compression_algorithms.quantizer import Quantizer
+
+    g = torch.Generator().manual_seed(0)
+    xb = (torch.randn((4096, 4096), generator=g) * 0.02).to(torch.bfloat16)
+    x = xb.float().numpy()
+    xd = xb.cuda()
+    got = hb.tile_stats(xd, 0xF).cpu().numpy()
+    want = orc.tile_stats(x, ALL)
+    assert np.array_equal(got.view(np.uint64), want.view(np.uint64))
+    # checksum of checksums: Σ over tiles of Σx / Σx² equals the float64 sums of the tensor
+    assert abs(got[:, 0].sum() - x.astype(np.float64).sum()) <= 1e-9 * np.abs(x).astype(np.float64).sum()
+    assert abs(got[:, 1].sum() - (x.astype(np.float64) ** 2).sum()) <= 1e-12 * (x.astype(np.float64) ** 2).sum()
+    # power-of-two homogeneity: x·2^k is exact in bf16; first moments scale by 2^k, second moments by 4^k, bit for bit
+    got8 = hb.tile_stats((xd.float() * 8.0).to(torch.bfloat16), 0xF).cpu().numpy()
+    scale = np.ones(22)
+    scale[[0, 2, 5, 6, 7, 10, 11, 12, 15, 16, 17, 20, 21]] = 8.0
+    scale[[1, 3, 4, 8, 9, 13, 14, 18, 19]] = 64.0
+    assert np.array_equal(got8, got * scale)
+    # tile independence: swapping two tile rows swaps their records
+    xs = xd.clone()
+    xs[0:32], xs[64:96] = xd[64:96], xd[0:32]
+    gs = hb.tile_stats(xs, 0xF).cpu().numpy().reshape(128, 128, 22)
+    g0 = got.reshape(128, 128, 22)
+    assert np.array_equal(gs[0], g0[2]) and np.array_equal(gs[2], g0[0]) and np.array_equal(gs[3:], g0[3:])
+    # batched launch == single launches
+    gb = hb.tile_stats_batched(torch.stack([xd, xs]), 0xF).cpu().numpy()
+    assert np.array_equal(gb[0], got) and np.array_equal(gb[1].reshape(128, 128, 22), gs)
+    # full greedy search: map identical to the oracle's at full size
+    res = create_algorithm("mixed-tile-greedy", {"metric": "pcc", "threshold": 0.999, "seed": 123, "materialize_y": False}).run(
+        xd, ALL, Quantizer("hip"), None)[0]
+    want_a, want_counts, _st = orc.greedy(x, ALL, "pcc", 0.999, 123)
+    assert np.array_equal(res.meta["assignment"], want_a) and res.tile_counts == want_counts
+    # a Llama-3-8B MLP shape (14336 x 4096), heavier tails
+    xl = (torch.randn((14336, 4096), generator=g) * 0.02 * torch.exp(0.5 * torch.randn((14336, 4096), generator=g))).to(torch.bfloat16)
+    gl = hb.tile_stats(xl.cuda(), 0xE).cpu().numpy()
+    assert np.array_equal(gl.view(np.uint64), orc.tile_stats(xl.float().numpy(), ["bfp8", "bfp4", "bfp2"]).view(np.uint64))
