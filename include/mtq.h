@@ -151,6 +151,14 @@ int mtq_greedy_run(const double *stats, int64_t tiles, uint32_t fmt_mask, const 
                    int64_t counts[4], double out[9]);
 
 /*
+ * mtq_greedy_run over `count` equally sized tensors (records contiguous: count × tiles × record doubles) on up to
+ * n_threads host threads.  seeds[count]; maps int8[count][tiles]; counts int64[count][4]; outs double[count][9].
+ */
+int mtq_greedy_run_batch(const double *stats, int64_t count, int64_t tiles, uint32_t fmt_mask, const int *formats,
+                         int n_formats, int metric, double threshold, double elem_count, const uint64_t *seeds,
+                         int8_t *maps, int64_t *counts, double *outs, int n_threads);
+
+/*
  * Per-tile scores from the raw sums, n = 1024 (tile_utils.py:46-57 semantics on float64 moments):
  * pcc via the moment formula, mae = Σ|d|/1024, atol = max|d|.  scores is [popcount(mask)][tiles],
  * formats in ascending mask-bit order.

@@ -11,7 +11,11 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <algorithm>
+#include <atomic>
 #include <new>
+#include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/mtq.h"
@@ -516,4 +520,39 @@ extern "C" int mtq_greedy_run(const double *stats, int64_t tiles, uint32_t fmt_m
     }
     mtq_greedy_destroy(g);
     return rc;
+}
+
+// mtq_greedy_run over `count` equally sized tensors on `n_threads` host threads (tensors are independent).
+extern "C" int mtq_greedy_run_batch(const double *stats, int64_t count, int64_t tiles, uint32_t fmt_mask, const int *formats,
+                                    int n_formats, int metric, double threshold, double elem_count, const uint64_t *seeds,
+                                    int8_t *maps, int64_t *counts, double *outs, int n_threads)
+{
+    if (!stats || !formats || !seeds || !maps) return fail(MTQ_ERR_INVALID, "null argument");
+    if (count <= 0 || tiles <= 0) return fail(MTQ_ERR_INVALID, "count and tiles must be positive");
+    const int rec = 2 + 5 * popcount4(fmt_mask);
+    const int nt = (int)std::max<int64_t>(1, std::min<int64_t>(n_threads, count));
+    std::atomic<int64_t> next(0);
+    std::atomic<int> first_error(MTQ_OK);
+    std::vector<std::string> msgs((size_t)nt);
+    auto work = [&](int tid) {
+        for (;;) {
+            const int64_t i = next.fetch_add(1);
+            if (i >= count) break;
+            const int rc = mtq_greedy_run(stats + i * tiles * rec, tiles, fmt_mask, formats, n_formats, metric, threshold, elem_count,
+                                          seeds[i], maps + i * tiles, counts ? counts + 4 * i : nullptr, outs ? outs + 9 * i : nullptr);
+            if (rc != MTQ_OK) {
+                int expected = MTQ_OK;
+                if (first_error.compare_exchange_strong(expected, rc)) msgs[(size_t)tid] = mtq_last_error();
+            }
+        }
+    };
+    std::vector<std::thread> pool;
+    for (int t = 1; t < nt; ++t) pool.emplace_back(work, t);
+    work(0);
+    for (auto &th : pool) th.join();
+    if (first_error.load() != MTQ_OK) {
+        for (auto &m : msgs) if (!m.empty()) return fail(first_error.load(), m.c_str());
+        return fail(first_error.load(), "mtq_greedy_run_batch failed");
+    }
+    return MTQ_OK;
 }

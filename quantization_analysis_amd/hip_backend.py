@@ -29,7 +29,7 @@ EXPORTS = [
     "mtq_greedy_create", "mtq_greedy_pass", "mtq_greedy_assignment", "mtq_greedy_fixed",
     "mtq_greedy_counts", "mtq_greedy_value", "mtq_greedy_destroy",
     "mtq_tile_scores", "mtq_threshold_assign", "mtq_columns_from_stats",
-    "mtq_rng_create", "mtq_rng_permutation", "mtq_rng_destroy", "mtq_greedy_run",
+    "mtq_rng_create", "mtq_rng_permutation", "mtq_rng_destroy", "mtq_greedy_run", "mtq_greedy_run_batch",
 ]
 
 
@@ -91,6 +91,7 @@ def lib() -> ctypes.CDLL:
     L.mtq_rng_destroy.argtypes = [vp]
     L.mtq_rng_destroy.restype = None
     L.mtq_greedy_run.argtypes = [vp, i64, u32, vp, ci, ci, dbl, dbl, ctypes.c_uint64, vp, vp, vp]
+    L.mtq_greedy_run_batch.argtypes = [vp, i64, i64, u32, vp, ci, ci, dbl, dbl, vp, vp, vp, vp, ci]
     if L.mtq_version() < 100:
         raise MtqError("libmtq_hip.so is older than this package")
     _lib = L
@@ -333,6 +334,21 @@ def greedy_run(stats: np.ndarray, mask: int, formats, metric: str, threshold: fl
     check(lib().mtq_greedy_run(stats.ctypes.data, T, mask, fm, len(formats), METRIC_CODE[metric], float(threshold),
                                float(elem_count), int(seed), amap.ctypes.data, counts, out))
     return amap, {f: int(counts[i]) for i, f in enumerate(MIXED_TILE_FORMATS)}, {"pcc": out[0], "mae": out[1], "atol": out[2], "sums": tuple(out[3:9])}
+
+
+def greedy_run_batch(stats: np.ndarray, mask: int, formats, metric: str, threshold: float, elem_count: float, seeds, n_threads: int):
+    """mtq_greedy_run over a [count, tiles, rec] record array on n_threads host threads (one GIL-free call)
+    → (int8 [count, tiles] maps, int64 [count, 4] counts, float64 [count, 9] columns+sums)."""
+    stats = np.ascontiguousarray(stats, dtype=np.float64)
+    count, T = stats.shape[0], stats.shape[1]
+    fm = (ctypes.c_int * len(formats))(*[MIXED_TILE_FORMATS.index(f) for f in formats])
+    sd = np.ascontiguousarray(seeds, dtype=np.uint64)
+    maps = np.empty((count, T), dtype=np.int8)
+    counts = np.empty((count, 4), dtype=np.int64)
+    outs = np.empty((count, 9), dtype=np.float64)
+    check(lib().mtq_greedy_run_batch(stats.ctypes.data, count, T, mask, fm, len(formats), METRIC_CODE[metric], float(threshold),
+                                     float(elem_count), sd.ctypes.data, maps.ctypes.data, counts.ctypes.data, outs.ctypes.data, int(n_threads)))
+    return maps, counts, outs
 
 
 def tile_scores(stats: np.ndarray, mask: int, metric: str) -> np.ndarray:

@@ -46,11 +46,16 @@ class KernelTiming:
         self.events.clear()
 
 
-def _scan_one(index, stats, mask, tiles_hw, numel, tile_formats, metric, threshold, seed) -> TensorResult:
-    """One tensor's whole search in a single GIL-free C call (mtq_greedy_run)."""
-    a, counts, cols = hb.greedy_run(stats, mask, tile_formats, metric, threshold, float(numel), seed)
-    return TensorResult(index, a.reshape(tiles_hw), counts, mixed_tile_total_bytes(counts), cols["pcc"], cols["mae"],
-                        cols["atol"], cols["pcc"] if metric == "pcc" else (cols["mae"] if metric == "mae" else cols["atol"]))
+def _scan_chunk(first, stats, mask, tiles_hw, numel, tile_formats, metric, threshold, seeds, n_threads) -> list[TensorResult]:
+    """The searches of one chunk of tensors: a single GIL-free C call fanning out over n_threads host threads."""
+    maps, counts, outs = hb.greedy_run_batch(stats, mask, tile_formats, metric, threshold, float(numel), seeds, n_threads)
+    k = {"pcc": 0, "mae": 1, "atol": 2}[metric]
+    res = []
+    for j in range(maps.shape[0]):
+        c = {f: int(counts[j, i]) for i, f in enumerate(MIXED_TILE_FORMATS)}
+        res.append(TensorResult(first + j, maps[j].reshape(tiles_hw), c, mixed_tile_total_bytes(c), float(outs[j, 0]), float(outs[j, 1]),
+                                float(outs[j, 2]), float(outs[j, k])))
+    return res
 
 
 class GreedyPipeline:
@@ -68,7 +73,8 @@ class GreedyPipeline:
         if self.seed == 0:
             raise ValueError("seed 0 means 'draw a random seed' in the reference; pass a non-zero seed")
         self.chunk = int(chunk)
-        self.pool = cf.ThreadPoolExecutor(max_workers=int(workers))
+        self.workers = int(workers)
+        self.pool = cf.ThreadPoolExecutor(max_workers=2)  # chunk-level tasks; the fan-out over tensors happens inside the C call
         self.stream = torch.cuda.Stream()        # K1 launches
         self.copy_stream = torch.cuda.Stream()   # records D2H, overlapped with the next chunk's K1
         self.timing = KernelTiming()
@@ -109,13 +115,12 @@ class GreedyPipeline:
                     done.record(self.copy_stream)
                 pending.append((done, first, n))
         futures = []
-        for evt, first, n in pending:      # scans of chunk k start while chunks k+1.. are still on the GPU
+        for evt, first, n in pending:      # scans of chunk k run while chunks k+1.. are still on the GPU / the PCIe link
             evt.synchronize()
-            for j in range(first, first + n):
-                seed = self.seed if seeds is None else int(seeds[j])
-                futures.append(self.pool.submit(_scan_one, j, host_np[j], self.mask, (th, tw), numel, self.tile_formats,
-                                                self.metric, self.threshold, seed))
-        results = [f.result() for f in futures]
+            sd = [self.seed] * n if seeds is None else [int(v) for v in seeds[first:first + n]]
+            futures.append(self.pool.submit(_scan_chunk, first, host_np[first:first + n], self.mask, (th, tw), numel, self.tile_formats,
+                                            self.metric, self.threshold, sd, self.workers))
+        results = [r for f in futures for r in f.result()]
         torch.cuda.current_stream().wait_stream(self.stream)
         torch.cuda.current_stream().wait_stream(self.copy_stream)
         return results

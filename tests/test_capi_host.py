@@ -141,3 +141,17 @@ def test_greedy_run_equals_numpy_driven_scan(golden_dir):
         assert np.array_equal(a_c.reshape(d[f"{name}_assign"].shape), d[f"{name}_assign"]), name
     with pytest.raises(hb.MtqError):
         hb.greedy_run(stats, mask, ["bf16"], "pcc", 0.9, 1.0, 0)  # seed 0 must be resolved by the caller
+
+
+def test_greedy_run_batch_equals_single_runs():
+    xs = [gen("normal_bf16", s, (256, 256)) for s in range(5)]
+    st = np.stack([orc.tile_stats(x, ALL) for x in xs])
+    seeds = [11, 12, 13, 14, 15]
+    maps, counts, outs = hb.greedy_run_batch(st, 0xF, ALL, "pcc", 0.999, 256 * 256.0, seeds, n_threads=3)
+    for i, x in enumerate(xs):
+        a, c, cols = hb.greedy_run(st[i], 0xF, ALL, "pcc", 0.999, 256 * 256.0, seeds[i])
+        assert np.array_equal(maps[i], a) and [c[f] for f in ALL] == list(counts[i])
+        assert (outs[i, 0], outs[i, 1], outs[i, 2]) == (cols["pcc"], cols["mae"], cols["atol"])
+        assert np.array_equal(maps[i].reshape(8, 8), orc.greedy(x, ALL, "pcc", 0.999, seeds[i])[0])
+    with pytest.raises(hb.MtqError):
+        hb.greedy_run_batch(st, 0xF, ALL, "pcc", 0.999, 1.0, [1, 2, 0, 4, 5], n_threads=2)  # a zero seed is reported, not ignored

@@ -1,0 +1,11 @@
+import torch, time
+for mb in (46, 369):
+    n = mb * 1024 * 1024 // 8
+    d = torch.empty(n, dtype=torch.float64, device='cuda'); h = torch.empty(n, dtype=torch.float64, pin_memory=True)
+    h.copy_(d, non_blocking=True); torch.cuda.synchronize()
+    t = time.perf_counter()
+    for _ in range(5): h.copy_(d, non_blocking=True)
+    torch.cuda.synchronize(); dt = (time.perf_counter() - t) / 5
+    print(f"D2H {mb} MB pinned: {mb/1024/dt:.1f} GiB/s")
+    hp = torch.empty(n, dtype=torch.float64)
+    t = time.perf_counter(); hp.copy_(d); torch.cuda.synchronize(); print(f"D2H {mb} MB pageable: {mb/1024/(time.perf_counter()-t):.1f} GiB/s")
