@@ -108,6 +108,15 @@ int mtq_quantize(const void *x, int in_dtype, int64_t rows, int64_t cols, int64_
 int mtq_apply_assignment(const void *x, int in_dtype, int64_t rows, int64_t cols, int64_t ld,
                          const int8_t *map, float *y, int64_t ldy, void *stream);
 
+/*
+ * K5 dequant_fp8_block (loader) — float8-e4m3fn weights × float32 inverse block scales → float32: the on-load
+ * dequantisation of DeepSeek-style checkpoints, `w.float() * scale_inv.repeat_interleave(block)` with
+ * block = ceil(dim / scale_dim) (hf_model_utils.py:199-215, used at :273-281).  w: rows × cols bytes (ldw),
+ * scale_inv: scale_rows × scale_cols float32 (contiguous), out: rows × cols float32 (ldo).  Bit-exact.
+ */
+int mtq_dequant_fp8_block(const void *w, const float *scale_inv, int64_t rows, int64_t cols, int64_t ldw,
+                          int64_t scale_rows, int64_t scale_cols, float *out, int64_t ldo, void *stream);
+
 /* ------------------------------------------------------------------ HOST: decisions on stats records */
 
 /*

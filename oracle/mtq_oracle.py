@@ -409,3 +409,32 @@ def columns_from_stats(stats: np.ndarray, slots: dict, assignment: np.ndarray, n
     denom = float(np.sqrt(am2 * bm2))
     pcc = (1.0 if sab == 0.0 else 0.0) if denom == 0.0 else (sxy - nn * mean_x * mean_y) / denom
     return pcc, sab / nn, mx
+
+
+# ----------------------------------------------------------------------------- loader (K5)
+
+def e4m3fn_table() -> np.ndarray:
+    """float32 value of every float8-e4m3fn code (OCP: bias 7, subnormals m*2^-9, S.1111.111 = NaN, no infinities)."""
+    t = np.empty(256, dtype=np.float32)
+    for b in range(256):
+        s, e, m = b >> 7, (b >> 3) & 0xF, b & 7
+        if e == 0:
+            v = m * 2.0 ** -9
+        elif e == 15 and m == 7:
+            v = float("nan")
+        else:
+            v = (1 + m / 8.0) * 2.0 ** (e - 7)
+        t[b] = -v if s else v
+    return t
+
+
+def dequant_fp8_block(w_bytes: np.ndarray, scale_inv: np.ndarray) -> np.ndarray:
+    """hf_model_utils.py:199-215: w.float() * scale_inv.repeat_interleave(ceil(dim/scale_dim)) in float32."""
+    w = e4m3fn_table()[np.asarray(w_bytes, dtype=np.uint8)]
+    sc = np.asarray(scale_inv, dtype=np.float32)
+    for ax in range(w.ndim):
+        block = max(1, -(-w.shape[ax] // sc.shape[ax]))
+        sc = np.repeat(sc, block, axis=ax)
+    sc = sc[tuple(slice(0, n) for n in w.shape)]
+    with np.errstate(invalid="ignore"):
+        return (w * sc).astype(np.float32)

@@ -133,6 +133,49 @@ __global__ __launch_bounds__(256) void quantize_groups(const T *__restrict__ x, 
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// K5 (loader): float8-e4m3fn weights × float32 inverse block scales → float32, the dequantisation the
+// reference's loader does on the host for DeepSeek-style checkpoints (hf_model_utils.py:199-215,273-281):
+// out = w.float() * scale_inv.repeat_interleave(block)[..].  Block shape = ceil(dim / scale_dim) (:199-206).
+// 16 bytes of fp8 per thread (one 16-B load, four 16-B stores); HBM bound (1 B read + 4 B written per element).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float e4m3fn_to_f32(uint32_t b)
+{
+    const uint32_t s = (b & 0x80u) << 24, e = (b >> 3) & 0xFu, m = b & 7u;
+    if (e == 0u) return __uint_as_float(s | __float_as_uint((float)m * 0.001953125f)); // subnormal: m * 2^-9 (exact)
+    if (e == 15u && m == 7u) return __uint_as_float(s | 0x7FC00000u);                  // the single NaN encoding
+    return __uint_as_float(s | ((e + 120u) << 23) | (m << 20));
+}
+
+__global__ __launch_bounds__(256) void dequant_fp8_block(const uint8_t *__restrict__ w, const float *__restrict__ scale, int64_t rows,
+                                                         int64_t cols, int64_t ldw, int64_t scale_cols, int bh, int bw,
+                                                         float *__restrict__ out, int64_t ldo, int chunks_w, int vec_ok)
+{
+    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t row = g / chunks_w;
+    if (row >= rows) return;
+    const int64_t c0 = (g - row * chunks_w) * 16;
+    const uint8_t *src = w + row * ldw + c0;
+    float *dst = out + row * ldo + c0;
+    const float *srow = scale + (row / bh) * scale_cols;
+    if (vec_ok && c0 + 16 <= cols) {
+        const uint4 v = *reinterpret_cast<const uint4 *>(src);
+        const uint32_t q[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float4 o;
+            o.x = e4m3fn_to_f32(q[k] & 0xFFu) * srow[(c0 + 4 * k + 0) / bw];
+            o.y = e4m3fn_to_f32((q[k] >> 8) & 0xFFu) * srow[(c0 + 4 * k + 1) / bw];
+            o.z = e4m3fn_to_f32((q[k] >> 16) & 0xFFu) * srow[(c0 + 4 * k + 2) / bw];
+            o.w = e4m3fn_to_f32(q[k] >> 24) * srow[(c0 + 4 * k + 3) / bw];
+            reinterpret_cast<float4 *>(dst)[k] = o;
+        }
+    } else {
+        for (int i = 0; i < 16 && c0 + i < cols; ++i) dst[i] = e4m3fn_to_f32(src[i]) * srow[(c0 + i) / bw];
+    }
+}
+
 static bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 static int check_matrix(const void *x, int in_dtype, int64_t rows, int64_t cols, int64_t ld)
@@ -236,4 +279,21 @@ extern "C" int mtq_apply_assignment(const void *x, int in_dtype, int64_t rows, i
 {
     if (!map) return fail(MTQ_ERR_INVALID, "map is null");
     return launch_quantize(x, in_dtype, rows, cols, ld, -1, map, y, ldy, stream, "mtq_apply_assignment");
+}
+
+extern "C" int mtq_dequant_fp8_block(const void *w, const float *scale_inv, int64_t rows, int64_t cols, int64_t ldw,
+                                     int64_t scale_rows, int64_t scale_cols, float *out, int64_t ldo, void *stream)
+{
+    if (!w || !scale_inv || !out) return fail(MTQ_ERR_INVALID, "null argument");
+    if (rows <= 0 || cols <= 0 || scale_rows <= 0 || scale_cols <= 0) return fail(MTQ_ERR_INVALID, "shapes must be positive");
+    if (ldw < cols || ldo < cols) return fail(MTQ_ERR_INVALID, "leading dimension < cols");
+    if (int rc = require_device()) return rc;
+    const int64_t bh = (rows + scale_rows - 1) / scale_rows, bw = (cols + scale_cols - 1) / scale_cols; // hf_model_utils.py:199-206
+    if ((rows + bh - 1) / bh > scale_rows || (cols + bw - 1) / bw > scale_cols) return fail(MTQ_ERR_INVALID, "scale grid does not cover the tensor");
+    const int64_t chunks_w = (cols + 15) / 16, total = rows * chunks_w;
+    if (chunks_w > INT32_MAX || total > ((int64_t)1 << 38) || bh > INT32_MAX || bw > INT32_MAX) return fail(MTQ_ERR_INVALID, "tensor too large");
+    const int vec_ok = aligned16(w) && ldw % 16 == 0 && aligned16(out) && (ldo * 4) % 16 == 0;
+    hipLaunchKernelGGL(dequant_fp8_block, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       static_cast<const uint8_t *>(w), scale_inv, rows, cols, ldw, scale_cols, (int)bh, (int)bw, out, ldo, (int)chunks_w, vec_ok);
+    return check_launch("mtq_dequant_fp8_block");
 }

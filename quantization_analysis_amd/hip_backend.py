@@ -25,7 +25,7 @@ TILE = 32
 # every symbol include/mtq.h declares (tests check the library exports exactly these)
 EXPORTS = [
     "mtq_version", "mtq_last_error", "mtq_device_count", "mtq_stats_record_doubles",
-    "mtq_tile_stats", "mtq_tile_stats_batched", "mtq_quantize", "mtq_apply_assignment",
+    "mtq_tile_stats", "mtq_tile_stats_batched", "mtq_quantize", "mtq_apply_assignment", "mtq_dequant_fp8_block",
     "mtq_greedy_create", "mtq_greedy_pass", "mtq_greedy_assignment", "mtq_greedy_fixed",
     "mtq_greedy_counts", "mtq_greedy_value", "mtq_greedy_destroy",
     "mtq_tile_scores", "mtq_threshold_assign", "mtq_columns_from_stats",
@@ -75,6 +75,7 @@ def lib() -> ctypes.CDLL:
     L.mtq_tile_stats_batched.argtypes = [vp, ci, i64, i64, i64, i64, i64, u32, vp, vp]
     L.mtq_quantize.argtypes = [vp, ci, i64, i64, i64, ci, vp, i64, vp]
     L.mtq_apply_assignment.argtypes = [vp, ci, i64, i64, i64, vp, vp, i64, vp]
+    L.mtq_dequant_fp8_block.argtypes = [vp, vp, i64, i64, i64, i64, i64, vp, i64, vp]
     L.mtq_greedy_create.argtypes = [ctypes.POINTER(vp), vp, i64, u32, ci, dbl, dbl, ci]
     L.mtq_greedy_pass.argtypes = [vp, ci, vp, i64]
     L.mtq_greedy_assignment.argtypes = [vp, vp]
@@ -252,6 +253,21 @@ def apply_assignment(x2d, assignment, out=None):
     if out is None:
         out = torch.empty((rows, cols), dtype=torch.float32, device=x2d.device)
     check(lib().mtq_apply_assignment(x2d.data_ptr(), _dtype_code(x2d), rows, cols, ld, a.data_ptr(), out.data_ptr(), out.stride(0), _stream_ptr()))
+    return out
+
+
+def dequant_fp8_block(w, scale_inv):
+    """K5: w — 2-D device tensor of float8_e4m3fn (or its uint8 bytes); scale_inv — 2-D float32 block scales →
+    float32 device tensor w.float() * scale_inv.repeat_interleave(block) (hf_model_utils.py:209-215)."""
+    torch = _torch()
+    require_gpu()
+    if w.dim() != 2 or scale_inv.dim() != 2 or not w.is_cuda:
+        raise MtqError("expected 2-D device tensors")
+    wb = w.view(torch.uint8).contiguous()
+    sc = scale_inv.to(device=w.device, dtype=torch.float32).contiguous()
+    out = torch.empty(wb.shape, dtype=torch.float32, device=w.device)
+    check(lib().mtq_dequant_fp8_block(wb.data_ptr(), sc.data_ptr(), wb.shape[0], wb.shape[1], wb.stride(0), sc.shape[0], sc.shape[1],
+                                      out.data_ptr(), out.stride(0), _stream_ptr()))
     return out
 
 

@@ -68,6 +68,15 @@ def safe_repo_revision_key(repo_id: str, revision: str) -> str:
     return f"{safe_repo}--{safe_rev}--{digest}"
 
 
+def dequantize_with_scale_inv(tensor, inv_scale):
+    """Host form of the reference's block dequantisation (hf_model_utils.py:199-215)."""
+    assert tensor.ndim == inv_scale.ndim
+    for i, (ts, ss) in enumerate(zip(tensor.shape, inv_scale.shape)):
+        inv_scale = inv_scale.repeat_interleave(max(1, -(-int(ts) // int(ss))) if ss > 0 else 1, dim=i)
+    slices = tuple(slice(0, int(s)) for s in tensor.shape)
+    return tensor.float() * inv_scale[slices].float()
+
+
 @dataclass
 class TensorSpec:
     shape: tuple
@@ -104,6 +113,16 @@ class ModelIndex:
 
             with safe_open(self.files[name], framework="pt") as f:
                 t = f.get_tensor(name)
+            scale_name = f"{name}_scale_inv"
+            if scale_name in self.files and not name.endswith("_scale_inv"):  # hf_model_utils.py:273-281
+                with safe_open(self.files[scale_name], framework="pt") as f:
+                    sc = f.get_tensor(scale_name)
+                if device is not None and t.dtype == torch.float8_e4m3fn and t.dim() == 2 and sc.dim() == 2:
+                    from . import hip_backend as hb
+
+                    return hb.dequant_fp8_block(t.to(device), sc.to(device))  # K5 on the GPU
+                t = dequantize_with_scale_inv(t, sc)
+                return t.to(device) if device is not None else t
             if t.dtype != torch.bfloat16:
                 t = t.to(torch.float32)
             return t.to(device) if device is not None else t

@@ -264,6 +264,26 @@ def main() -> None:
         f6[f"{tag}_pareto"] = np.asarray(ref_sweep._pareto_mask([{"size": r[2], "metric": r[col]} for r in rows], metric))
     np.savez_compressed(OUT / "f6_sweep.npz", **f6)
 
+
+    # ---------------------------------------------------------------- F9: fp8 x scale_inv block dequantisation (loader)
+    import torch
+    from hf_model_utils import _dequantize_tensor_with_scale_inv
+
+    f9 = {}
+    rng9 = np.random.default_rng(99)
+    for tag, shape, sshape in (("all_codes", (16, 256), (1, 2)), ("blocks128", (300, 260), (3, 3)), ("ragged", (130, 47), (2, 1)), ("rowscale", (8, 64), (8, 1))):
+        if tag == "all_codes":
+            wb = np.tile(np.arange(256, dtype=np.uint8), (16, 1))
+        else:
+            wb = rng9.integers(0, 256, size=shape, dtype=np.uint8)
+        sc = np.exp(rng9.standard_normal(sshape)).astype(np.float32) * np.float32(0.01)
+        w = torch.from_numpy(wb).view(torch.float8_e4m3fn)
+        out = _dequantize_tensor_with_scale_inv(w, torch.from_numpy(sc)).to(dtype=torch.float32).numpy()
+        f9[f"{tag}_w"] = wb
+        f9[f"{tag}_scale"] = sc
+        f9[f"{tag}_out_bits"] = out.view(np.uint32)
+    np.savez_compressed(OUT / "f9_fp8_dequant.npz", **f9)
+
     # ---------------------------------------------------------------- F8: RNG drift + misc scalars
     f8 = {
         "perm_123_16384_head": np.random.default_rng(123).permutation(16384)[:32].astype(np.int64),
