@@ -46,6 +46,37 @@ __device__ __forceinline__ uint32_t bfp_elem_bits(uint32_t u, uint32_t shared)
     return (u & 0x80000000u) | (exp_out << 23) | (ms << (23u - M)); // :158
 }
 
+// Same arithmetic with the mantissa width as a run-time value (1..7): lets lanes holding different BFP formats
+// share one instruction stream (K3, where neighbouring tiles of a wave use different formats).
+__device__ __forceinline__ uint32_t bfp_elem_bits_rt(uint32_t u, uint32_t shared, uint32_t M)
+{
+    const uint32_t shift = 24u - M, round_mask = (1u << shift) - 1u, tie = 1u << (shift - 1u), qmax = (1u << M) - 1u;
+    const uint32_t e = (u >> 23) & 0xFFu;
+    const uint32_t d = shared - e;
+    uint32_t man = (1u << 23) | (u & 0x007FFFFFu);
+    man = d > 31u ? 0u : (man >> d);
+    const uint32_t rv = man & round_mask;
+    man >>= shift;
+    const uint32_t up = (rv > tie) | ((rv == tie) & (man & 1u));
+    man = min(man + up, qmax);
+    man = e == 0u ? 0u : man;
+    if (man == 0u) return 0u;
+    const uint32_t msb = 31u - (uint32_t)__clz((int)man);
+    const uint32_t sc = (M - 1u) - msb;
+    const uint32_t ms = (man << (sc + 1u)) & qmax;
+    const uint32_t exp_out = shared - sc;
+    return (u & 0x80000000u) | (exp_out << 23) | (ms << (23u - M));
+}
+
+// format code → y bits with NO divergence between the mixed-tile formats: one BFP evaluation with a per-lane
+// mantissa width, bf16 / fp0 by select.
+__device__ __forceinline__ uint32_t quant_elem_bits_mixed(int fmt, uint32_t u, uint32_t shared)
+{
+    const uint32_t M = fmt == 1 ? 7u : (fmt == 2 ? 3u : 1u);
+    const uint32_t b = bfp_elem_bits_rt(u, shared, M);
+    return fmt == 0 ? bf16_round_bits(u) : ((fmt >= 1 && fmt <= 3) ? b : 0u);
+}
+
 __device__ __forceinline__ uint32_t quant_elem_bits(int fmt, uint32_t u, uint32_t shared)
 {
     switch (fmt) {

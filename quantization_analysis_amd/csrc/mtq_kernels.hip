@@ -176,6 +176,49 @@ __global__ __launch_bounds__(256) void dequant_fp8_block(const uint8_t *__restri
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// K2 / K3, coalesced form: one lane per 4 elements — 8-byte (bf16) or 16-byte (fp32) loads and 16-byte
+// stores, every wave instruction touching one contiguous 512 B / 1 KiB span; the 4 lanes of a
+// shared-exponent group agree on the exponent with two DPP-class lane exchanges.  Needs cols % 16 == 0
+// and 16-byte aligned rows; anything else takes quantize_groups.
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void quantize_quads(const T *__restrict__ x, int64_t rows, int64_t cols, int64_t ld, int quads_w,
+                                                      int tiles_w, int fmt, const int8_t *__restrict__ map,
+                                                      float *__restrict__ y, int64_t ldy)
+{
+    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t row = q / quads_w;
+    const bool live = row < rows;                                        // the whole group is live or not (cols % 16 == 0)
+    const int64_t col0 = live ? (q - row * quads_w) * 4 : 0;
+    uint32_t u[4] = {0u, 0u, 0u, 0u};
+    if (live) {
+        if constexpr (sizeof(T) == 2) {
+            const uint2 v = *reinterpret_cast<const uint2 *>(x + row * ld + col0);
+            u[0] = v.x << 16; u[1] = v.x & 0xFFFF0000u; u[2] = v.y << 16; u[3] = v.y & 0xFFFF0000u;
+        } else {
+            const uint4 v = *reinterpret_cast<const uint4 *>(x + row * ld + col0);
+            u[0] = v.x; u[1] = v.y; u[2] = v.z; u[3] = v.w;
+        }
+    }
+    uint32_t m = max(max(u[0] & 0x7F800000u, u[1] & 0x7F800000u), max(u[2] & 0x7F800000u, u[3] & 0x7F800000u));
+    m = max(m, (uint32_t)__shfl_xor((int)m, 1, 64));                     // lanes 4k..4k+3 hold one group
+    m = max(m, (uint32_t)__shfl_xor((int)m, 2, 64));
+    if (!live) return;
+    const uint32_t shared = m >> 23;
+    uint4 o;
+    if (fmt >= 0) { // K2: one format for the whole launch (uniform branch)
+        o.x = quant_elem_bits(fmt, u[0], shared); o.y = quant_elem_bits(fmt, u[1], shared);
+        o.z = quant_elem_bits(fmt, u[2], shared); o.w = quant_elem_bits(fmt, u[3], shared);
+    } else {        // K3: the tile's own format, evaluated without divergence
+        const int f = map[(row / kTile) * tiles_w + col0 / kTile];
+        o.x = quant_elem_bits_mixed(f, u[0], shared); o.y = quant_elem_bits_mixed(f, u[1], shared);
+        o.z = quant_elem_bits_mixed(f, u[2], shared); o.w = quant_elem_bits_mixed(f, u[3], shared);
+    }
+    *reinterpret_cast<uint4 *>(y + row * ldy + col0) = o;
+}
+
 static bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 static int check_matrix(const void *x, int in_dtype, int64_t rows, int64_t cols, int64_t ld)
@@ -256,8 +299,19 @@ static int launch_quantize(const void *x, int in_dtype, int64_t rows, int64_t co
     const int64_t esz = in_dtype == MTQ_DTYPE_BF16 ? 2 : 4;
     const int vec_ok = aligned16(x) && (ld * esz) % 16 == 0;
     const int vec_ok_y = aligned16(y) && (ldy * 4) % 16 == 0;
-    const int64_t blocks = (groups + 255) / 256;
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (vec_ok && vec_ok_y && cols % kGroup == 0 && (in_dtype == MTQ_DTYPE_F32 || aligned16(x))) { // coalesced quad form
+        const int64_t qw = cols / 4, quads = rows * qw;
+        const int64_t qblocks = (quads + 255) / 256;
+        if (in_dtype == MTQ_DTYPE_BF16)
+            hipLaunchKernelGGL(quantize_quads<uint16_t>, dim3((unsigned)qblocks), dim3(256), 0, s, static_cast<const uint16_t *>(x), rows, cols,
+                               ld, (int)qw, (int)tw, fmt, map, y, ldy);
+        else
+            hipLaunchKernelGGL(quantize_quads<float>, dim3((unsigned)qblocks), dim3(256), 0, s, static_cast<const float *>(x), rows, cols, ld,
+                               (int)qw, (int)tw, fmt, map, y, ldy);
+        return check_launch(what);
+    }
+    const int64_t blocks = (groups + 255) / 256;
     if (in_dtype == MTQ_DTYPE_BF16)
         hipLaunchKernelGGL(quantize_groups<uint16_t>, dim3((unsigned)blocks), dim3(256), 0, s, static_cast<const uint16_t *>(x), rows, cols,
                            ld, (int)gw, (int)tw, fmt, map, y, ldy, vec_ok, vec_ok_y);
