@@ -222,3 +222,23 @@ def test_full_size_parity_and_properties():
     xl = (torch.randn((14336, 4096), generator=g) * 0.02 * torch.exp(0.5 * torch.randn((14336, 4096), generator=g))).to(torch.bfloat16)
     gl = hb.tile_stats(xl.cuda(), 0xE).cpu().numpy()
     assert np.array_equal(gl.view(np.uint64), orc.tile_stats(xl.float().numpy(), ["bfp8", "bfp4", "bfp2"]).view(np.uint64))
+
+
+def test_fast_kernel_strided_view_and_batch_stride():
+    """The exact-integer kernel on a column window of a wider matrix (ld > cols) and on a batch whose tensors are
+    padded apart (stride > rows*cols): same records as the oracle on the dense copies."""
+    x = gen("heavy_bf16", 21, (96, 640))
+    big = dev(x, bf16=True)
+    view = big[:, 128:512]                      # cols 384 = 3 units, ld 640, 16-byte aligned start
+    assert view.stride(0) == 640
+    want = orc.tile_stats(np.ascontiguousarray(x[:, 128:512]), ALL)
+    assert np.array_equal(hb.tile_stats(view, 0xF).cpu().numpy().view(np.uint64), want.view(np.uint64))
+    xs = np.stack([gen("normal_bf16", s, (64, 128)) for s in range(3)])
+    buf = torch.zeros((3, 80, 128), dtype=torch.bfloat16, device="cuda")      # 16 spare rows between tensors
+    buf[:, :64] = dev(xs, bf16=True)
+    out = torch.empty((3, 2 * 4, 22), dtype=torch.float64, device="cuda")
+    hb.check(hb.lib().mtq_tile_stats_batched(buf.data_ptr(), hb.DTYPE_BF16, 3, 80 * 128, 64, 128, 128, 0xF, out.data_ptr(),
+                                              torch.cuda.current_stream().cuda_stream))
+    got = out.cpu().numpy()
+    for i in range(3):
+        assert np.array_equal(got[i].view(np.uint64), orc.tile_stats(xs[i], ALL).view(np.uint64)), i
