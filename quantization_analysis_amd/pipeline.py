@@ -88,9 +88,10 @@ class GreedyPipeline:
         key = (slot, count, tiles, rec)
         if key not in self._bufs:
             torch = self.torch
-            dev = torch.empty((count, tiles, rec), dtype=torch.float64, device=device)
-            host = torch.empty((count, tiles, rec), dtype=torch.float64, pin_memory=True)
-            self._bufs[key] = (dev, host, host.numpy())
+            for sl in (0, 1):  # both slots at once: pinned allocations are slow and must not land in a timed region
+                dev = torch.empty((count, tiles, rec), dtype=torch.float64, device=device)
+                host = torch.empty((count, tiles, rec), dtype=torch.float64, pin_memory=True)
+                self._bufs[(sl, count, tiles, rec)] = (dev, host, host.numpy())
         return self._bufs[key]
 
     def submit(self, x3d, seeds=None) -> "cf.Future":
