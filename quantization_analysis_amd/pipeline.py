@@ -74,39 +74,29 @@ class GreedyPipeline:
             raise ValueError("seed 0 means 'draw a random seed' in the reference; pass a non-zero seed")
         self.chunk = int(chunk)
         self.workers = int(workers)
-        self.pool = cf.ThreadPoolExecutor(max_workers=1)  # collector: waits for chunks, fans each out over `workers` threads inside C
-        self._next_slot = 0
-        self._slot_busy = [None, None]
+        self.pool = cf.ThreadPoolExecutor(max_workers=2)  # chunk-level tasks; the fan-out over tensors happens inside the C call
         self.stream = torch.cuda.Stream()        # K1 launches
         self.copy_stream = torch.cuda.Stream()   # records D2H, overlapped with the next chunk's K1
         self.timing = KernelTiming()
         self._bufs = {}
 
-    def _buffers(self, slot: int, count: int, tiles: int, rec: int, device):
-        """Records of a whole batch: device buffer + pinned host mirror (scans read the pinned memory in place).
-        Two slots, so the GPU side of batch i+1 can run while the host still scans batch i."""
-        key = (slot, count, tiles, rec)
+    def _buffers(self, count: int, tiles: int, rec: int, device):
+        """Records of a whole batch: device buffer + pinned host mirror (scans read the pinned memory in place)."""
+        key = (count, tiles, rec)
         if key not in self._bufs:
             torch = self.torch
-            for sl in (0, 1):  # both slots at once: pinned allocations are slow and must not land in a timed region
-                dev = torch.empty((count, tiles, rec), dtype=torch.float64, device=device)
-                host = torch.empty((count, tiles, rec), dtype=torch.float64, pin_memory=True)
-                self._bufs[(sl, count, tiles, rec)] = (dev, host, host.numpy())
+            dev = torch.empty((count, tiles, rec), dtype=torch.float64, device=device)
+            host = torch.empty((count, tiles, rec), dtype=torch.float64, pin_memory=True)
+            self._bufs = {key: (dev, host, host.numpy())}
         return self._bufs[key]
 
-    def submit(self, x3d, seeds=None) -> "cf.Future":
-        """Enqueue one batch: K1 chunks + record D2H go to the HIP streams now, the host scans follow on the
-        collector thread as each chunk lands.  Returns a future of the per-tensor results."""
+    def run(self, x3d, seeds=None) -> list[TensorResult]:
         torch = self.torch
         count, rows, cols = x3d.shape
         th, tw = hb.tiles_hw(rows, cols)
         tiles, rec = th * tw, hb.record_doubles(self.mask)
         numel = rows * cols
-        slot = self._next_slot
-        self._next_slot ^= 1
-        if self._slot_busy[slot] is not None:     # the batch that used these buffers two submits ago must be done
-            self._slot_busy[slot].result()
-        dev, host, host_np = self._buffers(slot, count, tiles, rec, x3d.device)
+        dev, host, host_np = self._buffers(count, tiles, rec, x3d.device)
         pending = []  # (event, first_index, n)
         self.stream.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(self.stream):
@@ -124,25 +114,16 @@ class GreedyPipeline:
                     done = torch.cuda.Event()
                     done.record(self.copy_stream)
                 pending.append((done, first, n))
-
-        def collect():
-            out = []
-            for evt, first, n in pending:      # scans of chunk k run while chunks k+1.. are still on the GPU / the PCIe link
-                evt.synchronize()
-                sd = [self.seed] * n if seeds is None else [int(v) for v in seeds[first:first + n]]
-                out.extend(_scan_chunk(first, host_np[first:first + n], self.mask, (th, tw), numel, self.tile_formats,
-                                       self.metric, self.threshold, sd, self.workers))
-            return out
-
-        fut = self.pool.submit(collect)
-        self._slot_busy[slot] = fut
-        return fut
-
-    def run(self, x3d, seeds=None) -> list[TensorResult]:
-        res = self.submit(x3d, seeds).result()
-        self.torch.cuda.current_stream().wait_stream(self.stream)
-        self.torch.cuda.current_stream().wait_stream(self.copy_stream)
-        return res
+        futures = []
+        for evt, first, n in pending:      # scans of chunk k run while chunks k+1.. are still on the GPU / the PCIe link
+            evt.synchronize()
+            sd = [self.seed] * n if seeds is None else [int(v) for v in seeds[first:first + n]]
+            futures.append(self.pool.submit(_scan_chunk, first, host_np[first:first + n], self.mask, (th, tw), numel, self.tile_formats,
+                                            self.metric, self.threshold, sd, self.workers))
+        results = [r for f in futures for r in f.result()]
+        torch.cuda.current_stream().wait_stream(self.stream)
+        torch.cuda.current_stream().wait_stream(self.copy_stream)
+        return results
 
     def close(self) -> None:
         self.pool.shutdown(wait=True)
