@@ -222,3 +222,27 @@ def test_hip_quantizer_and_none(tmp_path):
     res = create_algorithm("none").run(x, ["bfp4"], q, CacheContext(tmp_path, "t", "hip", False, "r"))
     assert "/none/hip/bfp4/" in str(CacheContext(tmp_path, "t", "hip", False, "r").quant_path("none", "bfp4"))
     assert np.array_equal(res[0].y, orc.quantize_weight_values(x, "bfp4"))
+
+
+def _threshold_mid_size(quantizer, to_input=lambda x: x):
+    """2048 tiles, threshold inside the bfp4 score distribution (many near-threshold tiles): the float64-moment
+    decision + literal float32 re-score of the knife-edge tiles must reproduce the literal algorithm's map."""
+    x = gen("normal_bf16", 91, (1024, 2048))
+    thr = 0.99372
+    want, want_counts, _ = orc.threshold(x, ALL, "pcc", thr)
+    r = create_algorithm("mixed-tile-threshold", {"metric": "pcc", "threshold": thr}).run(to_input(x), ALL, quantizer, ctx(quantizer.backend))[0]
+    assert np.array_equal(r.meta["assignment"], want)
+    assert r.tile_counts == want_counts and min(want_counts["bfp8"], want_counts["bfp4"]) > 100
+    y = r.y.cpu().numpy() if hasattr(r.y, "cpu") else r.y
+    assert np.array_equal(y.view(np.uint32), orc.apply_assignment(x, want).view(np.uint32))
+
+
+def test_threshold_mid_size_emulation():
+    _threshold_mid_size(Quantizer("emulation"))
+
+
+@pytest.mark.gpu
+def test_threshold_mid_size_hip():
+    import torch
+
+    _threshold_mid_size(Quantizer("hip"), to_input=lambda x: torch.from_numpy(x).cuda().to(torch.bfloat16))
