@@ -422,8 +422,7 @@ inline uint32_t pcg_next32(mtq_rng *r)
 inline uint64_t rng_interval(mtq_rng *r, uint64_t max)
 {
     if (max == 0) return 0;
-    uint64_t mask = max;
-    mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16; mask |= mask >> 32;
+    const uint64_t mask = ~0ull >> __builtin_clzll(max); // smallest 2^k − 1 ≥ max (NumPy builds it with shifts and ors)
     uint64_t v;
     if (max <= 0xFFFFFFFFull) { while ((v = (pcg_next32(r) & mask)) > max) {} }
     else { while ((v = (pcg_next64(r) & mask)) > max) {} }
