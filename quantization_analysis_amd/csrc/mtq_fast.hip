@@ -118,7 +118,7 @@ struct GroupOut {
     bool bad;   // outside the exact route's preconditions: the tile is redone by the literal fix-up kernel
 };
 
-template <typename Reload>
+template <uint32_t BFP, typename Reload>
 __device__ __forceinline__ void fast_group(const uint32_t w[8], GroupOut &G, Reload reload)
 {
     uint32_t ab[8];
@@ -148,9 +148,10 @@ __device__ __forceinline__ void fast_group(const uint32_t w[8], GroupOut &G, Rel
         sbs = __builtin_amdgcn_udot2(as_us2(b), as_us2(0x00010001u), sbs, false);
         bmaxp = as_u32(__builtin_elementwise_max(as_us2(bmaxp), as_us2(b)));
         const uint32_t abias = a | 0x80008000u;
+        // bfp8 also carries Σa² (see below), so it is evaluated for every mask; bfp4 / bfp2 only when requested
         fmt_step<Fmt8>(a, abias, sgn, A8);
-        fmt_step<Fmt4>(a, abias, sgn, A4);
-        fmt_step<Fmt2>(a, abias, sgn, A2);
+        if constexpr (BFP & 2u) fmt_step<Fmt4>(a, abias, sgn, A4);
+        if constexpr (BFP & 4u) fmt_step<Fmt2>(a, abias, sgn, A2);
     }
     // exact route needs every float32 term normal and finite: E in [80, 180]; anything else marks the tile
     G.bad = !((E >= 80u) & (E <= 180u));
@@ -165,6 +166,11 @@ __device__ __forceinline__ void fast_group(const uint32_t w[8], GroupOut &G, Rel
     const int mbs[3] = {7, 3, 1};
 #pragma unroll
     for (int f = 0; f < 3; ++f) {
+        if (!(BFP & (1u << f))) { // format not requested: its record slot is not written
+            G.term[2 + 4 * f] = G.term[3 + 4 * f] = G.term[4 + 4 * f] = G.term[5 + 4 * f] = 0.0;
+            G.mx[f] = 0.0f;
+            continue;
+        }
         G.term[2 + 4 * f] = __builtin_ldexp((double)A[f]->ssy, e1 + 7);                       // Σ±y · 2^(E−141)
         const uint32_t sq2 = f == 2 ? (A[f]->sq2 & 0xFFFFu) + (A[f]->sq2 >> 16) : A[f]->sq2;
         G.term[3 + 4 * f] = __builtin_ldexp((double)sq2, 2 * ((int)E - 126 - mbs[f]));        // Σq² · 2^(2(E−126−mb))
@@ -215,6 +221,7 @@ __device__ __forceinline__ void glds16(const void *sbase, uint32_t voff, uint32_
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_addr) : "memory");
 }
 
+template <uint32_t BFP>
 __global__ __launch_bounds__(kFastWaves * 64, MTQ_ROLLED_WAVES_PER_SIMD) void tile_stats_bf16_rolled(
     const uint16_t *__restrict__ x, int64_t stride, int64_t ld, int tiles_w, int64_t tiles, int units_w, int units_per_tensor,
     int total_units, uint32_t fmt_mask, int rec, double *__restrict__ stats)
@@ -275,7 +282,7 @@ __global__ __launch_bounds__(kFastWaves * 64, MTQ_ROLLED_WAVES_PER_SIMD) void ti
             const uint4 hi = *reinterpret_cast<const uint4 *>(rowp + ((c0 ^ (kl | 1u)) << 4));
             const uint32_t w[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
             GroupOut G;
-            fast_group(w, G, [&](uint32_t w2[8]) {
+            fast_group<BFP>(w, G, [&](uint32_t w2[8]) {
                 const uint4 l2 = *reinterpret_cast<const uint4 *>(rowp + ((c0 ^ kl) << 4));
                 const uint4 h2 = *reinterpret_cast<const uint4 *>(rowp + ((c0 ^ (kl | 1u)) << 4));
                 w2[0] = l2.x; w2[1] = l2.y; w2[2] = l2.z; w2[3] = l2.w; w2[4] = h2.x; w2[5] = h2.y; w2[6] = h2.z; w2[7] = h2.w;
@@ -374,7 +381,21 @@ extern "C" int mtq_launch_tile_stats_bf16_fast(const void *x, int64_t count, int
     const int64_t need = (total + kFastWaves - 1) / kFastWaves;
     const int64_t max_blocks = (int64_t)cus * MTQ_ROLLED_WAVES_PER_SIMD; // blocks of 4 waves per CU (one wave of each per SIMD)
     const unsigned blocks = (unsigned)(need < max_blocks ? need : max_blocks);
-    hipLaunchKernelGGL(tile_stats_bf16_rolled, dim3(blocks), dim3(kFastWaves * 64), kFastWaves * kRolledWaveLds, static_cast<hipStream_t>(stream),
-                       static_cast<const uint16_t *>(x), stride_elems, ld, (int)tw, tiles, (int)units_w, (int)upt, (int)total, fmt_mask, rec, stats);
+    const dim3 grid(blocks), block(kFastWaves * 64);
+    const size_t lds_bytes = kFastWaves * kRolledWaveLds;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const uint16_t *xp = static_cast<const uint16_t *>(x);
+#define MTQ_LAUNCH_FAST(B) \
+    hipLaunchKernelGGL(tile_stats_bf16_rolled<B>, grid, block, lds_bytes, st, xp, stride_elems, ld, (int)tw, tiles, (int)units_w, (int)upt, (int)total, fmt_mask, rec, stats)
+    switch ((fmt_mask >> 1) & 7u) { // one instantiation per requested BFP subset: unrequested formats cost nothing
+    case 1: MTQ_LAUNCH_FAST(1u); break;
+    case 2: MTQ_LAUNCH_FAST(2u); break;
+    case 3: MTQ_LAUNCH_FAST(3u); break;
+    case 4: MTQ_LAUNCH_FAST(4u); break;
+    case 5: MTQ_LAUNCH_FAST(5u); break;
+    case 6: MTQ_LAUNCH_FAST(6u); break;
+    default: MTQ_LAUNCH_FAST(7u); break;
+    }
+#undef MTQ_LAUNCH_FAST
     return check_launch("mtq_tile_stats (bf16 fast)");
 }
