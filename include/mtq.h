@@ -147,6 +147,9 @@ void mtq_greedy_destroy(mtq_greedy *g);
 typedef struct mtq_rng mtq_rng; /* opaque */
 int mtq_rng_create(mtq_rng **out, uint64_t seed);
 int mtq_rng_permutation(mtq_rng *r, int64_t n, int64_t *out);
+/* ≡ rng.integers(0, high, size=n, dtype=np.int64) for 1 <= high < 2^32 − 1 (mixed_tile_random.py:135: Lemire
+ * rejection on buffered 32-bit draws; high == 1 draws nothing). */
+int mtq_rng_integers(mtq_rng *r, int64_t high, int64_t n, int64_t *out);
 void mtq_rng_destroy(mtq_rng *r);
 
 /*

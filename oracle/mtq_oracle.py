@@ -391,6 +391,47 @@ def threshold(xf: np.ndarray, tile_formats, metric: str = "pcc", threshold: floa
     return a.reshape(th, tw), counts, scores
 
 
+def metric_better(value: float, best: float, metric: str) -> bool:
+    """metrics.py:36-39."""
+    return value > best if metric == "pcc" else value < best
+
+
+def random_search(xf: np.ndarray, tile_formats, metric: str = "pcc", threshold: float = 0.999, iters: int = 50, seed: int = 0):
+    """mixed_tile_random.py:88-186 → (assignment int8 (tiles_h,tiles_w), counts, samples).  `iters` random maps
+    drawn with default_rng(seed).integers (:135); every map is scored on the whole reconstructed tensor in
+    float32 (:139-143); the smallest map that meets the threshold wins, else the best-scoring one (:160-173)."""
+    xf = np.asarray(xf, dtype=np.float32)
+    if xf.size == 0:  # :94-100
+        return np.zeros((1, 1), dtype=np.int8), {f: 0 for f in MIXED_TILE_FORMATS}, []
+    x2d, _ = flatten_2d(xf)
+    th, tw = tiles_hw(*x2d.shape)
+    T = th * tw
+    fmt_indices = np.asarray([MIXED_TILE_FORMATS.index(f) for f in tile_formats] or list(range(4)), dtype=np.int8)  # :113-116
+    rng = np.random.default_rng(seed)  # :117 (seed 0 is a real seed here, unlike the greedy search)
+    bpe = np.asarray([MIXED_TILE_BYTES_PER_ELEM[f] for f in MIXED_TILE_FORMATS], dtype=np.float32)  # :118-126
+    best_metric = best_assign = best_bytes = None
+    samples = []
+    for sample_id in range(max(1, iters)):
+        choice = rng.integers(0, len(fmt_indices), size=T, dtype=np.int64)  # :135
+        a = fmt_indices[choice].astype(np.int8)
+        y = apply_assignment(xf, a.reshape(th, tw))  # :137-138 (tile-wise quantisation == whole-tensor quantisation, F2)
+        score = metric_value(xf, y, metric)
+        diff = np.abs(xf - y)
+        counts_arr = np.bincount(a.astype(np.int64), minlength=4)
+        counts = {f: int(counts_arr[i]) for i, f in enumerate(MIXED_TILE_FORMATS)}
+        samples.append({"id": sample_id, "counts": counts, "total_bytes": mixed_tile_total_bytes(counts),
+                        "pcc": pearson_corr(xf, y), "mae": float(np.mean(diff)), "atol": float(np.max(diff))})
+        if metric_is_good(score, metric, threshold):  # :160-167
+            total = float(np.sum(counts_arr * bpe) * (TILE * TILE))  # float32 product, as the reference
+            if best_bytes is None or total < best_bytes:
+                best_bytes, best_metric, best_assign = total, score, a.copy()
+        elif best_bytes is None:  # :168-172
+            if best_metric is None or metric_better(score, best_metric, metric):
+                best_metric, best_assign = score, a.copy()
+    counts = {f: int(np.sum(best_assign == i)) for i, f in enumerate(MIXED_TILE_FORMATS)}
+    return best_assign.reshape(th, tw), counts, samples
+
+
 def columns_from_stats(stats: np.ndarray, slots: dict, assignment: np.ndarray, n: int) -> tuple[float, float, float]:
     """Tensor-level (pcc, mae, atol) of the reconstruction implied by `assignment`, from the per-tile
     raw sums in float64 (what the hip backend reports).  Sums run in tile order."""

@@ -2,7 +2,7 @@
 
 Same flags, seed rules, tables and result artifacts as the reference (`wq:37-79,553-586,629-647,753-848,881-882`),
 plus `--backend hip`.  Differences forced by the environment: the model comes from `model_source` (synthetic presets or a
-local safetensors directory, no Hub access), plots are not drawn, and when launched under
+local safetensors directory, no Hub access), `--no-plots` skips the PNG artifacts, and when launched under
 `python -m torch.distributed.run` the matched tensors are sharded over the ranks (one process per GPU) with a single
 gather of fixed-width summary rows to rank 0.
 """
@@ -29,7 +29,7 @@ from .model_source import build_model_index, lpt_shards, resolve_format_list, re
 from .quantization_formats import SUPPORTED_FORMATS
 
 FORMAT_BYTES_PER_ELEM = {"bf16": 2.0, "bfp8": 1.088, "bfp4": 0.50097, "bfp2": 0.25097, "fp0": 0.0}  # wq:132-140
-MIXED_ALGOS = {"mixed-tile-greedy", "mixed-tile-threshold"}
+MIXED_ALGOS = {"mixed-tile-greedy", "mixed-tile-random", "mixed-tile-threshold"}
 ROW_W = 16  # summary row: idx, comp, fmt, pcc, mae, atol, time, gb, tile_bytes, 4 counts, xmin, xmean, xmax
 
 
@@ -46,6 +46,7 @@ def parse_args(argv=None) -> argparse.Namespace:
     parser.add_argument("--recompute", action="store_true", help="Recompute and overwrite cached quantized tensors.")
     parser.add_argument("--summary", action="store_true", help="Print the aggregate summary (default: off).")
     parser.add_argument("--results-dir", default="results", help="Root of the result artifacts (default: results).")
+    parser.add_argument("--no-plots", action="store_true", help="Skip the PNG artifacts (maps, size-vs-accuracy, random samples).")
     return parser.parse_args(argv)
 
 
@@ -77,19 +78,82 @@ def resolve_seed(config, algo_params: dict):
     return used_seed, seed_source
 
 
-def write_assignment_outputs(out_dir: Path, tensor_name: str, assignment: np.ndarray, algo_dir: str) -> None:
-    """wq:295-316 (assignment.npy int8 + assignment_mapping.json); the PNG plots are not drawn."""
-    mt_dir = out_dir / algo_dir / _slug(tensor_name)
-    mt_dir.mkdir(parents=True, exist_ok=True)
-    np.save(mt_dir / "assignment.npy", assignment.astype(np.int8))
-    mapping = {
+def _assignment_mapping(assignment: np.ndarray) -> dict:
+    return {
         "tile_hw": 32,
         "format_to_int": {fmt: idx for idx, fmt in enumerate(MIXED_TILE_FORMATS)},
         "int_to_format": MIXED_TILE_FORMATS,
         "assignment_shape": list(assignment.shape),
     }
+
+
+def write_assignment_outputs(out_dir: Path, tensor_name: str, assignment: np.ndarray, algo_dir: str, draw: bool = True) -> None:
+    """wq:295-316: <algo_dir>/<slug>/{assignment.npy (int8), assignment_mapping.json, <slug>_assignment.png}."""
+    mt_dir = out_dir / algo_dir / _slug(tensor_name)
+    mt_dir.mkdir(parents=True, exist_ok=True)
+    np.save(mt_dir / "assignment.npy", assignment.astype(np.int8))
     with (mt_dir / "assignment_mapping.json").open("w", encoding="utf-8") as f:
-        json.dump(mapping, f, indent=2)
+        json.dump(_assignment_mapping(assignment), f, indent=2)
+    if draw:
+        from . import plots
+
+        plots.write_assignment_map(mt_dir / f"{_slug(tensor_name)}_assignment.png", assignment)
+
+
+def write_random_outputs(out_dir: Path, tensor_name: str, samples: list, tile_formats: list, assignment, draw: bool = True) -> None:
+    """wq:151-218: mixed_tile_random/{<slug>.csv (one row per sample), <slug>_assignment.npy, <slug>_assignment_mapping.json,
+    <slug>.png}."""
+    import csv
+
+    if not samples:
+        return
+    mt_dir = out_dir / "mixed_tile_random"
+    mt_dir.mkdir(parents=True, exist_ok=True)
+    slug = _slug(tensor_name)
+    with (mt_dir / f"{slug}.csv").open("w", newline="", encoding="utf-8") as f:
+        w = csv.writer(f)
+        w.writerow(["sample_id", *[f"{fmt}_tiles" for fmt in tile_formats], "total_gb", "pcc", "mae", "atol"])
+        for s in samples:
+            w.writerow([s.get("id"), *[s.get("counts", {}).get(fmt, 0) for fmt in tile_formats],
+                        float(s.get("total_bytes", 0.0)) / 1e9, s.get("pcc"), s.get("mae"), s.get("atol")])
+    if assignment is not None:
+        np.save(mt_dir / f"{slug}_assignment.npy", assignment.astype(np.int8))
+        with (mt_dir / f"{slug}_assignment_mapping.json").open("w", encoding="utf-8") as f:
+            json.dump(_assignment_mapping(assignment), f, indent=2)
+    if draw:
+        from . import plots
+
+        plots.write_random_samples(mt_dir / f"{slug}.png", samples)
+
+
+def write_size_plot(out_dir: Path, tensor_name: str, metric_name: str, rows, formats, algo_name: str) -> None:
+    """wq:436-497: baselines (the `none` rows) and the MIXED row of one tensor → <algo_dir>/<slug>/size_vs_accuracy.png.
+    rows: this tensor's summary rows (ROW_W wide), comp index 0 = none, 1 = the selected algorithm."""
+    from . import plots
+
+    col = {"pcc": 3, "mae": 4, "atol": 5}[metric_name]
+    mixed_rows = [r for r in rows if int(r[1]) == 1]
+    if not mixed_rows:
+        return
+    total_tiles = next((int(sum(r[9:13])) for r in mixed_rows if r[9] >= 0), None)
+    points = []
+    for r in rows:
+        if int(r[1]) == 0:
+            fmt = formats_of_row(r)
+            tiles = {f: 0 for f in MIXED_TILE_FORMATS}
+            if total_tiles is not None and fmt in tiles:
+                tiles[fmt] = total_tiles
+            points.append({"label": fmt.upper(), "bytes": r[7] * 1e9, "metric": r[col], "kind": "baseline",
+                           **{f"{f}_tiles": tiles[f] for f in MIXED_TILE_FORMATS}})
+    for r in mixed_rows:
+        points.append({"label": "MIXED", "bytes": r[7] * 1e9, "metric": r[col], "kind": "mixed",
+                       **{f"{f}_tiles": max(0, int(r[9 + i])) for i, f in enumerate(MIXED_TILE_FORMATS)}})
+    plots.write_size_vs_accuracy(out_dir / algo_name.replace("-", "_") / _slug(tensor_name) / "size_vs_accuracy.png", metric_name,
+                                 points, MIXED_TILE_FORMATS)
+
+
+def formats_of_row(r) -> str:
+    return "mixed" if int(r[2]) < 0 else SUPPORTED_FORMATS[int(r[2])]
 
 
 def _columns_emulation(xf: np.ndarray, y: np.ndarray):
@@ -164,9 +228,16 @@ def _evaluate_tensor(idx, name, index, algorithms, formats, quantizer, args, run
             fcode = -1 if res.fmt == "MIXED" else SUPPORTED_FORMATS.index(fmt_l)
             rows.append([idx, ci, fcode, pcc, mae, atol, elapsed, gb, res.tile_bytes if res.tile_bytes is not None else np.nan,
                          *counts, *meta])
-            if res.compression in MIXED_ALGOS and res.meta and isinstance(res.meta.get("assignment"), np.ndarray):
-                write_assignment_outputs(results_dir, name, res.meta["assignment"], res.compression.replace("-", "_"))
-    return np.asarray(rows, dtype=np.float64).reshape(-1, ROW_W)
+            draw = not args.no_plots
+            if res.compression == "mixed-tile-random" and res.meta:  # wq:711-722
+                if isinstance(res.meta.get("samples"), list) and res.meta.get("tile_formats"):
+                    write_random_outputs(results_dir, name, res.meta["samples"], res.meta["tile_formats"], res.meta.get("assignment"), draw)
+            elif res.compression in MIXED_ALGOS and res.meta and isinstance(res.meta.get("assignment"), np.ndarray):
+                write_assignment_outputs(results_dir, name, res.meta["assignment"], res.compression.replace("-", "_"), draw)
+    out = np.asarray(rows, dtype=np.float64).reshape(-1, ROW_W)
+    if not args.no_plots and len(algorithms) > 1 and algorithms[1].name in {"mixed-tile-threshold", "mixed-tile-greedy"}:  # wq:743-750
+        write_size_plot(results_dir, name, algorithms[1].params.get("metric", "pcc"), out, formats, algorithms[1].name)
+    return out
 
 
 def _print_tables(names, rows, comp_names, shapes, table_lines, summary: bool, formats):

@@ -1,31 +1,31 @@
-"""Algorithm registry (reference compression_algorithms/__init__.py:11-29).
-
-Built here: none, mixed-tile-greedy (alias mixed-tile), mixed-tile-threshold.  `transpose` and
-`mixed-tile-random` of the reference are outside the hot path this package covers and are
-reported as unsupported rather than silently mapped to something else.
+"""Search algorithms selectable from the JSON config (`algorithm` key) — same names as the reference's registry
+(compression_algorithms/__init__.py:11-29) for the mixed-tile family and the `none` baseline; `mixed-tile` is the
+reference's alias of the greedy search.  The reference's `transpose` experiment (not a mixed-tile search, no
+kernel of this package involved) is not provided and is reported as unsupported rather than mapped to
+something else.
 """
 from __future__ import annotations
 
-from .base import CompressionAlgorithm, CompressionResult
-from .config import CompressionConfig, load_compression_config
-from .mixed_tile_greedy import MixedTileGreedyCompression
-from .mixed_tile_threshold import MixedTileThresholdCompression
-from .none import NoneCompression
+from . import base as _base, config as _config
+from . import mixed_tile_greedy as _greedy, mixed_tile_random as _random, mixed_tile_threshold as _threshold, none as _none
 
-ALGORITHM_REGISTRY: dict[str, type[CompressionAlgorithm]] = {
-    "none": NoneCompression,
-    "mixed-tile-greedy": MixedTileGreedyCompression,
-    "mixed-tile-threshold": MixedTileThresholdCompression,
-    "mixed-tile": MixedTileGreedyCompression,
-}
+CompressionAlgorithm, CompressionResult = _base.CompressionAlgorithm, _base.CompressionResult
+CompressionConfig, load_compression_config = _config.CompressionConfig, _config.load_compression_config
+NoneCompression = _none.NoneCompression
+MixedTileGreedyCompression = _greedy.MixedTileGreedyCompression
+MixedTileRandomCompression = _random.MixedTileRandomCompression
+MixedTileThresholdCompression = _threshold.MixedTileThresholdCompression
+
+ALGORITHM_REGISTRY: dict = {cls.name: cls for cls in (NoneCompression, MixedTileGreedyCompression,
+                                                      MixedTileRandomCompression, MixedTileThresholdCompression)}
+ALGORITHM_REGISTRY["mixed-tile"] = MixedTileGreedyCompression
 
 
 def create_algorithm(name: str, params: dict | None = None) -> CompressionAlgorithm:
-    key = name.strip().lower()
-    cls = ALGORITHM_REGISTRY.get(key)
-    if cls is None:
-        raise ValueError(
-            f"Unsupported compression algorithm '{name}'. "
-            f"Supported: {', '.join(sorted(ALGORITHM_REGISTRY))}"
-        )
-    return cls.from_params(params or {})
+    """Case-insensitive lookup; an unknown name lists what is available."""
+    try:
+        algorithm_cls = ALGORITHM_REGISTRY[name.strip().lower()]
+    except KeyError:
+        known = ", ".join(sorted(ALGORITHM_REGISTRY))
+        raise ValueError(f"Unsupported compression algorithm '{name}'. Supported: {known}") from None
+    return algorithm_cls.from_params(params if params else {})

@@ -1,60 +1,67 @@
-"""JSON compression config → dataclass (reference compression_algorithms/config.py:8-69).
-Seed rules: an int seed is kept; 0 or "random" mean "draw a fresh seed" (:52-61)."""
+"""The `--compression-config` JSON file (reference compression_algorithms/config.py:8-69).
+
+{"algorithm": "...", "params": {...}, "quantization_formats": [...], "seed": int | 0 | "random", "random_seed": bool}
+Seed rules (:52-61): a non-zero int is used as is; 0, "random" or random_seed=true mean "draw a fresh seed per run".
+"""
 from __future__ import annotations
 
+import dataclasses
 import json
-from dataclasses import dataclass
-from pathlib import Path
+import pathlib
+from typing import Optional
 
 
-@dataclass
+@dataclasses.dataclass
 class CompressionConfig:
     algorithm: str
     params: dict
-    quantization_formats: list[str] | None
-    seed: int | None
+    quantization_formats: Optional[list]
+    seed: Optional[int]
     random_seed: bool
 
 
-def load_compression_config(path: str | None) -> CompressionConfig:
-    if path is None:
-        return CompressionConfig(algorithm="none", params={}, quantization_formats=None, seed=None, random_seed=False)
-    cfg_path = Path(path)
-    if not cfg_path.exists():
-        raise FileNotFoundError(f"Compression config not found: {path}")
-    with cfg_path.open("r", encoding="utf-8") as f:
-        data = json.load(f)
-    if not isinstance(data, dict):
-        raise ValueError("Compression config must be a JSON object")
+def _formats_field(raw) -> Optional[list]:
+    if raw is None:
+        return None
+    if not isinstance(raw, list):
+        raise ValueError("Compression config 'quantization_formats' must be a list of strings")
+    cleaned = [str(entry).strip().lower() for entry in raw]
+    cleaned = [entry for entry in cleaned if entry]
+    return cleaned if cleaned else None
 
-    algorithm = str(data.get("algorithm", "none")).strip().lower()
-    params = data.get("params", {})
+
+def _seed_fields(raw, want_random: bool) -> tuple:
+    """→ (seed or None, random_seed)."""
+    if raw is None:
+        return None, want_random
+    if isinstance(raw, str) and raw.strip().lower() == "random":
+        return None, True
+    try:
+        value = int(raw)
+    except (TypeError, ValueError) as exc:
+        raise ValueError("Compression config 'seed' must be an int, 0, or 'random'") from exc
+    return (None, True) if value == 0 else (value, want_random)
+
+
+def load_compression_config(path: Optional[str]) -> CompressionConfig:
+    if path is None:  # no file: the plain per-format baseline
+        return CompressionConfig("none", {}, None, None, False)
+    file = pathlib.Path(path)
+    if not file.exists():
+        raise FileNotFoundError(f"Compression config not found: {path}")
+    doc = json.loads(file.read_text(encoding="utf-8"))
+    if not isinstance(doc, dict):
+        raise ValueError("Compression config must be a JSON object")
+    params = doc.get("params")
     if params is None:
         params = {}
-    if not isinstance(params, dict):
+    elif not isinstance(params, dict):
         raise ValueError("Compression config 'params' must be an object")
-
-    qformats = data.get("quantization_formats")
-    if qformats is None:
-        quantization_formats = None
-    else:
-        if not isinstance(qformats, list):
-            raise ValueError("Compression config 'quantization_formats' must be a list of strings")
-        quantization_formats = [str(item).strip().lower() for item in qformats if str(item).strip()] or None
-
-    seed_value = data.get("seed")
-    random_seed = bool(data.get("random_seed", False))
-    seed = None
-    if seed_value is not None:
-        if isinstance(seed_value, str) and seed_value.strip().lower() == "random":
-            random_seed = True
-        else:
-            try:
-                seed = int(seed_value)
-            except (TypeError, ValueError) as exc:
-                raise ValueError("Compression config 'seed' must be an int, 0, or 'random'") from exc
-            if seed == 0:
-                random_seed = True
-                seed = None
-    return CompressionConfig(algorithm=algorithm, params=params, quantization_formats=quantization_formats,
-                             seed=seed, random_seed=random_seed)
+    seed, random_seed = _seed_fields(doc.get("seed"), bool(doc.get("random_seed", False)))
+    return CompressionConfig(
+        algorithm=str(doc.get("algorithm", "none")).strip().lower(),
+        params=params,
+        quantization_formats=_formats_field(doc.get("quantization_formats")),
+        seed=seed,
+        random_seed=random_seed,
+    )

@@ -6,40 +6,39 @@ import numpy as np
 
 from .metrics import metric_value, pearson_corr
 
+TILE_HW = 32
+# index in this list = int8 code in assignment maps; bytes per element include the shared exponents (1 B per 16 values)
 MIXED_TILE_FORMATS = ["bf16", "bfp8", "bfp4", "bfp2"]
-MIXED_TILE_BYTES_PER_ELEM = {
-    "bf16": 2.0,
-    "bfp8": 1.088,
-    "bfp4": 0.50097,
-    "bfp2": 0.25097,
-}
+MIXED_TILE_BYTES_PER_ELEM = dict(zip(MIXED_TILE_FORMATS, (2.0, 1.088, 0.50097, 0.25097)))
 
 
-def assignment_to_array(assignment: np.ndarray) -> np.ndarray:
+def assignment_to_array(assignment) -> np.ndarray:
     return np.asarray(assignment, dtype=np.int8)
 
 
-def mixed_tile_total_bytes(counts: dict[str, int], tile_hw: int = 32) -> float:
-    total = 0.0
-    elems_per_tile = float(tile_hw * tile_hw)
-    for fmt, count in counts.items():
-        total += float(count) * elems_per_tile * MIXED_TILE_BYTES_PER_ELEM.get(fmt, 0.0)
-    return total
+def mixed_tile_total_bytes(counts: dict, tile_hw: int = TILE_HW) -> float:
+    """Size model of a mixed map: Σ tiles × elements per tile × bytes per element, accumulated in the iteration
+    order of `counts` (Python floats — the BYTES column is compared exactly)."""
+    per_tile = float(tile_hw * tile_hw)
+    acc = 0.0
+    for name, n_tiles in counts.items():
+        acc += float(n_tiles) * per_tile * MIXED_TILE_BYTES_PER_ELEM.get(name, 0.0)
+    return acc
 
 
-def format_tag(formats: list[str]) -> str:
+def format_tag(formats) -> str:
     return "+".join(formats) if formats else "none"
 
 
 def tile_metrics(ref_tiles: np.ndarray, q_tiles: np.ndarray, metric: str) -> np.ndarray:
+    """float32 score of every (T, 32, 32) tile pair over all 1024 positions, pads included (:46-57)."""
+    count = ref_tiles.shape[0]
     if metric == "pcc":
-        return np.asarray([pearson_corr(ref_tiles[i], q_tiles[i]) for i in range(ref_tiles.shape[0])], dtype=np.float32)
-    diff = np.abs(ref_tiles - q_tiles)
-    if metric == "mae":
-        return diff.reshape(diff.shape[0], -1).mean(axis=1)
-    if metric == "atol":
-        return diff.reshape(diff.shape[0], -1).max(axis=1)
-    raise ValueError(f"Unsupported metric: {metric}")
+        return np.fromiter((pearson_corr(ref_tiles[t], q_tiles[t]) for t in range(count)), dtype=np.float32, count=count)
+    if metric not in ("mae", "atol"):
+        raise ValueError(f"Unsupported metric: {metric}")
+    err = np.abs(ref_tiles - q_tiles).reshape(count, -1)
+    return err.mean(axis=1) if metric == "mae" else err.max(axis=1)
 
 
 def flatten_2d(xf: np.ndarray) -> tuple[np.ndarray, tuple]:
@@ -57,13 +56,13 @@ def flatten_2d(xf: np.ndarray) -> tuple[np.ndarray, tuple]:
 
 
 def reshape_to_2d_with_padding(xf: np.ndarray) -> tuple[np.ndarray, tuple, tuple]:
-    data2d, shape_info = flatten_2d(xf)
-    h, w = data2d.shape
-    h_pad = int(np.ceil(h / 32.0)) * 32
-    w_pad = int(np.ceil(w / 32.0)) * 32
-    padded = np.zeros((h_pad, w_pad), dtype=np.float32)
-    padded[:h, :w] = data2d
-    return padded, shape_info, (h, w, h_pad, w_pad)
+    """→ (zero-padded matrix with 32-multiple sides, shape_info for unflatten_2d, (h, w, h_pad, w_pad))."""
+    flat, shape_info = flatten_2d(xf)
+    h, w = flat.shape
+    h_pad, w_pad = -(-h // TILE_HW) * TILE_HW, -(-w // TILE_HW) * TILE_HW
+    out = np.zeros((h_pad, w_pad), dtype=np.float32)
+    out[:h, :w] = flat
+    return out, shape_info, (h, w, h_pad, w_pad)
 
 
 def to_tiles(padded: np.ndarray, tile_hw: int = 32) -> np.ndarray:

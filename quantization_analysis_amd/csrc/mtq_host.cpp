@@ -468,6 +468,25 @@ void rng_permutation(mtq_rng *r, int64_t n, int64_t *out)
     }
 }
 
+// Generator.integers(0, high, size=n, dtype=int64) for high − 1 < 2^32 − 1: Lemire's multiply-shift rejection
+// on buffered 32-bit draws (numpy/random/src/distributions/distributions.c, buffered_bounded_lemire_uint32;
+// Generator.integers never takes the masked form).  high == 1 consumes nothing.
+void rng_integers(mtq_rng *r, uint32_t high, int64_t n, int64_t *out)
+{
+    const uint32_t rng = high - 1u;
+    if (rng == 0u) { for (int64_t i = 0; i < n; ++i) out[i] = 0; return; }
+    const uint32_t rng_excl = high;
+    for (int64_t i = 0; i < n; ++i) {
+        uint64_t m = (uint64_t)pcg_next32(r) * rng_excl;
+        uint32_t leftover = (uint32_t)m;
+        if (leftover < rng_excl) {
+            const uint32_t threshold = (0xFFFFFFFFu - rng) % rng_excl;
+            while (leftover < threshold) { m = (uint64_t)pcg_next32(r) * rng_excl; leftover = (uint32_t)m; }
+        }
+        out[i] = (int64_t)(m >> 32);
+    }
+}
+
 } // namespace
 
 extern "C" int mtq_rng_create(mtq_rng **out, uint64_t seed)
@@ -484,6 +503,14 @@ extern "C" int mtq_rng_permutation(mtq_rng *r, int64_t n, int64_t *out)
 {
     if (!r || (!out && n > 0) || n < 0) return fail(MTQ_ERR_INVALID, "bad argument");
     rng_permutation(r, n, out);
+    return MTQ_OK;
+}
+
+extern "C" int mtq_rng_integers(mtq_rng *r, int64_t high, int64_t n, int64_t *out)
+{
+    if (!r || (!out && n > 0) || n < 0) return fail(MTQ_ERR_INVALID, "bad argument");
+    if (high < 1 || high >= 0xFFFFFFFFll) return fail(MTQ_ERR_INVALID, "high must be in [1, 2^32 - 2]");
+    rng_integers(r, (uint32_t)high, n, out);
     return MTQ_OK;
 }
 

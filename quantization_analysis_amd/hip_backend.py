@@ -29,7 +29,7 @@ EXPORTS = [
     "mtq_greedy_create", "mtq_greedy_pass", "mtq_greedy_assignment", "mtq_greedy_fixed",
     "mtq_greedy_counts", "mtq_greedy_value", "mtq_greedy_destroy",
     "mtq_tile_scores", "mtq_threshold_assign", "mtq_columns_from_stats",
-    "mtq_rng_create", "mtq_rng_permutation", "mtq_rng_destroy", "mtq_greedy_run", "mtq_greedy_run_batch",
+    "mtq_rng_create", "mtq_rng_permutation", "mtq_rng_integers", "mtq_rng_destroy", "mtq_greedy_run", "mtq_greedy_run_batch",
 ]
 
 
@@ -89,6 +89,7 @@ def lib() -> ctypes.CDLL:
     L.mtq_columns_from_stats.argtypes = [vp, i64, u32, vp, dbl, vp]
     L.mtq_rng_create.argtypes = [ctypes.POINTER(vp), ctypes.c_uint64]
     L.mtq_rng_permutation.argtypes = [vp, i64, vp]
+    L.mtq_rng_integers.argtypes = [vp, i64, i64, vp]
     L.mtq_rng_destroy.argtypes = [vp]
     L.mtq_rng_destroy.restype = None
     L.mtq_greedy_run.argtypes = [vp, i64, u32, vp, ci, ci, dbl, dbl, ctypes.c_uint64, vp, vp, vp]
@@ -329,6 +330,12 @@ class NumpyCompatRng:
     def permutation(self, n: int) -> np.ndarray:
         out = np.empty(int(n), dtype=np.int64)
         check(lib().mtq_rng_permutation(self._h, int(n), out.ctypes.data))
+        return out
+
+    def integers(self, high: int, n: int) -> np.ndarray:
+        """≡ rng.integers(0, high, size=n, dtype=np.int64)."""
+        out = np.empty(int(n), dtype=np.int64)
+        check(lib().mtq_rng_integers(self._h, int(high), int(n), out.ctypes.data))
         return out
 
     def __del__(self):

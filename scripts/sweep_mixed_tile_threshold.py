@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Sweep mixed-tile-threshold over a range of metric thresholds (reference scripts/sweep_mixed_tile_threshold.py).
-Same flags; `--backend hip` added; tensors come from quantization_analysis_amd.model_source (offline).  Under
-torch.distributed.run the matched tensors are sharded over the ranks; every rank writes the CSVs of its tensors."""
+Same flags; `--backend hip` and `--no-plots` added; tensors come from quantization_analysis_amd.model_source (offline).
+Under torch.distributed.run the matched tensors are sharded over the ranks; every rank writes the CSVs and the per-tensor
+plot of its tensors, and the Pareto frontiers are gathered to rank 0 (one gather of small Python objects) for the two
+overlay figures."""
 from __future__ import annotations
 
 import argparse
@@ -18,7 +20,20 @@ sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
 from quantization_analysis_amd.compression_algorithms.mixed_tile_greedy import parse_tile_formats
 from quantization_analysis_amd.compression_algorithms.quantizer import BACKENDS, Quantizer
 from quantization_analysis_amd.model_source import build_model_index, filter_tensor_names, lpt_shards
+from quantization_analysis_amd import plots
 from quantization_analysis_amd.sweep import pareto_frontier, sweep_tensor, write_csv
+
+_LAYER = re.compile(r"(?:^|.*\.)layers\.(\d+)\.(.+)$")
+_EXPERT = re.compile(r"^(.*\bexperts)\.(\d+)\.(.+)$")
+
+
+def split_name(tensor_name: str):
+    """'model.layers.3.mlp.experts.7.up_proj.weight' → (layer 3, group 'mlp.experts.up_proj.weight', expert 7);
+    names without a `layers.N.` part keep layer None (reference :293-310)."""
+    m = _LAYER.match(tensor_name)
+    layer, rest = (int(m.group(1)), m.group(2)) if m else (None, tensor_name)
+    e = _EXPERT.match(rest)
+    return (layer, f"{e.group(1)}.{e.group(3)}", int(e.group(2))) if e else (layer, rest, None)
 
 
 def parse_args(argv=None):
@@ -36,6 +51,7 @@ def parse_args(argv=None):
     p.add_argument("--lowest-metric-val", type=float, default=0.9)
     p.add_argument("--steps", type=int, default=50)
     p.add_argument("--out-dir", default=None)
+    p.add_argument("--no-plots", action="store_true", help="CSV / JSON artifacts only")
     return p.parse_args(argv)
 
 
@@ -86,6 +102,13 @@ def main(argv=None) -> int:
     detail = base_out / "details"
     detail.mkdir(parents=True, exist_ok=True)
     quantizer = Quantizer(args.backend)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl" if args.backend == "hip" else "gloo", **({"device_id": device} if device is not None else {}))
+    lines = []  # (tensor name, frontier points, baseline points) of this rank's tensors
     for i in lpt_shards(selected, index.numel, world)[rank]:
         name = selected[i]
         x = index.load(name, device=device)
@@ -101,10 +124,40 @@ def main(argv=None) -> int:
             "repo_or_url": args.repo_or_url, "tensor_name": name, "revision": args.revision, "backend": args.backend,
             "formats": formats, "metric": args.metric, "lowest_metric_val": args.lowest_metric_val, "steps": args.steps}, indent=2))
         write_csv(out / "sweep_results.csv", rows, formats)
-        mixed = [{"label": f"t{r['step']}", "size": r["size_bytes"], "metric": r[args.metric], "kind": "mixed"} for r in rows]
+        mixed = [{"label": f"t{r['step']}", "size": r["size_bytes"], "metric": r[args.metric], "kind": "mixed",
+                  **{f"{f}_tiles": r.get(f"{f}_tiles", 0) for f in formats}} for r in rows]
         front = pareto_frontier(baselines + mixed, args.metric)
         (out / "pareto.json").write_text(json.dumps([{k: p[k] for k in ("label", "size", "metric", "kind")} for p in front], indent=1))
+        if not args.no_plots:
+            plots.write_sweep_pareto(out / "size_vs_metric.png", args.metric, front, formats, name)
+        lines.append((name, front, baselines))
         print(f"[rank {rank}] {name}: {len(rows)} steps, pareto {len(front)} points -> {out}")
+
+    if dist is not None:  # frontiers are a few KB per tensor
+        box = [None] * world if rank == 0 else None
+        dist.gather_object(lines, box, dst=0)
+        if rank == 0:
+            lines = [entry for part in box for entry in part]
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0 and not args.no_plots:
+        by_weight, by_layer, base_weight, base_layer = {}, {}, {}, {}
+        for name, front, baselines in sorted(lines, key=lambda e: e[0]):
+            layer, group, expert = split_name(name)
+            entry = {"layer_id": layer, "expert_id": expert, "weight_name": group}
+            if front:
+                by_weight.setdefault(group, []).append(dict(entry, points=front))
+                if layer is not None:
+                    by_layer.setdefault(layer, []).append(dict(entry, points=front))
+            if baselines:
+                base_weight.setdefault(group, []).append(dict(entry, points=baselines))
+                if layer is not None:
+                    base_layer.setdefault(layer, []).append(dict(entry, points=baselines))
+        floor = args.lowest_metric_val if args.metric == "pcc" else None
+        plots.write_overlays(base_out / "weight_overlays.png", args.metric, by_weight, base_weight, "weight", floor)
+        plots.write_overlays(base_out / "layer_overlays.png", args.metric, by_layer, base_layer, "layer", floor)
+    if rank == 0:
+        print(f"Wrote sweep results to {base_out}")
     return 0
 
 

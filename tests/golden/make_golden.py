@@ -265,6 +265,44 @@ def main() -> None:
     np.savez_compressed(OUT / "f6_sweep.npz", **f6)
 
 
+    # ---------------------------------------------------------------- F10: random search (mixed_tile_random.py)
+    random_cases = [
+        # name, kind, seed, shape, formats, metric, thr, iters, algo seed.  Thresholds sit inside the spread of the
+        # samples' scores so that both branches (:160-167 smallest passing map, :168-172 best failing map) are taken.
+        ("r_pcc_256_bf16", "normal_bf16", 71, (256, 256), ALL, "pcc", 0.9705, 12, 0),
+        # knife edge: the threshold IS sample score #5 of the case above (float32 value as a Python float), and that + 1e-9
+        ("r_pcc_knife_eq", "normal_bf16", 71, (256, 256), ALL, "pcc", 0.9704277515411377, 12, 0),
+        ("r_pcc_knife_eps", "normal_bf16", 71, (256, 256), ALL, "pcc", 0.9704277515411377 + 1e-9, 12, 0),
+        ("r_pcc_none_pass", "normal_bf16", 72, (128, 192), ALL, "pcc", 0.9999, 10, 3),
+        ("r_pcc_heavy_160x96", "heavy_f32", 73, (160, 96), ALL, "pcc", 0.9885, 16, 5),
+        ("r_mae_130x200", "normal_f32", 74, (130, 200), ALL, "mae", 2.2e-3, 12, 7),
+        ("r_atol_50x70", "heavy_f32", 75, (50, 70), ALL, "atol", 0.2, 10, 11),
+        ("r_pcc_subset", "normal_bf16", 76, (96, 128), ["bfp4", "bfp8"], "pcc", 0.9972, 14, 13),
+        ("r_pcc_single", "normal_bf16", 77, (64, 64), ["bfp4"], "pcc", 0.99, 3, 17),
+        ("r_pcc_vec1003", "normal_f32", 78, (1003,), ALL, "pcc", 0.96, 9, 19),
+        ("r_mae_3x40x48", "heavy_bf16", 79, (3, 40, 48), ["bf16", "bfp8", "bfp2"], "mae", 6e-3, 8, 23),
+    ]
+    f10 = {}
+    f10_meta = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        for name, kind, seed, shape, fmts, metric, thr, iters, aseed in random_cases:
+            xi = gen(kind, seed, shape)
+            algo = create_algorithm("mixed-tile-random", {"metric": metric, "threshold": thr, "seed": aseed, "iters": iters, "formats": fmts})
+            res = algo.run(xi, fmts, q, cache_ctx(tmp))[0]
+            y = res.y
+            diff = np.abs(xi - y)
+            smp = res.meta["samples"]
+            f10[f"{name}_x"] = xi
+            f10[f"{name}_assign"] = res.meta["assignment"].astype(np.int8)
+            f10[f"{name}_counts"] = np.array([res.tile_counts[f] for f in ALL], dtype=np.int64)
+            f10[f"{name}_cols"] = np.array([pearson_corr(xi, y), float(np.mean(diff)), float(np.max(diff)), res.tile_bytes], dtype=np.float64)
+            f10[f"{name}_y"] = y.astype(np.float32)
+            f10[f"{name}_samples"] = np.array([[s_["id"], s_["total_bytes"], s_["pcc"], s_["mae"], s_["atol"], *[s_["counts"][f] for f in ALL]]
+                                               for s_ in smp], dtype=np.float64)
+            f10_meta[name] = {"formats": fmts, "metric": metric, "threshold": thr, "iters": iters, "algo_seed": aseed}
+    np.savez_compressed(OUT / "f10_random.npz", **f10)
+    meta["f10"] = f10_meta
+
     # ---------------------------------------------------------------- F9: fp8 x scale_inv block dequantisation (loader)
     import torch
     from hf_model_utils import _dequantize_tensor_with_scale_inv
@@ -290,6 +328,8 @@ def main() -> None:
         "perm_5_subset": np.random.default_rng(5).permutation(np.array([3, 9, 10, 40, 41, 77, 100], dtype=np.int64)),
         "total_bytes_check": np.array([mixed_tile_total_bytes({"bf16": 0, "bfp8": 0, "bfp4": 128088, "bfp2": 936})]),
         "nep50_f32_ge": np.array([bool(np.float32(0.94) >= 0.94), bool(np.float32(0.999) >= 0.999)]),
+        "integers_7_4_head": np.random.default_rng(7).integers(0, 4, size=64, dtype=np.int64),
+        "integers_7_3_after_perm": (lambda g: (g.permutation(10), g.integers(0, 3, size=40, dtype=np.int64))[1])(np.random.default_rng(7)),
     }
     np.savez_compressed(OUT / "f8_misc.npz", **f8)
 

@@ -34,7 +34,7 @@ def load_meta(golden_dir):
 # ------------------------------------------------------------------------------------------ CPU
 
 def test_registry_and_errors():
-    assert set(ALGORITHM_REGISTRY) == {"none", "mixed-tile-greedy", "mixed-tile-threshold", "mixed-tile"}
+    assert set(ALGORITHM_REGISTRY) == {"none", "mixed-tile-greedy", "mixed-tile-threshold", "mixed-tile", "mixed-tile-random"}
     assert ALGORITHM_REGISTRY["mixed-tile"] is ALGORITHM_REGISTRY["mixed-tile-greedy"]
     with pytest.raises(ValueError, match="Unsupported compression algorithm"):
         create_algorithm("nope")
@@ -130,6 +130,42 @@ def _run_threshold_cases(golden_dir, quantizer, to_input=lambda x: x):
     assert knife >= 2
 
 
+def _run_random_cases(golden_dir, quantizer, to_input=lambda x: x):
+    d = np.load(golden_dir / "f10_random.npz")
+    rescored = 0
+    for name, m in load_meta(golden_dir)["f10"].items():
+        x = d[f"{name}_x"]
+        algo = create_algorithm("mixed-tile-random", {"metric": m["metric"], "threshold": m["threshold"], "seed": m["algo_seed"],
+                                                      "iters": m["iters"], "formats": m["formats"]})
+        assert algo.expected_evals(ALL) == 1
+        r = algo.run(to_input(x), m["formats"], quantizer, ctx(quantizer.backend))[0]
+        assert r.fmt == "MIXED" and r.compression == "mixed-tile-random" and r.meta["tile_formats"] == m["formats"]
+        a = r.meta["assignment"]
+        assert a.dtype == np.int8 and np.array_equal(a, d[f"{name}_assign"]), name
+        assert [r.tile_counts[f] for f in ALL] == list(d[f"{name}_counts"]), name
+        y = r.y.cpu().numpy() if hasattr(r.y, "cpu") else r.y
+        assert y.shape == x.shape and np.array_equal(y.view(np.uint32), d[f"{name}_y"].view(np.uint32)), name
+        cols = d[f"{name}_cols"]
+        assert r.tile_bytes == cols[3]
+        want = d[f"{name}_samples"]
+        got = np.array([[s["id"], s["total_bytes"], s["pcc"], s["mae"], s["atol"], *[s["counts"][f] for f in ALL]] for s in r.meta["samples"]])
+        assert np.array_equal(got[:, [0, 1, 5, 6, 7, 8]], want[:, [0, 1, 5, 6, 7, 8]]), name  # ids, bytes, counts: exact
+        # sample columns come from the float64 raw sums; the reference's are float32 two-pass values: tolerance 1e-6
+        assert np.max(np.abs(got[:, 2:5] - want[:, 2:5])) <= 1e-6, (name, np.max(np.abs(got[:, 2:5] - want[:, 2:5]), axis=0))
+        rescored += r.meta["literal_rescored_samples"]
+    assert rescored >= 2  # the two knife-edge cases went through the literal float32 expression
+
+
+def test_random_emulation_backend(golden_dir):
+    _run_random_cases(golden_dir, Quantizer("emulation"))
+    with pytest.raises(ValueError, match="iters must be >= 1"):
+        create_algorithm("mixed-tile-random", {"iters": 0})
+    with pytest.raises(ValueError, match="requires at least one of"):
+        create_algorithm("mixed-tile-random").run(np.ones((4, 4), np.float32), ["fp0"], Quantizer("emulation"), ctx())
+    r = create_algorithm("mixed-tile-random").run(np.zeros((0, 8), np.float32), ALL, Quantizer("emulation"), ctx())[0]
+    assert r.meta["samples"] == [] and r.meta["assignment"].shape == (1, 1) and r.tile_bytes == 0.0
+
+
 def test_greedy_emulation_backend(golden_dir):
     _run_greedy_cases(golden_dir, Quantizer("emulation"))
 
@@ -189,6 +225,14 @@ def test_config_loader(tmp_path):
 @pytest.mark.gpu
 def test_greedy_hip_backend_numpy_in(golden_dir):
     _run_greedy_cases(golden_dir, Quantizer("hip"))
+
+
+@pytest.mark.gpu
+def test_random_hip_backend(golden_dir):
+    import torch
+
+    _run_random_cases(golden_dir, Quantizer("hip"))
+    _run_random_cases(golden_dir, Quantizer("hip"), to_input=lambda x: torch.from_numpy(x).cuda())
 
 
 @pytest.mark.gpu

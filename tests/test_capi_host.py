@@ -130,6 +130,26 @@ def test_numpy_compatible_rng():
     assert np.array_equal(np.random.default_rng(9).permutation(c), c[hb.NumpyCompatRng(9).permutation(c.size)])
 
 
+def test_numpy_compatible_rng_integers(golden_dir):
+    """mtq_rng_integers ≡ Generator.integers(0, high, size=n, dtype=int64) (the random search's draws,
+    mixed_tile_random.py:135), also interleaved with permutation calls on the same generator."""
+    d = np.load(golden_dir / "f8_misc.npz")
+    assert np.array_equal(hb.NumpyCompatRng(7).integers(4, 64), d["integers_7_4_head"])
+    r = hb.NumpyCompatRng(7)
+    r.permutation(10)
+    assert np.array_equal(r.integers(3, 40), d["integers_7_3_after_perm"])
+    for seed in (0, 1, 123, 2**31 - 1, 2**40 + 7):
+        for high in (1, 2, 3, 4, 5, 7, 100, 2**31 + 3, 2**32 - 2):
+            mine, ref = hb.NumpyCompatRng(seed), np.random.default_rng(seed)
+            for n in (0, 1, 7, 4097):
+                assert np.array_equal(mine.integers(high, n), ref.integers(0, high, size=n, dtype=np.int64)), (seed, high, n)
+                assert np.array_equal(mine.permutation(33), ref.permutation(33)), (seed, high, n)
+    with pytest.raises(hb.MtqError):
+        hb.NumpyCompatRng(1).integers(0, 4)
+    with pytest.raises(hb.MtqError):
+        hb.NumpyCompatRng(1).integers(2**32, 4)
+
+
 def test_greedy_run_equals_numpy_driven_scan(golden_dir):
     d = np.load(golden_dir / "f4_greedy.npz")
     meta = json.loads((golden_dir / "golden_meta.json").read_text())["f4"]

@@ -86,8 +86,43 @@ def test_wq_emulation_single_process(tmp_path, monkeypatch):
     check_maps_against_oracle(rdir, "mixed_tile_greedy", names, idx, lambda x: orc.greedy(x, ALL, "pcc", 0.999, 123)[0])
     table = (rdir / "table.txt").read_text()
     assert "Summary (mean across matched tensors)" in table and table.count("mixed-tile-greedy  MIXED") == len(names)
+    # PNG artifacts next to every map (wq:282, :412)
+    for name in names:
+        d = rdir / "mixed_tile_greedy" / cli._slug(name)
+        for png in (d / f"{cli._slug(name)}_assignment.png", d / "size_vs_accuracy.png"):
+            assert png.read_bytes()[:8] == b"\x89PNG\r\n\x1a\n", png
     # no match → exit code 1 (wq:599-601); unknown source → error
     assert cli.run(["synthetic:tiny", "zzz", "--results-dir", str(tmp_path / "r2")]) == 1
+
+
+def test_wq_random_search_artifacts(tmp_path, monkeypatch):
+    """mixed-tile-random through the CLI: table row, per-tensor CSV of the samples, the selected map and its mapping
+    (wq:151-218); the map is the oracle's (i.e. the reference's) map for the same seed."""
+    monkeypatch.chdir(tmp_path)
+    cfg = write_cfg(tmp_path, algo="mixed-tile-random", seed=5, params={"metric": "pcc", "threshold": 0.97, "iters": 6})
+    assert cli.run(["synthetic:tiny", "model.layers.1", "--compression-config", cfg, "--results-dir", str(tmp_path / "results")]) == 0
+    rdir = run_dir(tmp_path / "results")
+    assert rdir.parent.name == "mixed-tile-random"
+    idx = model_source.build_model_index("synthetic:tiny")
+    table = (rdir / "table.txt").read_text()
+    for name in ("model.layers.1.attn.q.weight", "model.layers.1.mlp.up.weight"):
+        x = idx.load(name).float().numpy()
+        want, _counts, samples = orc.random_search(x, ALL, "pcc", 0.97, 6, 5)
+        slug = cli._slug(name)
+        d = rdir / "mixed_tile_random"
+        assert np.array_equal(np.load(d / f"{slug}_assignment.npy"), want), name
+        assert json.loads((d / f"{slug}_assignment_mapping.json").read_text())["assignment_shape"] == list(want.shape)
+        rows = (d / f"{slug}.csv").read_text().splitlines()
+        assert rows[0] == "sample_id,bf16_tiles,bfp8_tiles,bfp4_tiles,bfp2_tiles,total_gb,pcc,mae,atol" and len(rows) == 7
+        for line, s in zip(rows[1:], samples):
+            f = line.split(",")
+            assert [int(v) for v in f[:5]] == [s["id"], *[s["counts"][k] for k in ALL]]
+            assert abs(float(f[6]) - s["pcc"]) <= 1e-6 and abs(float(f[7]) - s["mae"]) <= 1e-6 and abs(float(f[8]) - s["atol"]) <= 1e-6
+        assert (d / f"{slug}.png").read_bytes()[:4] == b"\x89PNG"
+    assert table.count("mixed-tile-random  MIXED") == 2 and "BYTES" in table
+    # --no-plots: every non-image artifact, no PNG
+    assert cli.run(["synthetic:tiny", "model.layers.1", "--compression-config", cfg, "--results-dir", str(tmp_path / "r3"), "--no-plots"]) == 0
+    assert not list((tmp_path / "r3").rglob("*.png")) and len(list((tmp_path / "r3").rglob("*.csv"))) == 2
 
 
 def test_wq_random_seed_is_recorded(tmp_path, monkeypatch):

@@ -136,6 +136,29 @@ def test_f5_moment_scores_close_to_float32_scores(golden_dir, meta):
             assert np.max(np.abs(got - want)) <= 1e-6, (name, fmt, np.max(np.abs(got - want)))
 
 
+def test_f10_random_search_maps(golden_dir, meta):
+    """mixed_tile_random.py: the oracle's literal restatement reproduces the reference's selected map, counts and
+    every sample's float32 pcc/mae/atol exactly (same NumPy Generator, same float32 expressions)."""
+    d = np.load(golden_dir / "f10_random.npz")
+    assert len(meta["f10"]) == 11
+    branches = set()
+    for name, m in meta["f10"].items():
+        x = d[f"{name}_x"]
+        assign, counts, samples = orc.random_search(x, m["formats"], m["metric"], m["threshold"], m["iters"], m["algo_seed"])
+        assert np.array_equal(assign, d[f"{name}_assign"]), name
+        assert [counts[f] for f in ALL] == list(d[f"{name}_counts"]), name
+        rows = np.array([[s["id"], s["total_bytes"], s["pcc"], s["mae"], s["atol"], *[s["counts"][f] for f in ALL]] for s in samples])
+        assert np.array_equal(rows, d[f"{name}_samples"]), name
+        y = orc.apply_assignment(x, assign)
+        assert np.array_equal(y.view(np.uint32), d[f"{name}_y"].view(np.uint32)), name
+        col = rows[:, {"pcc": 2, "mae": 3, "atol": 4}[m["metric"]]]
+        ok = col >= m["threshold"] if m["metric"] == "pcc" else col <= m["threshold"]
+        branches.add("none" if not ok.any() else ("all" if ok.all() else "split"))
+    assert branches == {"none", "all", "split"}
+    # the two knife-edge thresholds (a sample's float32 score, and that + 1e-9) select different maps
+    assert not np.array_equal(d["r_pcc_knife_eq_assign"], d["r_pcc_knife_eps_assign"])
+
+
 def test_f8_rng_and_bytes(golden_dir):
     d = np.load(golden_dir / "f8_misc.npz")
     assert np.array_equal(np.random.default_rng(123).permutation(16384)[:32], d["perm_123_16384_head"])
@@ -143,3 +166,4 @@ def test_f8_rng_and_bytes(golden_dir):
     assert orc.mixed_tile_total_bytes({"bf16": 0, "bfp8": 0, "bfp4": 128088, "bfp2": 936}) == d["total_bytes_check"][0]
     assert round(d["total_bytes_check"][0]) == 65948829  # notebooks/wq_mixed_tile_walkthrough.ipynb:438
     assert bool(np.float32(0.94) >= 0.94) == bool(d["nep50_f32_ge"][0])
+    assert np.array_equal(np.random.default_rng(7).integers(0, 4, size=64, dtype=np.int64), d["integers_7_4_head"])

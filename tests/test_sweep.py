@@ -50,6 +50,9 @@ def test_sweep_script_cli(tmp_path):
     assert len(csvs) == 2
     lines = csvs[0].read_text().splitlines()
     assert lines[0] == "step,threshold,size_bytes,pcc,mae,atol,bf16_tiles,bfp8_tiles,bfp4_tiles,bfp2_tiles" and len(lines) == 7
+    pngs = sorted(p.relative_to(out).as_posix() for p in out.rglob("*.png"))  # per-tensor frontier + the two overlays (:796, :818-835)
+    assert len(pngs) == 4 and "weight_overlays.png" in pngs and "layer_overlays.png" in pngs
+    assert sum(p.endswith("size_vs_metric.png") for p in pngs) == 2
     r = subprocess.run([sys.executable, str(ROOT / "scripts" / "sweep_mixed_tile_threshold.py"), "synthetic:tiny", "layers", "--list-matches"],
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "Matched 5 tensor(s)" in r.stdout
