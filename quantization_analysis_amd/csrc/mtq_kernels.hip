@@ -79,10 +79,11 @@ __global__ __launch_bounds__(256) void tile_stats_generic(const T *__restrict__ 
     tile_stats_one<T>(x, gt, stride, rows, cols, ld, tiles_w, tiles, fmt_mask, rec, stats, vec_ok);
 }
 
-// Follow-up of tile_stats_bf16_fast: every wave inspects 64 records, and recomputes by the literal route the
-// tiles whose Σx carries kRedoMagic (groups outside the exact-integer route's preconditions).
+// Follow-up of the exact-route kernels (mtq_fast.hip, mtq_direct.hip): every wave inspects 64 records, and recomputes
+// by the literal route the tiles whose Σx carries kRedoMagic (groups outside the exact routes' preconditions).
 constexpr unsigned long long kRedoMagicGeneric = 0x7FF8C0DE5EED0001ull;
-__global__ __launch_bounds__(256) void tile_stats_redo_flagged(const uint16_t *__restrict__ x, int64_t count, int64_t stride,
+template <typename T>
+__global__ __launch_bounds__(256) void tile_stats_redo_flagged(const T *__restrict__ x, int64_t count, int64_t stride,
                                                                int64_t rows, int64_t cols, int64_t ld, int tiles_w,
                                                                int64_t tiles, uint32_t fmt_mask, int rec,
                                                                double *__restrict__ stats, int vec_ok)
@@ -96,7 +97,7 @@ __global__ __launch_bounds__(256) void tile_stats_redo_flagged(const uint16_t *_
     while (todo) {                                                     // wave-uniform loop over the flagged tiles
         const int k = __builtin_ctzll(todo);
         todo &= todo - 1;
-        tile_stats_one<uint16_t>(x, first + k, stride, rows, cols, ld, tiles_w, tiles, fmt_mask, rec, stats, vec_ok);
+        tile_stats_one<T>(x, first + k, stride, rows, cols, ld, tiles_w, tiles, fmt_mask, rec, stats, vec_ok);
     }
 }
 
@@ -237,6 +238,8 @@ using namespace mtq;
 
 extern "C" int mtq_launch_tile_stats_bf16_fast(const void *x, int64_t count, int64_t stride_elems, int64_t rows, int64_t cols,
                                                int64_t ld, uint32_t fmt_mask, double *stats, void *stream);
+extern "C" int mtq_launch_tile_stats_direct(const void *x, int in_dtype, int64_t count, int64_t stride_elems, int64_t rows, int64_t cols,
+                                            int64_t ld, uint32_t fmt_mask, double *stats, int vec_ok, void *stream);
 
 // MTQ_FORCE_GENERIC=1 routes every input through tile_stats_generic (A/B checks of the fast kernel).
 static bool force_generic()
@@ -265,12 +268,24 @@ extern "C" int mtq_tile_stats_batched(const void *x, int in_dtype, int64_t count
     if (in_dtype == MTQ_DTYPE_BF16 && vec_ok && rows % kTile == 0 && cols % 128 == 0 && (fmt_mask & 0xEu) != 0 && !force_generic()) {
         if (int rc = mtq_launch_tile_stats_bf16_fast(x, count, stride_elems, rows, cols, ld, fmt_mask, stats, stream)) return rc;
         const int64_t waves = (count * tiles + 63) / 64;
-        hipLaunchKernelGGL(tile_stats_redo_flagged, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, static_cast<hipStream_t>(stream),
+        hipLaunchKernelGGL(tile_stats_redo_flagged<uint16_t>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, static_cast<hipStream_t>(stream),
                            static_cast<const uint16_t *>(x), count, stride_elems, rows, cols, ld, (int)tw, tiles, fmt_mask, rec, stats, vec_ok);
         return check_launch("mtq_tile_stats (redo flagged)");
     }
-    const int64_t blocks = (count * tiles + 3) / 4;
     hipStream_t s = static_cast<hipStream_t>(stream);
+    // float32 storage, ragged or unaligned bf16: one wave per tile on the reduced-arithmetic route (mtq_direct.hip)
+    if ((fmt_mask & MTQ_MASK_ALL) != 0 && count * tiles < ((int64_t)1 << 31) && !force_generic()) {
+        if (int rc = mtq_launch_tile_stats_direct(x, in_dtype, count, stride_elems, rows, cols, ld, fmt_mask, stats, vec_ok, stream)) return rc;
+        const dim3 rgrid((unsigned)(((count * tiles + 63) / 64 + 3) / 4));
+        if (in_dtype == MTQ_DTYPE_BF16)
+            hipLaunchKernelGGL(tile_stats_redo_flagged<uint16_t>, rgrid, dim3(256), 0, s, static_cast<const uint16_t *>(x), count, stride_elems,
+                               rows, cols, ld, (int)tw, tiles, fmt_mask, rec, stats, vec_ok);
+        else
+            hipLaunchKernelGGL(tile_stats_redo_flagged<float>, rgrid, dim3(256), 0, s, static_cast<const float *>(x), count, stride_elems, rows,
+                               cols, ld, (int)tw, tiles, fmt_mask, rec, stats, vec_ok);
+        return check_launch("mtq_tile_stats (redo flagged)");
+    }
+    const int64_t blocks = (count * tiles + 3) / 4;
     if (in_dtype == MTQ_DTYPE_BF16)
         hipLaunchKernelGGL(tile_stats_generic<uint16_t>, dim3((unsigned)blocks), dim3(256), 0, s, static_cast<const uint16_t *>(x), count,
                            stride_elems, rows, cols, ld, (int)tw, tiles, fmt_mask, rec, stats, vec_ok);

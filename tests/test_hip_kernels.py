@@ -174,6 +174,70 @@ def test_fast_bf16_kernel_fallback_groups():
     assert np.array_equal(np.where(both_nan, 0, got.view(np.uint64)), np.where(both_nan, 0, want.view(np.uint64)))
 
 
+def _nan_eq(got, want):
+    both_nan = np.isnan(want) & np.isnan(got)
+    return np.array_equal(np.where(both_nan, 0, got.view(np.uint64)), np.where(both_nan, 0, want.view(np.uint64)))
+
+
+def test_direct_kernel_every_mask_and_edge_groups():
+    """mtq_direct.hip (float32 storage; ragged / unaligned bf16): every format subset, tail-class elements, zeros,
+    shared exponents at and beyond the borders of the exact route's range [80,180], specials — all bit-identical to the
+    oracle's literal route, and to the literal GPU kernel where NaN payloads are involved."""
+    rng = np.random.default_rng(11)
+    x = gen("heavy_f32", 7, (70, 200)).copy()           # ragged in both directions: zero pads inside edge tiles
+    x[0, :16] = 0.0                                      # all-zero group inside a live tile
+    x[1, 3] = 0.0
+    x[1, 4] = -0.0
+    x[2, 16:32] *= np.float32(2.0 ** -20)
+    x[3, 5] = np.float32(2.0 ** -40)                     # 16+ binades below its group's maximum: tail class
+    x[3, 6] = np.float32(-(2.0 ** -30))
+    x[4, 32:48] = (rng.standard_normal(16) * 2.0 ** -15).astype(np.float32) * x[4, 32]   # d around the 14/15 class border
+    x[5, :16] = np.float32(1e-40)                        # denormals only (E = 0, non-zero): literal redo
+    x[6, 7] = np.inf
+    x[7, 9] = np.nan
+    x[8, :16] = np.float32(3.0e38)
+    for r, e in ((9, 79), (10, 80), (11, 180), (12, 181)):  # borders of the exact route
+        x[r, 48:64] = (1.0 + rng.random(16)).astype(np.float32) * np.float32(2.0 ** (e - 127)) * np.where(rng.random(16) < 0.5, -1, 1)
+    x[13, 64:80] = np.ldexp(np.float32(1.0), -np.arange(16, dtype=np.int32) * 2).astype(np.float32)  # one value per 2 binades
+    x[14, 64:80] = np.float32(1.9999999)                 # saturating round-up in every format
+    x[40:64, 128:160] = 0.0                              # an all-zero tile
+    for fm_bits in range(1, 16):
+        fm = [f for i, f in enumerate(ALL) if fm_bits >> i & 1]
+        with np.errstate(all="ignore"):
+            want = orc.tile_stats(x, fm)
+        got = hb.tile_stats(dev(x), fm_bits).cpu().numpy()
+        assert _nan_eq(got, want), fm
+    # unaligned rows (ld not a multiple of 4 elements) and a column offset: scalar loads, same records
+    big = torch.zeros((70, 203), dtype=torch.float32, device="cuda")
+    big[:, 3:] = dev(x)
+    with np.errstate(all="ignore"):
+        assert _nan_eq(hb.tile_stats(big[:, 3:], 0xF).cpu().numpy(), orc.tile_stats(x, ALL))
+    # bf16 STORAGE on the same route (ragged shape → not the LDS-staged kernel)
+    xb = torch.from_numpy(x).to(torch.bfloat16)
+    x16 = xb.float().numpy()
+    for fm_bits in (0xF, 0x1, 0x6, 0x9):
+        fm = [f for i, f in enumerate(ALL) if fm_bits >> i & 1]
+        with np.errstate(all="ignore"):
+            want = orc.tile_stats(x16, fm)
+        assert _nan_eq(hb.tile_stats(xb.cuda(), fm_bits).cpu().numpy(), want), fm
+
+
+def test_direct_kernel_mid_size_f32_and_batched():
+    """gpt2-like (768x2304) and DeepSeek-like (fp8 values x block scales) float32 tensors, plus a batched launch."""
+    x = gen("normal_f32", 21, (768, 2304))
+    assert np.array_equal(hb.tile_stats(dev(x), 0xF).cpu().numpy().view(np.uint64), orc.tile_stats(x, ALL).view(np.uint64))
+    rng = np.random.default_rng(5)
+    m, e = np.frexp(rng.standard_normal((512, 640)))
+    base = np.ldexp(np.round(m * 16) / 16, e)
+    sc = np.exp(rng.standard_normal((4, 5))) * 0.01
+    y = (base * np.repeat(np.repeat(sc, 128, 0), 128, 1)).astype(np.float32)
+    assert np.array_equal(hb.tile_stats(dev(y), 0xE).cpu().numpy().view(np.uint64), orc.tile_stats(y, ["bfp8", "bfp4", "bfp2"]).view(np.uint64))
+    xs = np.stack([gen("heavy_f32", s, (96, 160)) for s in range(5)])
+    got = hb.tile_stats_batched(dev(xs), 0xF).cpu().numpy()
+    for i in range(5):
+        assert np.array_equal(got[i].view(np.uint64), orc.tile_stats(xs[i], ALL).view(np.uint64)), i
+
+
 def test_fast_and_generic_kernels_agree_batched():
     xs = np.stack([gen("normal_bf16", s, (64, 256)) for s in range(6)])
     got = hb.tile_stats_batched(dev(xs, bf16=True), 0xF).cpu().numpy()
