@@ -188,14 +188,21 @@ __device__ __forceinline__ void direct_group(const uint32_t (&u)[kGroup], double
 template <typename T, uint32_t FM>
 __global__ __launch_bounds__(kDirectWaves * 64, MTQ_DIRECT_WAVES_PER_SIMD) void tile_stats_direct(
     const T *__restrict__ x, int64_t stride, int64_t rows, int64_t cols, int64_t ld, uint32_t tiles_w, uint32_t tiles,
-    uint32_t total_tiles, double *__restrict__ stats, int vec_ok)
+    uint32_t total_tiles, double *__restrict__ stats, int vec_ok, unsigned *__restrict__ work)
 {
     constexpr int nf = popc4(FM), nsum = 2 + 4 * nf, pad = direct_pad(FM), rec = 2 + 5 * nf;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     double *part = reinterpret_cast<double *>(lds) + wave * (64 * pad);          // [64 groups][pad]
-    const uint32_t wave_global = blockIdx.x * kDirectWaves + wave, wave_count = gridDim.x * kDirectWaves;
+    const uint32_t groups = min(gridDim.x, (unsigned)kWorkGroups), group = blockIdx.x % groups;
+    unsigned *queue = work + group * kWorkStride;                        // tiles come from per-group device counters (see mtq_fast.hip)
+    auto claim = [&]() -> uint32_t {
+        unsigned v = 0u;
+        if (lane == 0) v = __hip_atomic_fetch_add(queue, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned k = (unsigned)__builtin_amdgcn_readfirstlane(v);
+        return k < 0x02000000u ? group + k * groups : 0xFFFFFFFFu;
+    };
 
     auto fetch = [&](uint32_t gt, uint32_t (&u)[kGroup]) {
         const uint32_t b = gt / tiles, t = gt - b * tiles;
@@ -204,14 +211,15 @@ __global__ __launch_bounds__(kDirectWaves * 64, MTQ_DIRECT_WAVES_PER_SIMD) void 
                          cols, ld, vec_ok != 0, u);
     };
 
-    uint32_t gt = wave_global;
+    uint32_t gt = claim();
     uint32_t nxt[kGroup];
     if (gt < total_tiles) fetch(gt, nxt);
-    for (; gt < total_tiles; gt += wave_count) {
+    while (gt < total_tiles) {
         uint32_t u[kGroup];
 #pragma unroll
         for (int i = 0; i < kGroup; ++i) u[i] = nxt[i];
-        if (gt + wave_count < total_tiles) fetch(gt + wave_count, nxt);         // in flight while this tile is processed
+        const uint32_t gt_next = claim();
+        if (gt_next < total_tiles) fetch(gt_next, nxt);                         // in flight while this tile is processed
 
         double s[kMaxSums];
         float mx[kNumFmt];
@@ -252,17 +260,18 @@ __global__ __launch_bounds__(kDirectWaves * 64, MTQ_DIRECT_WAVES_PER_SIMD) void 
             for (int j = 1; j < nf; ++j) v = (lane - 32 == j) ? mx[j] : v;
             out[2 + 5 * (lane - 32) + 4] = (double)v;
         }
+        gt = gt_next;
     }
 }
 
 template <typename T>
 static void launch_direct(uint32_t fm, dim3 grid, hipStream_t st, const T *x, int64_t stride, int64_t rows, int64_t cols, int64_t ld,
-                          uint32_t tiles_w, uint32_t tiles, uint32_t total, double *stats, int vec_ok)
+                          uint32_t tiles_w, uint32_t tiles, uint32_t total, double *stats, int vec_ok, unsigned *work)
 {
     const dim3 block(kDirectWaves * 64);
 #define MTQ_LAUNCH_DIRECT(M) \
     case M: hipLaunchKernelGGL((tile_stats_direct<T, M>), grid, block, (size_t)kDirectWaves * 64 * direct_pad(M) * sizeof(double), st, x, \
-                               stride, rows, cols, ld, tiles_w, tiles, total, stats, vec_ok); break;
+                               stride, rows, cols, ld, tiles_w, tiles, total, stats, vec_ok, work); break;
     switch (fm) { // one instantiation per requested format subset: unrequested formats cost nothing
         MTQ_LAUNCH_DIRECT(1u) MTQ_LAUNCH_DIRECT(2u) MTQ_LAUNCH_DIRECT(3u) MTQ_LAUNCH_DIRECT(4u) MTQ_LAUNCH_DIRECT(5u)
         MTQ_LAUNCH_DIRECT(6u) MTQ_LAUNCH_DIRECT(7u) MTQ_LAUNCH_DIRECT(8u) MTQ_LAUNCH_DIRECT(9u) MTQ_LAUNCH_DIRECT(10u)
@@ -279,7 +288,7 @@ using namespace mtq;
 // Launcher used by mtq_tile_stats_batched for every input the bf16 LDS-staged kernel does not take (mtq_kernels.hip
 // decides and follows up with tile_stats_redo_flagged).  fmt_mask != 0, count * tiles < 2^31.
 extern "C" int mtq_launch_tile_stats_direct(const void *x, int in_dtype, int64_t count, int64_t stride_elems, int64_t rows, int64_t cols,
-                                            int64_t ld, uint32_t fmt_mask, double *stats, int vec_ok, void *stream)
+                                            int64_t ld, uint32_t fmt_mask, double *stats, int vec_ok, void *stream, unsigned **work_out)
 {
     const int64_t th = (rows + kTile - 1) / kTile, tw = (cols + kTile - 1) / kTile, tiles = th * tw, total = count * tiles;
     if (total >= ((int64_t)1 << 31) || (fmt_mask & MTQ_MASK_ALL) == 0) return fail(MTQ_ERR_INVALID, "direct tile_stats launch out of range");
@@ -294,11 +303,14 @@ extern "C" int mtq_launch_tile_stats_direct(const void *x, int in_dtype, int64_t
     const int64_t max_blocks = (int64_t)cus * MTQ_DIRECT_WAVES_PER_SIMD;   // blocks of 4 waves: one wave of each per SIMD
     const dim3 grid((unsigned)(need < max_blocks ? need : max_blocks));
     hipStream_t st = static_cast<hipStream_t>(stream);
+    unsigned *work = work_counter_slot();
+    if (!work) return fail(MTQ_ERR_HIP, "could not allocate the work counters");
+    *work_out = work;
     if (in_dtype == MTQ_DTYPE_BF16)
         launch_direct<uint16_t>(fmt_mask & MTQ_MASK_ALL, grid, st, static_cast<const uint16_t *>(x), stride_elems, rows, cols, ld, (uint32_t)tw,
-                                (uint32_t)tiles, (uint32_t)total, stats, vec_ok);
+                                (uint32_t)tiles, (uint32_t)total, stats, vec_ok, work);
     else
         launch_direct<float>(fmt_mask & MTQ_MASK_ALL, grid, st, static_cast<const float *>(x), stride_elems, rows, cols, ld, (uint32_t)tw,
-                             (uint32_t)tiles, (uint32_t)total, stats, vec_ok);
+                             (uint32_t)tiles, (uint32_t)total, stats, vec_ok, work);
     return check_launch("mtq_tile_stats (direct)");
 }

@@ -13,8 +13,9 @@
 // An exact integer times a power of two is exactly the float64 the literal route (sequential float64 sum
 // of the float32 terms) produces for the main class, so the records are bit-identical to tile_stats_generic
 // and the oracle.  Tail-class values (d ≥ 15; rare) are added in a short divergent loop.  A group whose E is
-// outside [80,180] (float32 products could under/overflow; also all-zero, Inf/NaN groups) marks its tile; marked
+// outside [80,180] (float32 products could under/overflow; also denormal-only, Inf/NaN groups) marks its tile; marked
 // tiles are recomputed by the literal route in a follow-up launch (tile_stats_redo_flagged, mtq_kernels.hip).
+// An all-zero group marks nothing: it contributes ±0.0 to every sum.
 //
 // Mapping: a wave owns a 32-row × 128-column unit (4 tiles, 8 KiB).  8 LDS-DMA instructions
 // (global_load_lds_dwordx4, 1 KiB each, 256-B contiguous row segments) fill a wave-private LDS image;
@@ -153,15 +154,19 @@ __device__ __forceinline__ void fast_group(const uint32_t w[8], GroupOut &G, Rel
         if constexpr (BFP & 2u) fmt_step<Fmt4>(a, abias, sgn, A4);
         if constexpr (BFP & 4u) fmt_step<Fmt2>(a, abias, sgn, A2);
     }
-    // exact route needs every float32 term normal and finite: E in [80, 180]; anything else marks the tile
-    G.bad = !((E >= 80u) & (E <= 180u));
+    // exact route needs every float32 term normal and finite: E in [80, 180]; anything else marks the tile — except an
+    // all-zero group (pruned weights, padding), which contributes nothing: its (garbage) integers are scaled by
+    // 2^−3000 → ±0.0, and adding ±0.0 changes no accumulator.
+    const bool zero_group = mxp == 0u;
+    G.bad = !((E >= 80u) & (E <= 180u)) && !zero_group;
     const uint32_t bmax = max(bmaxp & 0xFFFFu, bmaxp >> 16);
-    const int e1 = (int)E - 148, e2 = 2 * (int)E - 296;         // 2^(E−148), 2^(2E−296)
+    const int Ei = zero_group ? -3000 : (int)E;
+    const int e1 = Ei - 148, e2 = 2 * Ei - 296;                 // 2^(E−148), 2^(2E−296)
     G.term[0] = __builtin_ldexp((double)(sxa * 128 + sxb), e1);
     // Σa² without 64-bit accumulation: a = y8 + δ8 with y8 = 256·q8, so Σa² = 512·Σa·q8 − 65536·Σq8² + Σδ8² (all exact in float64)
     const double a2 = __builtin_fma(512.0, (double)A8.saq, __builtin_fma(-65536.0, (double)A8.sq2, (double)A8.sd2)); // < 2^35
     G.term[1] = __builtin_ldexp(__builtin_fma(a2, 16384.0, (double)sb2), e2);                  // exact (< 2^49)
-    const float sf = __uint_as_float(((E - 21u) & 0xFFu) << 23); // 2^(E−148) as float32 (masked: garbage-safe when bad)
+    const float sf = zero_group ? 0.0f : __uint_as_float(((E - 21u) & 0xFFu) << 23); // 2^(E−148) as float32 (masked: garbage-safe when bad)
     const FmtAcc *A[3] = {&A8, &A4, &A2};
     const int mbs[3] = {7, 3, 1};
 #pragma unroll
@@ -173,8 +178,8 @@ __device__ __forceinline__ void fast_group(const uint32_t w[8], GroupOut &G, Rel
         }
         G.term[2 + 4 * f] = __builtin_ldexp((double)A[f]->ssy, e1 + 7);                       // Σ±y · 2^(E−141)
         const uint32_t sq2 = f == 2 ? (A[f]->sq2 & 0xFFFFu) + (A[f]->sq2 >> 16) : A[f]->sq2;
-        G.term[3 + 4 * f] = __builtin_ldexp((double)sq2, 2 * ((int)E - 126 - mbs[f]));        // Σq² · 2^(2(E−126−mb))
-        G.term[4 + 4 * f] = __builtin_ldexp((double)A[f]->saq, 2 * (int)E - 267 - mbs[f]);    // Σa·q · 2^(2E−267−mb)
+        G.term[3 + 4 * f] = __builtin_ldexp((double)sq2, 2 * (Ei - 126 - mbs[f]));            // Σq² · 2^(2(E−126−mb))
+        G.term[4 + 4 * f] = __builtin_ldexp((double)A[f]->saq, 2 * Ei - 267 - mbs[f]);        // Σa·q · 2^(2E−267−mb)
         G.term[5 + 4 * f] = __builtin_ldexp((double)((A[f]->sad << 7) + sbs), e1);            // (128·Σ|a−y| + Σb) · 2^(E−148)
         G.mx[f] = (float)max(fmt_maxabs(*A[f]) << 7, bmax) * sf; // integer < 2^23: exact
     }
@@ -224,7 +229,7 @@ __device__ __forceinline__ void glds16(const void *sbase, uint32_t voff, uint32_
 template <uint32_t BFP>
 __global__ __launch_bounds__(kFastWaves * 64, MTQ_ROLLED_WAVES_PER_SIMD) void tile_stats_bf16_rolled(
     const uint16_t *__restrict__ x, int64_t stride, int64_t ld, int tiles_w, int64_t tiles, int units_w, int units_per_tensor,
-    int total_units, uint32_t fmt_mask, int rec, double *__restrict__ stats)
+    int total_units, uint32_t fmt_mask, int rec, double *__restrict__ stats, unsigned *__restrict__ work)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int lane = threadIdx.x & 63;
@@ -245,8 +250,19 @@ __global__ __launch_bounds__(kFastWaves * 64, MTQ_ROLLED_WAVES_PER_SIMD) void ti
     const uint32_t rd_base = (j >> 1) * 1024u + (2u * (j & 1u)) * 256u;
     const uint32_t c0 = (4u * t) ^ swz(j);                                    // chunk (4t+kl)^swz(j) = c0 ^ kl
 
-    const int wave_global = (int)blockIdx.x * kFastWaves + wave;
-    const int wave_count = (int)gridDim.x * kFastWaves;
+    // Units are claimed from a device counter (zero at launch, reset by the follow-up kernel) rather than by a fixed
+    // stride: when other work (a copy kernel, a profiler's blit) keeps part of the persistent grid from being resident,
+    // the resident waves take the whole queue instead of the launch waiting for the late blocks' fixed shares.
+    // One counter per group of blocks (kWorkGroups counters on separate 128-B lines; ≈ 12 ns per same-address atomic on
+    // MI355X, so a single queue would serialise the launch): group g of G = min(blocks, kWorkGroups) owns units g, g + G, …
+    const int groups = (int)min(gridDim.x, (unsigned)kWorkGroups), group = (int)(blockIdx.x % (unsigned)groups);
+    unsigned *queue = work + group * kWorkStride;
+    auto claim = [&]() -> int {
+        unsigned v = 0u;
+        if (lane == 0) v = __hip_atomic_fetch_add(queue, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned k = (unsigned)__builtin_amdgcn_readfirstlane(v);
+        return k < 0x01000000u ? group + (int)k * groups : 0x7FFFFFFF;
+    };
     const int o_bf16 = 2, o8 = 2 + 5 * __builtin_popcount(fmt_mask & 1u), o4 = 2 + 5 * __builtin_popcount(fmt_mask & 3u),
               o2 = 2 + 5 * __builtin_popcount(fmt_mask & 7u);
 
@@ -264,10 +280,11 @@ __global__ __launch_bounds__(kFastWaves * 64, MTQ_ROLLED_WAVES_PER_SIMD) void ti
         for (int i = 0; i < 8; ++i) glds16(base, dma_off[i], in_addr + i * 1024);
     };
 
-    int u = wave_global;
+    int u = claim();
     if (u < total_units) issue_dma(u);
-    for (; u < total_units; u += wave_count) {
+    while (u < total_units) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                     // image landed (and the previous records retired)
+        const int u_next = claim();                                           // its latency hides behind this unit's arithmetic
 
         double acc[kSums];
 #pragma unroll
@@ -353,9 +370,10 @@ __global__ __launch_bounds__(kFastWaves * 64, MTQ_ROLLED_WAVES_PER_SIMD) void ti
         if (lane < nrec) r0 = recbuf[lane];
         if (lane + 64 < nrec) r1 = recbuf[lane + 64];
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                   // records are in registers: the image may be refilled
-        if (u + wave_count < total_units) issue_dma(u + wave_count);
+        if (u_next < total_units) issue_dma(u_next);
         if (lane < nrec) out[lane] = r0;
         if (lane + 64 < nrec) out[lane + 64] = r1;
+        u = u_next;
     }
 }
 
@@ -365,7 +383,7 @@ using namespace mtq;
 
 // Launcher used by mtq_tile_stats_batched when the input qualifies (mtq_kernels.hip decides).
 extern "C" int mtq_launch_tile_stats_bf16_fast(const void *x, int64_t count, int64_t stride_elems, int64_t rows, int64_t cols,
-                                               int64_t ld, uint32_t fmt_mask, double *stats, void *stream)
+                                               int64_t ld, uint32_t fmt_mask, double *stats, void *stream, unsigned **work_out)
 {
     const int64_t th = rows / kTile, tw = cols / kTile, tiles = th * tw;
     const int64_t units_w = cols / kUnitCols, upt = th * units_w, total = count * upt;
@@ -385,8 +403,11 @@ extern "C" int mtq_launch_tile_stats_bf16_fast(const void *x, int64_t count, int
     const size_t lds_bytes = kFastWaves * kRolledWaveLds;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const uint16_t *xp = static_cast<const uint16_t *>(x);
+    unsigned *work = work_counter_slot();
+    if (!work) return fail(MTQ_ERR_HIP, "could not allocate the work counters");
+    *work_out = work;
 #define MTQ_LAUNCH_FAST(B) \
-    hipLaunchKernelGGL(tile_stats_bf16_rolled<B>, grid, block, lds_bytes, st, xp, stride_elems, ld, (int)tw, tiles, (int)units_w, (int)upt, (int)total, fmt_mask, rec, stats)
+    hipLaunchKernelGGL(tile_stats_bf16_rolled<B>, grid, block, lds_bytes, st, xp, stride_elems, ld, (int)tw, tiles, (int)units_w, (int)upt, (int)total, fmt_mask, rec, stats, work)
     switch ((fmt_mask >> 1) & 7u) { // one instantiation per requested BFP subset: unrequested formats cost nothing
     case 1: MTQ_LAUNCH_FAST(1u); break;
     case 2: MTQ_LAUNCH_FAST(2u); break;

@@ -5,6 +5,9 @@
 #include <stdio.h>
 #include <stdlib.h>
 
+#include <atomic>
+#include <mutex>
+
 #include "../../include/mtq.h"
 #include "mtq_device.hpp"
 #include "mtq_error.hpp"
@@ -86,8 +89,9 @@ template <typename T>
 __global__ __launch_bounds__(256) void tile_stats_redo_flagged(const T *__restrict__ x, int64_t count, int64_t stride,
                                                                int64_t rows, int64_t cols, int64_t ld, int tiles_w,
                                                                int64_t tiles, uint32_t fmt_mask, int rec,
-                                                               double *__restrict__ stats, int vec_ok)
+                                                               double *__restrict__ stats, int vec_ok, unsigned *__restrict__ work)
 {
+    if (blockIdx.x == 0 && threadIdx.x < kWorkGroups) work[threadIdx.x * kWorkStride] = 0u; // the launch's unit counters, ready for their next user
     const int lane = threadIdx.x & 63;
     const int64_t first = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 64;
     const int64_t mine = first + lane;
@@ -139,7 +143,10 @@ __global__ __launch_bounds__(256) void quantize_groups(const T *__restrict__ x, 
 // K5 (loader): float8-e4m3fn weights × float32 inverse block scales → float32, the dequantisation the
 // reference's loader does on the host for DeepSeek-style checkpoints (hf_model_utils.py:199-215,273-281):
 // out = w.float() * scale_inv.repeat_interleave(block)[..].  Block shape = ceil(dim / scale_dim) (:199-206).
-// 16 bytes of fp8 per thread (one 16-B load, four 16-B stores); HBM bound (1 B read + 4 B written per element).
+// HBM bound (1 B read + 4 B written per element).  Coalesced form: one lane per 4 elements — a wave instruction
+// reads 256 contiguous bytes and writes 1 KiB contiguous; blockIdx.y walks the rows, so no per-thread division by
+// the row length; gfx950's OCP-fp8 convert (v_cvt_pk_f32_fp8) decodes two codes per instruction.  The scalar form
+// takes unaligned / strided views and the ragged row ends.
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ float e4m3fn_to_f32(uint32_t b)
 {
@@ -149,32 +156,44 @@ __device__ __forceinline__ float e4m3fn_to_f32(uint32_t b)
     return __uint_as_float(s | ((e + 120u) << 23) | (m << 20));
 }
 
-__global__ __launch_bounds__(256) void dequant_fp8_block(const uint8_t *__restrict__ w, const float *__restrict__ scale, int64_t rows,
-                                                         int64_t cols, int64_t ldw, int64_t scale_cols, int bh, int bw,
-                                                         float *__restrict__ out, int64_t ldo, int chunks_w, int vec_ok)
+typedef float k5f2 __attribute__((ext_vector_type(2)));
+
+__global__ __launch_bounds__(256) void dequant_fp8_quads(const uint8_t *__restrict__ w, const float *__restrict__ scale, int64_t rows,
+                                                         uint32_t cols, int64_t ldw, int64_t scale_cols, uint32_t bh, uint32_t bw,
+                                                         int bw_shift, float *__restrict__ out, int64_t ldo)
+{
+    const uint32_t c0 = (blockIdx.x * 256u + threadIdx.x) * 4u;
+    if (c0 >= cols) return;
+    for (int64_t row = blockIdx.y; row < rows; row += gridDim.y) {
+        const float *srow = scale + (row / bh) * scale_cols;                      // block-uniform: scalar unit
+        const uint8_t *src = w + row * ldw + c0;
+        float *dst = out + row * ldo + c0;
+        if (c0 + 4u <= cols) {
+            const uint32_t v = *reinterpret_cast<const uint32_t *>(src);
+            const k5f2 lo = __builtin_amdgcn_cvt_pk_f32_fp8((int)v, false), hi = __builtin_amdgcn_cvt_pk_f32_fp8((int)v, true);
+            float4 o;
+            if (bw_shift >= 0 && (bw & 3u) == 0u) {                               // 4 | block width: one scale for the quad
+                const float sc = srow[c0 >> bw_shift];
+                o.x = lo.x * sc; o.y = lo.y * sc; o.z = hi.x * sc; o.w = hi.y * sc;
+            } else {
+                o.x = lo.x * srow[c0 / bw]; o.y = lo.y * srow[(c0 + 1u) / bw]; o.z = hi.x * srow[(c0 + 2u) / bw]; o.w = hi.y * srow[(c0 + 3u) / bw];
+            }
+            *reinterpret_cast<float4 *>(dst) = o;
+        } else {
+            for (uint32_t i = 0; c0 + i < cols; ++i) dst[i] = e4m3fn_to_f32(src[i]) * srow[(c0 + i) / bw];
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void dequant_fp8_scalar(const uint8_t *__restrict__ w, const float *__restrict__ scale, int64_t rows,
+                                                          int64_t cols, int64_t ldw, int64_t scale_cols, int bh, int bw,
+                                                          float *__restrict__ out, int64_t ldo)
 {
     const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t row = g / chunks_w;
+    const int64_t row = g / cols;
     if (row >= rows) return;
-    const int64_t c0 = (g - row * chunks_w) * 16;
-    const uint8_t *src = w + row * ldw + c0;
-    float *dst = out + row * ldo + c0;
-    const float *srow = scale + (row / bh) * scale_cols;
-    if (vec_ok && c0 + 16 <= cols) {
-        const uint4 v = *reinterpret_cast<const uint4 *>(src);
-        const uint32_t q[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            float4 o;
-            o.x = e4m3fn_to_f32(q[k] & 0xFFu) * srow[(c0 + 4 * k + 0) / bw];
-            o.y = e4m3fn_to_f32((q[k] >> 8) & 0xFFu) * srow[(c0 + 4 * k + 1) / bw];
-            o.z = e4m3fn_to_f32((q[k] >> 16) & 0xFFu) * srow[(c0 + 4 * k + 2) / bw];
-            o.w = e4m3fn_to_f32(q[k] >> 24) * srow[(c0 + 4 * k + 3) / bw];
-            reinterpret_cast<float4 *>(dst)[k] = o;
-        }
-    } else {
-        for (int i = 0; i < 16 && c0 + i < cols; ++i) dst[i] = e4m3fn_to_f32(src[i]) * srow[(c0 + i) / bw];
-    }
+    const int64_t c = g - row * cols;
+    out[row * ldo + c] = e4m3fn_to_f32(w[row * ldw + c]) * scale[(row / bh) * scale_cols + c / bw];
 }
 
 
@@ -237,9 +256,32 @@ static int check_matrix(const void *x, int in_dtype, int64_t rows, int64_t cols,
 using namespace mtq;
 
 extern "C" int mtq_launch_tile_stats_bf16_fast(const void *x, int64_t count, int64_t stride_elems, int64_t rows, int64_t cols,
-                                               int64_t ld, uint32_t fmt_mask, double *stats, void *stream);
+                                               int64_t ld, uint32_t fmt_mask, double *stats, void *stream, unsigned **work_out);
 extern "C" int mtq_launch_tile_stats_direct(const void *x, int in_dtype, int64_t count, int64_t stride_elems, int64_t rows, int64_t cols,
-                                            int64_t ld, uint32_t fmt_mask, double *stats, int vec_ok, void *stream);
+                                            int64_t ld, uint32_t fmt_mask, double *stats, int vec_ok, void *stream, unsigned **work_out);
+
+// Per-device ring of zeroed unit counters (mtq_error.hpp).  A slot is handed to one K1 launch and set back to zero by
+// that launch's follow-up kernel on the same stream; kWorkSlots launches would have to be pending for a slot to be shared.
+unsigned *mtq::work_counter_slot()
+{
+    constexpr int kMaxDev = 64;
+    constexpr size_t kSlotUnsigned = (size_t)kWorkGroups * kWorkStride;
+    static unsigned *ring[kMaxDev] = {nullptr};
+    static std::atomic<unsigned> next[kMaxDev];
+    static std::mutex mu;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev) return nullptr;
+    if (!ring[dev]) {
+        std::lock_guard<std::mutex> lock(mu);
+        if (!ring[dev]) {
+            unsigned *p = nullptr;
+            if (hipMalloc(reinterpret_cast<void **>(&p), kWorkSlots * kSlotUnsigned * sizeof(unsigned)) != hipSuccess) return nullptr;
+            if (hipMemset(p, 0, kWorkSlots * kSlotUnsigned * sizeof(unsigned)) != hipSuccess || hipDeviceSynchronize() != hipSuccess) { (void)hipFree(p); return nullptr; }
+            ring[dev] = p;
+        }
+    }
+    return ring[dev] + (next[dev].fetch_add(1u) % kWorkSlots) * kSlotUnsigned;
+}
 
 // MTQ_FORCE_GENERIC=1 routes every input through tile_stats_generic (A/B checks of the fast kernel).
 static bool force_generic()
@@ -247,6 +289,15 @@ static bool force_generic()
     static int v = -1;
     if (v < 0) { const char *e = getenv("MTQ_FORCE_GENERIC"); v = (e && e[0] == '1') ? 1 : 0; }
     return v == 1;
+}
+
+// The follow-up kernel zeroes the launch's unit counter; if it could not be launched, do it with a memset so that the
+// slot's next user does not start from a stale count.
+static int finish_counter_launch(unsigned *work, hipStream_t s)
+{
+    const int rc = check_launch("mtq_tile_stats (redo flagged)");
+    if (rc != MTQ_OK) (void)hipMemsetAsync(work, 0, (size_t)kWorkGroups * kWorkStride * sizeof(unsigned), s);
+    return rc;
 }
 
 extern "C" size_t mtq_stats_record_doubles(uint32_t fmt_mask) { return 2 + 5 * (size_t)__builtin_popcount(fmt_mask & MTQ_MASK_ALL); }
@@ -266,24 +317,26 @@ extern "C" int mtq_tile_stats_batched(const void *x, int in_dtype, int64_t count
     const int vec_ok = aligned16(x) && (ld * esz) % 16 == 0 && (stride_elems * esz) % 16 == 0;
     // bf16 storage, whole 32x128 units, 16-byte aligned rows, at least one BFP format → exact-integer fast kernel
     if (in_dtype == MTQ_DTYPE_BF16 && vec_ok && rows % kTile == 0 && cols % 128 == 0 && (fmt_mask & 0xEu) != 0 && !force_generic()) {
-        if (int rc = mtq_launch_tile_stats_bf16_fast(x, count, stride_elems, rows, cols, ld, fmt_mask, stats, stream)) return rc;
+        unsigned *work = nullptr;
+        if (int rc = mtq_launch_tile_stats_bf16_fast(x, count, stride_elems, rows, cols, ld, fmt_mask, stats, stream, &work)) return rc;
         const int64_t waves = (count * tiles + 63) / 64;
         hipLaunchKernelGGL(tile_stats_redo_flagged<uint16_t>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, static_cast<hipStream_t>(stream),
-                           static_cast<const uint16_t *>(x), count, stride_elems, rows, cols, ld, (int)tw, tiles, fmt_mask, rec, stats, vec_ok);
-        return check_launch("mtq_tile_stats (redo flagged)");
+                           static_cast<const uint16_t *>(x), count, stride_elems, rows, cols, ld, (int)tw, tiles, fmt_mask, rec, stats, vec_ok, work);
+        return finish_counter_launch(work, static_cast<hipStream_t>(stream));
     }
     hipStream_t s = static_cast<hipStream_t>(stream);
     // float32 storage, ragged or unaligned bf16: one wave per tile on the reduced-arithmetic route (mtq_direct.hip)
     if ((fmt_mask & MTQ_MASK_ALL) != 0 && count * tiles < ((int64_t)1 << 31) && !force_generic()) {
-        if (int rc = mtq_launch_tile_stats_direct(x, in_dtype, count, stride_elems, rows, cols, ld, fmt_mask, stats, vec_ok, stream)) return rc;
+        unsigned *work = nullptr;
+        if (int rc = mtq_launch_tile_stats_direct(x, in_dtype, count, stride_elems, rows, cols, ld, fmt_mask, stats, vec_ok, stream, &work)) return rc;
         const dim3 rgrid((unsigned)(((count * tiles + 63) / 64 + 3) / 4));
         if (in_dtype == MTQ_DTYPE_BF16)
             hipLaunchKernelGGL(tile_stats_redo_flagged<uint16_t>, rgrid, dim3(256), 0, s, static_cast<const uint16_t *>(x), count, stride_elems,
-                               rows, cols, ld, (int)tw, tiles, fmt_mask, rec, stats, vec_ok);
+                               rows, cols, ld, (int)tw, tiles, fmt_mask, rec, stats, vec_ok, work);
         else
             hipLaunchKernelGGL(tile_stats_redo_flagged<float>, rgrid, dim3(256), 0, s, static_cast<const float *>(x), count, stride_elems, rows,
-                               cols, ld, (int)tw, tiles, fmt_mask, rec, stats, vec_ok);
-        return check_launch("mtq_tile_stats (redo flagged)");
+                               cols, ld, (int)tw, tiles, fmt_mask, rec, stats, vec_ok, work);
+        return finish_counter_launch(work, s);
     }
     const int64_t blocks = (count * tiles + 3) / 4;
     if (in_dtype == MTQ_DTYPE_BF16)
@@ -359,10 +412,17 @@ extern "C" int mtq_dequant_fp8_block(const void *w, const float *scale_inv, int6
     if (int rc = require_device()) return rc;
     const int64_t bh = (rows + scale_rows - 1) / scale_rows, bw = (cols + scale_cols - 1) / scale_cols; // hf_model_utils.py:199-206
     if ((rows + bh - 1) / bh > scale_rows || (cols + bw - 1) / bw > scale_cols) return fail(MTQ_ERR_INVALID, "scale grid does not cover the tensor");
-    const int64_t chunks_w = (cols + 15) / 16, total = rows * chunks_w;
-    if (chunks_w > INT32_MAX || total > ((int64_t)1 << 38) || bh > INT32_MAX || bw > INT32_MAX) return fail(MTQ_ERR_INVALID, "tensor too large");
-    const int vec_ok = aligned16(w) && ldw % 16 == 0 && aligned16(out) && (ldo * 4) % 16 == 0;
-    hipLaunchKernelGGL(dequant_fp8_block, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
-                       static_cast<const uint8_t *>(w), scale_inv, rows, cols, ldw, scale_cols, (int)bh, (int)bw, out, ldo, (int)chunks_w, vec_ok);
+    if (cols > (int64_t)1 << 31 || rows * cols > ((int64_t)1 << 38) || bh > INT32_MAX || bw > INT32_MAX) return fail(MTQ_ERR_INVALID, "tensor too large");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const bool vec_ok = (reinterpret_cast<uintptr_t>(w) & 3u) == 0 && ldw % 4 == 0 && aligned16(out) && (ldo * 4) % 16 == 0;
+    if (vec_ok) {
+        const int bw_shift = (bw & (bw - 1)) == 0 ? __builtin_ctzll((unsigned long long)bw) : -1;
+        const dim3 grid((unsigned)((cols + 1023) / 1024), (unsigned)(rows < 65535 ? rows : 65535));
+        hipLaunchKernelGGL(dequant_fp8_quads, grid, dim3(256), 0, st, static_cast<const uint8_t *>(w), scale_inv, rows, (uint32_t)cols, ldw,
+                           scale_cols, (uint32_t)bh, (uint32_t)bw, bw_shift, out, ldo);
+    } else {
+        hipLaunchKernelGGL(dequant_fp8_scalar, dim3((unsigned)((rows * cols + 255) / 256)), dim3(256), 0, st, static_cast<const uint8_t *>(w),
+                           scale_inv, rows, cols, ldw, scale_cols, (int)bh, (int)bw, out, ldo);
+    }
     return check_launch("mtq_dequant_fp8_block");
 }
