@@ -120,8 +120,8 @@ struct mtq_greedy {
     double mean_x, am2; // mean_x = sum_x / n and am2 = max(sum_x2 - n*mean_x*mean_x, 0): constant during the scan (:179,181,183)
     double max_abs;
     int64_t max_count;
-    std::vector<double> cur; // per tile: sy, sy2, sxy, sab, max of the CURRENT format
-    std::vector<int8_t> assign;
+    int slot4[MTQ_NUM_TILE_FORMATS]; // record slot of every format (−1: not in mask)
+    std::vector<int8_t> assign;  // the CURRENT format of every tile; its sums are stats[t][2 + 5*slot4[assign[t]] ..]
     std::vector<uint8_t> fixed;
     int64_t counts[MTQ_NUM_TILE_FORMATS];
 };
@@ -159,7 +159,7 @@ extern "C" int mtq_greedy_create(mtq_greedy **out, const double *stats, int64_t 
     g->thr = threshold;
     g->n = elem_count;
     g->stats = stats;
-    g->cur.resize((size_t)tiles * 5);
+    for (int f = 0; f < MTQ_NUM_TILE_FORMATS; ++f) g->slot4[f] = slot_of(fmt_mask, f);
     g->assign.assign((size_t)tiles, (int8_t)base_fmt); // :99
     g->fixed.assign((size_t)tiles, 0);                 // :100
     for (int f = 0; f < MTQ_NUM_TILE_FORMATS; ++f) g->counts[f] = 0;
@@ -174,19 +174,22 @@ extern "C" int mtq_greedy_create(mtq_greedy **out, const double *stats, int64_t 
         g->sum_y2 += b[1];
         g->sum_xy += b[2];
         g->sum_abs += b[3];
-        std::memcpy(&g->cur[(size_t)t * 5], b, 5 * sizeof(double));
     }
     g->cur_valid = false;
     g->cur_value = 0.0;
     g->mean_x = elem_count != 0.0 ? g->sum_x / elem_count : 0.0;
     g->am2 = g->sum_x2 - elem_count * g->mean_x * g->mean_x;
     if (g->am2 < 0.0) g->am2 = 0.0;
-    double m = g->cur[4]; // :219-220
-    for (int64_t t = 1; t < tiles; ++t) m = nanmax(m, g->cur[(size_t)t * 5 + 4]);
-    int64_t c = 0;
-    for (int64_t t = 0; t < tiles; ++t) c += (g->cur[(size_t)t * 5 + 4] == m);
-    g->max_abs = m;
-    g->max_count = c;
+    g->max_abs = 0.0;
+    g->max_count = 0;
+    if (metric == MTQ_METRIC_ATOL) { // :219-220 — the running maximum and its multiplicity (only the atol scan reads them)
+        double m = stats[2 + 5 * bslot + 4];
+        for (int64_t t = 1; t < tiles; ++t) m = nanmax(m, stats[t * g->rec + 2 + 5 * bslot + 4]);
+        int64_t c = 0;
+        for (int64_t t = 0; t < tiles; ++t) c += (stats[t * g->rec + 2 + 5 * bslot + 4] == m);
+        g->max_abs = m;
+        g->max_count = c;
+    }
     *out = g;
     return MTQ_OK;
 }
@@ -197,12 +200,24 @@ extern "C" int mtq_greedy_pass(mtq_greedy *g, int fmt, const int64_t *order, int
     const int slot = slot_of(g->mask, fmt);
     if (slot < 0) return fail(MTQ_ERR_INVALID, "format is not in the handle's fmt_mask");
     const double thr = g->thr, N = g->n;
+    constexpr int64_t kAhead = 12; // the visiting order is random and a record is 2–3 cache lines: fetch ahead of the dependent arithmetic
     for (int64_t k = 0; k < n; ++k) {
         const int64_t t = order[k];
         if (t < 0 || t >= g->T) return fail(MTQ_ERR_INVALID, "order contains a tile id out of range");
+        if (k + kAhead < n) {
+            const int64_t ta = order[k + kAhead];
+            if (ta >= 0 && ta < g->T && g->assign[(size_t)ta] != fmt) { // a tile already in this format is decided without its record
+                const double *ra = g->stats + ta * g->rec + 2;
+                __builtin_prefetch(ra + 5 * slot);
+                __builtin_prefetch(ra + 5 * slot + 4);
+                const int pa = g->slot4[g->assign[(size_t)ta]];
+                __builtin_prefetch(ra + 5 * pa);
+                __builtin_prefetch(ra + 5 * pa + 4);
+            }
+        }
         const int prev = g->assign[(size_t)t];
-        double *cur = &g->cur[(size_t)t * 5];
-        const double *q = g->stats + t * g->rec + 2 + 5 * slot;
+        const double *cur = g->stats + t * g->rec + 2 + 5 * g->slot4[prev]; // sums of the tile's CURRENT format
+        const double *q = cur + 5 * (slot - g->slot4[prev]);                // … and of the candidate format
         bool accept;
         if (g->metric == MTQ_METRIC_PCC) {
             if (prev == fmt) { // :237-241 — current_value is a pure function of the running sums: reuse it until a move is accepted
@@ -243,10 +258,11 @@ extern "C" int mtq_greedy_pass(mtq_greedy *g, int fmt, const int64_t *order, int
             } else if (old_max == g->max_abs) { // :329
                 if (g->max_count > 1) cand_count = g->max_count - 1; // :330-331
                 else {                                                 // :333-336 full recount
-                    double m = (t == 0) ? new_max : g->cur[4];
-                    for (int64_t j = 1; j < g->T; ++j) m = nanmax(m, j == t ? new_max : g->cur[(size_t)j * 5 + 4]);
+                    auto cur_max = [&](int64_t j) { return g->stats[j * g->rec + 2 + 5 * g->slot4[g->assign[(size_t)j]] + 4]; };
+                    double m = (t == 0) ? new_max : cur_max(0);
+                    for (int64_t j = 1; j < g->T; ++j) m = nanmax(m, j == t ? new_max : cur_max(j));
                     int64_t c = 0;
-                    for (int64_t j = 0; j < g->T; ++j) c += ((j == t ? new_max : g->cur[(size_t)j * 5 + 4]) == m);
+                    for (int64_t j = 0; j < g->T; ++j) c += ((j == t ? new_max : cur_max(j)) == m);
                     cand_max = m;
                     cand_count = c;
                 }
@@ -254,8 +270,7 @@ extern "C" int mtq_greedy_pass(mtq_greedy *g, int fmt, const int64_t *order, int
             accept = is_good(cand_max, MTQ_METRIC_ATOL, thr); // :337
             if (accept) { g->max_abs = cand_max; g->max_count = cand_count; }
         }
-        if (accept) { // :264-276 / :295-301 / :337-344
-            std::memcpy(cur, q, 5 * sizeof(double));
+        if (accept) { // :264-276 / :295-301 / :337-344 — the tile's current sums are now the candidate's record slot
             g->counts[prev]--;
             g->counts[fmt]++;
             g->assign[(size_t)t] = (int8_t)fmt;
@@ -468,6 +483,21 @@ void rng_permutation(mtq_rng *r, int64_t n, int64_t *out)
     }
 }
 
+// Generator.permutation(arr) in place: the same draws and swaps as rng_permutation applied to arr itself
+// (permutation(arr) == arr[permutation(len(arr))]); the rejection mask shrinks with i instead of being rebuilt.
+void rng_shuffle(mtq_rng *r, int64_t n, int64_t *arr)
+{
+    if (n < 2) return;
+    uint64_t mask = ~0ull >> __builtin_clzll((uint64_t)(n - 1));
+    for (int64_t i = n - 1; i >= 1; --i) {
+        while ((mask >> 1) >= (uint64_t)i) mask >>= 1;
+        uint64_t v;
+        if ((uint64_t)i <= 0xFFFFFFFFull) { while ((v = (pcg_next32(r) & mask)) > (uint64_t)i) {} }
+        else { while ((v = (pcg_next64(r) & mask)) > (uint64_t)i) {} }
+        const int64_t t = arr[i]; arr[i] = arr[(int64_t)v]; arr[(int64_t)v] = t;
+    }
+}
+
 // Generator.integers(0, high, size=n, dtype=int64) for high − 1 < 2^32 − 1: Lemire's multiply-shift rejection
 // on buffered 32-bit draws (numpy/random/src/distributions/distributions.c, buffered_bounded_lemire_uint32;
 // Generator.integers never takes the masked form).  high == 1 consumes nothing.
@@ -529,15 +559,14 @@ extern "C" int mtq_greedy_run(const double *stats, int64_t tiles, uint32_t fmt_m
     if (int rc = mtq_greedy_create(&g, stats, tiles, fmt_mask, metric, threshold, elem_count, formats[0])) return rc;
     mtq_rng rng;
     rng_seed(&rng, seed);
-    std::vector<int64_t> cand((size_t)tiles), perm((size_t)tiles), order((size_t)tiles);
+    std::vector<int64_t> cand((size_t)tiles);
     int rc = MTQ_OK;
     for (int f = 0; f < n_formats && rc == MTQ_OK; ++f) {
         int64_t n = 0;
         for (int64_t t = 0; t < tiles; ++t) if (!g->fixed[(size_t)t]) cand[(size_t)n++] = t; // np.where(~fixed)[0], :228
         if (n == 0) break;                                                                     // :229-230
-        rng_permutation(&rng, n, perm.data());                                                // :231
-        for (int64_t i = 0; i < n; ++i) order[(size_t)i] = cand[(size_t)perm[(size_t)i]];
-        rc = mtq_greedy_pass(g, formats[f], order.data(), n);
+        rng_shuffle(&rng, n, cand.data());                                                    // order = rng.permutation(candidates), :231
+        rc = mtq_greedy_pass(g, formats[f], cand.data(), n);
     }
     if (rc == MTQ_OK) {
         std::memcpy(map, g->assign.data(), (size_t)tiles);
