@@ -50,6 +50,10 @@ enum { MTQ_DTYPE_BF16 = 0, MTQ_DTYPE_F32 = 1 };
 enum { MTQ_FMT_BF16 = 0, MTQ_FMT_BFP8 = 1, MTQ_FMT_BFP4 = 2, MTQ_FMT_BFP2 = 3, MTQ_FMT_FP0 = 4 };
 #define MTQ_NUM_TILE_FORMATS 4
 #define MTQ_MASK_ALL 0xFu
+/* HOST functions only: "the records hold no bf16 slot; the bf16 candidate is the identity" — true for bf16 STORAGE, where
+ * K1's bf16 slot is [Σx, Σx², Σx², |Σx|·0, |Σx|·0].  Set together with a mask WITHOUT bit 0 (records written by K1 for
+ * mask & 0xE: 17 instead of 22 doubles per tile cross PCIe); format 0 is then synthesised from Σx, Σx² on the host. */
+#define MTQ_MASK_BF16_IDENTITY 0x10u
 
 /* metrics (compression_algorithms/metrics.py:19-39) */
 enum { MTQ_METRIC_PCC = 0, MTQ_METRIC_MAE = 1, MTQ_METRIC_ATOL = 2 };
@@ -172,8 +176,8 @@ int mtq_greedy_run_batch(const double *stats, int64_t count, int64_t tiles, uint
 
 /*
  * Per-tile scores from the raw sums, n = 1024 (tile_utils.py:46-57 semantics on float64 moments):
- * pcc via the moment formula, mae = Σ|d|/1024, atol = max|d|.  scores is [popcount(mask)][tiles],
- * formats in ascending mask-bit order.
+ * pcc via the moment formula, mae = Σ|d|/1024, atol = max|d|.  scores is [formats][tiles], formats in ascending
+ * code order: popcount(mask & 0xF) rows, plus a leading bf16 row under MTQ_MASK_BF16_IDENTITY.
  */
 int mtq_tile_scores(const double *stats, int64_t tiles, uint32_t fmt_mask, int metric, double *scores);
 

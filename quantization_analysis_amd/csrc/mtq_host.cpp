@@ -63,11 +63,26 @@ int check_launch(const char *what)
 
 static inline int popcount4(uint32_t m) { return __builtin_popcount(m & MTQ_MASK_ALL); }
 
-// slot of format f among the set bits of mask, or -1
+constexpr int kVirtualSlot = -2; // bf16 as the identity (MTQ_MASK_BF16_IDENTITY): no record slot, sums come from Σx, Σx²
+
+// slot of format f among the set bits of mask, kVirtualSlot for the identity bf16, or -1 when f is not available
 static inline int slot_of(uint32_t mask, int f)
 {
-    if (f < 0 || f >= MTQ_NUM_TILE_FORMATS || !(mask & (1u << f))) return -1;
+    if (f < 0 || f >= MTQ_NUM_TILE_FORMATS) return -1;
+    if (f == 0 && (mask & MTQ_MASK_BF16_IDENTITY) && !(mask & 1u)) return kVirtualSlot;
+    if (!(mask & (1u << f))) return -1;
     return __builtin_popcount(mask & ((1u << f) - 1u));
+}
+static inline bool slot_ok(int slot) { return slot >= 0 || slot == kVirtualSlot; }
+
+// The 5 sums (Σy, Σy², Σxy, Σ|d|, max|d|) of one format of record r: a pointer into the record, or — identity bf16 —
+// the values K1 writes for bf16 storage (y == x), built in buf.
+static inline const double *sums5(const double *r, int slot, double buf[5])
+{
+    if (slot >= 0) return r + 2 + 5 * slot;
+    const double z = std::fabs(r[0]) * 0.0; // 0, or NaN when Σx is not finite (what the kernel stores)
+    buf[0] = r[0]; buf[1] = r[1]; buf[2] = r[1]; buf[3] = z; buf[4] = z;
+    return buf;
 }
 
 static inline double nanmax(double m, double d) { return (d > m || d != d) ? d : m; }
@@ -149,11 +164,11 @@ extern "C" int mtq_greedy_create(mtq_greedy **out, const double *stats, int64_t 
     if (tiles <= 0) return fail(MTQ_ERR_INVALID, "tiles must be positive");
     if (metric < MTQ_METRIC_PCC || metric > MTQ_METRIC_ATOL) return fail(MTQ_ERR_INVALID, "unknown metric");
     const int bslot = slot_of(fmt_mask, base_fmt);
-    if (bslot < 0) return fail(MTQ_ERR_INVALID, "base format is not in fmt_mask");
+    if (!slot_ok(bslot)) return fail(MTQ_ERR_INVALID, "base format is not in fmt_mask");
     mtq_greedy *g = new (std::nothrow) mtq_greedy();
     if (!g) return fail(MTQ_ERR_INVALID, "out of memory");
     g->T = tiles;
-    g->mask = fmt_mask & MTQ_MASK_ALL;
+    g->mask = fmt_mask & (MTQ_MASK_ALL | MTQ_MASK_BF16_IDENTITY);
     g->rec = 2 + 5 * popcount4(fmt_mask);
     g->metric = metric;
     g->thr = threshold;
@@ -166,8 +181,9 @@ extern "C" int mtq_greedy_create(mtq_greedy **out, const double *stats, int64_t 
     g->counts[base_fmt] = tiles;                       // :102-103
     g->sum_x = g->sum_x2 = g->sum_y = g->sum_y2 = g->sum_xy = g->sum_abs = 0.0;
     // running globals accumulated in tile order (:147-174, :195-204, :208-218)
+    double vb[5];
     for (int64_t t = 0; t < tiles; ++t) {
-        const double *r = stats + t * g->rec, *b = r + 2 + 5 * bslot;
+        const double *r = stats + t * g->rec, *b = sums5(r, bslot, vb);
         g->sum_x += r[0];
         g->sum_x2 += r[1];
         g->sum_y += b[0];
@@ -183,10 +199,10 @@ extern "C" int mtq_greedy_create(mtq_greedy **out, const double *stats, int64_t 
     g->max_abs = 0.0;
     g->max_count = 0;
     if (metric == MTQ_METRIC_ATOL) { // :219-220 — the running maximum and its multiplicity (only the atol scan reads them)
-        double m = stats[2 + 5 * bslot + 4];
-        for (int64_t t = 1; t < tiles; ++t) m = nanmax(m, stats[t * g->rec + 2 + 5 * bslot + 4]);
+        double m = sums5(stats, bslot, vb)[4];
+        for (int64_t t = 1; t < tiles; ++t) m = nanmax(m, sums5(stats + t * g->rec, bslot, vb)[4]);
         int64_t c = 0;
-        for (int64_t t = 0; t < tiles; ++t) c += (stats[t * g->rec + 2 + 5 * bslot + 4] == m);
+        for (int64_t t = 0; t < tiles; ++t) c += (sums5(stats + t * g->rec, bslot, vb)[4] == m);
         g->max_abs = m;
         g->max_count = c;
     }
@@ -198,8 +214,9 @@ extern "C" int mtq_greedy_pass(mtq_greedy *g, int fmt, const int64_t *order, int
 {
     if (!g || (!order && n > 0)) return fail(MTQ_ERR_INVALID, "null argument");
     const int slot = slot_of(g->mask, fmt);
-    if (slot < 0) return fail(MTQ_ERR_INVALID, "format is not in the handle's fmt_mask");
+    if (!slot_ok(slot)) return fail(MTQ_ERR_INVALID, "format is not in the handle's fmt_mask");
     const double thr = g->thr, N = g->n;
+    double vcur[5], vq[5];
     constexpr int64_t kAhead = 12; // the visiting order is random and a record is 2–3 cache lines: fetch ahead of the dependent arithmetic
     for (int64_t k = 0; k < n; ++k) {
         const int64_t t = order[k];
@@ -207,17 +224,18 @@ extern "C" int mtq_greedy_pass(mtq_greedy *g, int fmt, const int64_t *order, int
         if (k + kAhead < n) {
             const int64_t ta = order[k + kAhead];
             if (ta >= 0 && ta < g->T && g->assign[(size_t)ta] != fmt) { // a tile already in this format is decided without its record
-                const double *ra = g->stats + ta * g->rec + 2;
-                __builtin_prefetch(ra + 5 * slot);
-                __builtin_prefetch(ra + 5 * slot + 4);
-                const int pa = g->slot4[g->assign[(size_t)ta]];
-                __builtin_prefetch(ra + 5 * pa);
-                __builtin_prefetch(ra + 5 * pa + 4);
+                const double *ra = g->stats + ta * g->rec;      // the identity slot lives in the record's first two doubles
+                const int sa = slot >= 0 ? 2 + 5 * slot : 0, pa = g->slot4[g->assign[(size_t)ta]] >= 0 ? 2 + 5 * g->slot4[g->assign[(size_t)ta]] : 0;
+                __builtin_prefetch(ra + sa);
+                __builtin_prefetch(ra + sa + 4);
+                __builtin_prefetch(ra + pa);
+                __builtin_prefetch(ra + pa + 4);
             }
         }
         const int prev = g->assign[(size_t)t];
-        const double *cur = g->stats + t * g->rec + 2 + 5 * g->slot4[prev]; // sums of the tile's CURRENT format
-        const double *q = cur + 5 * (slot - g->slot4[prev]);                // … and of the candidate format
+        const double *rt = g->stats + t * g->rec;
+        const double *cur = sums5(rt, g->slot4[prev], vcur); // sums of the tile's CURRENT format
+        const double *q = sums5(rt, slot, vq);               // … and of the candidate format
         bool accept;
         if (g->metric == MTQ_METRIC_PCC) {
             if (prev == fmt) { // :237-241 — current_value is a pure function of the running sums: reuse it until a move is accepted
@@ -258,7 +276,7 @@ extern "C" int mtq_greedy_pass(mtq_greedy *g, int fmt, const int64_t *order, int
             } else if (old_max == g->max_abs) { // :329
                 if (g->max_count > 1) cand_count = g->max_count - 1; // :330-331
                 else {                                                 // :333-336 full recount
-                    auto cur_max = [&](int64_t j) { return g->stats[j * g->rec + 2 + 5 * g->slot4[g->assign[(size_t)j]] + 4]; };
+                    auto cur_max = [&](int64_t j) { double vb[5]; return sums5(g->stats + j * g->rec, g->slot4[g->assign[(size_t)j]], vb)[4]; };
                     double m = (t == 0) ? new_max : cur_max(0);
                     for (int64_t j = 1; j < g->T; ++j) m = nanmax(m, j == t ? new_max : cur_max(j));
                     int64_t c = 0;
@@ -316,7 +334,8 @@ extern "C" void mtq_greedy_destroy(mtq_greedy *g) { delete g; }
 // Per-tile score of one record slot, n = 1024 (tile_utils.py:46-57 on the raw sums).
 static inline double tile_score(const double *r, int slot, int metric)
 {
-    const double *b = r + 2 + 5 * slot;
+    double vb[5];
+    const double *b = sums5(r, slot, vb);
     if (metric == MTQ_METRIC_MAE) return b[3] / 1024.0;
     if (metric == MTQ_METRIC_ATOL) return b[4];
     return pcc_from_moments(1024.0, r[0], r[1], b[0], b[1], b[2], b[3]);
@@ -326,9 +345,14 @@ extern "C" int mtq_tile_scores(const double *stats, int64_t tiles, uint32_t fmt_
 {
     if (!stats || !scores) return fail(MTQ_ERR_INVALID, "null argument");
     if (metric < MTQ_METRIC_PCC || metric > MTQ_METRIC_ATOL) return fail(MTQ_ERR_INVALID, "unknown metric");
-    const int nf = popcount4(fmt_mask), rec = 2 + 5 * nf;
-    for (int s = 0; s < nf; ++s)
-        for (int64_t t = 0; t < tiles; ++t) scores[(int64_t)s * tiles + t] = tile_score(stats + t * rec, s, metric);
+    const int rec = 2 + 5 * popcount4(fmt_mask);
+    int64_t row = 0;
+    for (int f = 0; f < MTQ_NUM_TILE_FORMATS; ++f) { // ascending format code; the identity bf16 (if any) comes first
+        const int slot = slot_of(fmt_mask, f);
+        if (!slot_ok(slot)) continue;
+        for (int64_t t = 0; t < tiles; ++t) scores[row * tiles + t] = tile_score(stats + t * rec, slot, metric);
+        ++row;
+    }
     return MTQ_OK;
 }
 
@@ -343,7 +367,7 @@ extern "C" int mtq_threshold_assign(const double *stats, int64_t tiles, uint32_t
     static const double bytes_per_elem[MTQ_NUM_TILE_FORMATS] = {2.0, 1.088, 0.50097, 0.25097};
     int order[MTQ_NUM_TILE_FORMATS], slots[MTQ_NUM_TILE_FORMATS];
     for (int i = 0; i < n_formats; ++i) {
-        if (slot_of(fmt_mask, formats[i]) < 0) return fail(MTQ_ERR_INVALID, "a requested format is not in fmt_mask");
+        if (!slot_ok(slot_of(fmt_mask, formats[i]))) return fail(MTQ_ERR_INVALID, "a requested format is not in fmt_mask");
         order[i] = formats[i];
     }
     // stable sort ascending bytes (mixed_tile_threshold.py:112-114); best_precision = FIRST max in that order (:115)
@@ -383,8 +407,9 @@ extern "C" int mtq_columns_from_stats(const double *stats, int64_t tiles, uint32
     double sx = 0, sx2 = 0, sy = 0, sy2 = 0, sxy = 0, sab = 0, mx = 0;
     for (int64_t t = 0; t < tiles; ++t) {
         const int slot = slot_of(fmt_mask, map[t]);
-        if (slot < 0) return fail(MTQ_ERR_INVALID, "map names a format that is not in fmt_mask");
-        const double *r = stats + t * rec, *b = r + 2 + 5 * slot;
+        if (!slot_ok(slot)) return fail(MTQ_ERR_INVALID, "map names a format that is not in fmt_mask");
+        double vb[5];
+        const double *r = stats + t * rec, *b = sums5(r, slot, vb);
         sx += r[0]; sx2 += r[1]; sy += b[0]; sy2 += b[1]; sxy += b[2]; sab += b[3];
         mx = nanmax(mx, b[4]);
     }
@@ -434,16 +459,6 @@ inline uint32_t pcg_next32(mtq_rng *r)
     return (uint32_t)n;
 }
 
-inline uint64_t rng_interval(mtq_rng *r, uint64_t max)
-{
-    if (max == 0) return 0;
-    const uint64_t mask = ~0ull >> __builtin_clzll(max); // smallest 2^k − 1 ≥ max (NumPy builds it with shifts and ors)
-    uint64_t v;
-    if (max <= 0xFFFFFFFFull) { while ((v = (pcg_next32(r) & mask)) > max) {} }
-    else { while ((v = (pcg_next64(r) & mask)) > max) {} }
-    return v;
-}
-
 void rng_seed(mtq_rng *r, uint64_t seed)
 {
     // SeedSequence(seed): entropy = little-endian uint32 words of the integer (at least one word)
@@ -474,28 +489,62 @@ void rng_seed(mtq_rng *r, uint64_t seed)
     r->u32 = 0;
 }
 
-void rng_permutation(mtq_rng *r, int64_t n, int64_t *out)
-{
-    for (int64_t i = 0; i < n; ++i) out[i] = i;
-    for (int64_t i = n - 1; i >= 1; --i) {
-        const int64_t j = (int64_t)rng_interval(r, (uint64_t)i);
-        const int64_t t = out[i]; out[i] = out[j]; out[j] = t;
-    }
-}
-
-// Generator.permutation(arr) in place: the same draws and swaps as rng_permutation applied to arr itself
-// (permutation(arr) == arr[permutation(len(arr))]); the rejection mask shrinks with i instead of being rebuilt.
+// Generator.permutation(arr) in place (Fisher–Yates from the top, random_interval's masked rejection on buffered 32-bit
+// draws; permutation(arr) == arr[permutation(len(arr))]).  The visiting order is a third of the scan's time when done
+// draw by draw (an unpredictable rejection branch per element), so the draws of a block are generated first and then
+// consumed without branches: a rejected draw swaps an element with itself and leaves i where it is.  Draws generated
+// beyond the last one consumed are handed back by replaying the generator from the block's start.
 void rng_shuffle(mtq_rng *r, int64_t n, int64_t *arr)
 {
     if (n < 2) return;
-    uint64_t mask = ~0ull >> __builtin_clzll((uint64_t)(n - 1));
-    for (int64_t i = n - 1; i >= 1; --i) {
-        while ((mask >> 1) >= (uint64_t)i) mask >>= 1;
-        uint64_t v;
-        if ((uint64_t)i <= 0xFFFFFFFFull) { while ((v = (pcg_next32(r) & mask)) > (uint64_t)i) {} }
-        else { while ((v = (pcg_next64(r) & mask)) > (uint64_t)i) {} }
-        const int64_t t = arr[i]; arr[i] = arr[(int64_t)v]; arr[(int64_t)v] = t;
+    int64_t i = n - 1;
+    uint64_t mask = ~0ull >> __builtin_clzll((uint64_t)i);
+    if ((uint64_t)i > 0xFFFFFFFFull) { // 64-bit draws: the plain loop (never reached by the scan: tiles < 2^31)
+        for (; i >= 1; --i) {
+            while ((mask >> 1) >= (uint64_t)i) mask >>= 1;
+            uint64_t v;
+            if ((uint64_t)i <= 0xFFFFFFFFull) { while ((v = (pcg_next32(r) & mask)) > (uint64_t)i) {} }
+            else { while ((v = (pcg_next64(r) & mask)) > (uint64_t)i) {} }
+            const int64_t t = arr[i]; arr[i] = arr[(int64_t)v]; arr[(int64_t)v] = t;
+        }
+        return;
     }
+    constexpr int kBlock = 128;                       // 64-bit outputs per block
+    uint32_t buf[2 * kBlock + 1];
+    uint32_t m32 = (uint32_t)mask, ii = (uint32_t)i;
+    while (ii >= 1u) {
+        int cnt = 0;
+        const int pend = r->has32 ? 1 : 0;            // a buffered high half is the next draw
+        if (pend) buf[cnt++] = r->u32;
+        const unsigned __int128 state0 = r->state;
+        for (int k = 0; k < kBlock; ++k) { const uint64_t o = pcg_next64(r); buf[cnt++] = (uint32_t)o; buf[cnt++] = (uint32_t)(o >> 32); }
+        int p = 0;
+        while (p < cnt && ii >= 1u) {
+            const uint32_t v = buf[p++] & m32;
+            const bool ok = v <= ii;
+            const uint32_t j = ok ? v : ii;           // rejected: swap with itself
+            const int64_t a = arr[ii], b = arr[j];
+            arr[ii] = b; arr[j] = a;
+            ii -= ok ? 1u : 0u;
+            m32 = ((m32 >> 1) >= ii) ? (m32 >> 1) : m32; // smallest 2^k − 1 >= ii: one step at most per decrement (harmless at ii == 0)
+        }
+        if (p == cnt) { r->has32 = false; continue; } // the whole block was consumed, its last high half included
+        // finished inside the block: hand the unused draws back by replaying from the block's start
+        const int fresh = p - pend;                   // halves taken from this block's own outputs
+        r->state = state0;
+        if (fresh < 0) continue;                      // not even the pending half was needed (cannot happen with ii >= 1 on entry)
+        if (fresh == 0) { r->has32 = false; continue; } // only the pending half was used
+        uint64_t last = 0;
+        for (int k = 0; k < (fresh + 1) / 2; ++k) last = pcg_next64(r);
+        r->has32 = (fresh & 1) != 0;                  // an odd count leaves the last output's high half buffered
+        r->u32 = (uint32_t)(last >> 32);
+    }
+}
+
+void rng_permutation(mtq_rng *r, int64_t n, int64_t *out)
+{
+    for (int64_t i = 0; i < n; ++i) out[i] = i;
+    rng_shuffle(r, n, out);
 }
 
 // Generator.integers(0, high, size=n, dtype=int64) for high − 1 < 2^32 − 1: Lemire's multiply-shift rejection

@@ -116,6 +116,9 @@ def mask_formats(mask: int) -> list[str]:
     return [f for i, f in enumerate(MIXED_TILE_FORMATS) if mask & (1 << i)]
 
 
+MASK_BF16_IDENTITY = 0x10  # include/mtq.h MTQ_MASK_BF16_IDENTITY (host functions only)
+
+
 def record_doubles(mask: int) -> int:
     return 2 + 5 * bin(mask & 0xF).count("1")
 
@@ -377,7 +380,8 @@ def greedy_run_batch(stats: np.ndarray, mask: int, formats, metric: str, thresho
 def tile_scores(stats: np.ndarray, mask: int, metric: str) -> np.ndarray:
     stats = np.ascontiguousarray(stats, dtype=np.float64)
     T = stats.shape[0]
-    out = np.empty((bin(mask & 0xF).count("1"), T), dtype=np.float64)
+    rows = bin(mask & 0xF).count("1") + (1 if (mask & MASK_BF16_IDENTITY) and not (mask & 1) else 0)  # identity bf16 comes first
+    out = np.empty((rows, T), dtype=np.float64)
     check(lib().mtq_tile_scores(stats.ctypes.data, T, mask, METRIC_CODE[metric], out.ctypes.data))
     return out
 

@@ -163,6 +163,32 @@ def test_greedy_run_equals_numpy_driven_scan(golden_dir):
         hb.greedy_run(stats, mask, ["bf16"], "pcc", 0.9, 1.0, 0)  # seed 0 must be resolved by the caller
 
 
+def test_identity_bf16_mask_equals_full_records():
+    """MTQ_MASK_BF16_IDENTITY: for bf16-valued data the bf16 slot of a record is [Σx, Σx², Σx², 0, 0]; host functions given
+    the 17-double records (BFP slots only) and the identity flag must decide exactly like the 22-double records."""
+    for kind, shape, metric, thr in (("normal_bf16", (256, 256), "pcc", 0.999), ("heavy_bf16", (192, 160), "pcc", 0.995),
+                                     ("heavy_bf16", (96, 160), "mae", 5e-4), ("heavy_bf16", (96, 160), "atol", 2e-2)):
+        x = gen(kind, 3, shape)
+        full = orc.tile_stats(x, ALL)
+        z = np.zeros(full.shape[0])
+        assert np.array_equal(full[:, 2:7], np.stack([full[:, 0], full[:, 1], full[:, 1], z, z], axis=1))
+        slim = np.ascontiguousarray(np.delete(full, np.s_[2:7], axis=1))
+        assert slim.shape[1] == hb.record_doubles(0xE) == 17
+        ident = 0xE | hb.MASK_BF16_IDENTITY
+        for fmts in (ALL, ["bf16", "bfp4"], ["bfp8", "bf16", "bfp2"]):
+            a1, c1, o1 = hb.greedy_run(full, 0xF, fmts, metric, thr, float(x.size), 77)
+            a2, c2, o2 = hb.greedy_run(slim, ident, fmts, metric, thr, float(x.size), 77)
+            assert np.array_equal(a1, a2) and c1 == c2 and o1 == o2, (kind, metric, fmts)
+        m1, k1 = hb.threshold_assign(full, 0xF, ALL, metric, thr, 2e-6)
+        m2, k2 = hb.threshold_assign(slim, ident, ALL, metric, thr, 2e-6)
+        assert np.array_equal(m1, m2) and np.array_equal(k1, k2)
+        assert np.array_equal(hb.tile_scores(full, 0xF, metric).view(np.uint64), hb.tile_scores(slim, ident, metric).view(np.uint64))
+        amap = np.random.default_rng(1).integers(0, 4, full.shape[0]).astype(np.int8)
+        assert hb.columns_from_stats(full, 0xF, amap, float(x.size)) == hb.columns_from_stats(slim, ident, amap, float(x.size))
+    with pytest.raises(hb.MtqError):  # without the flag format 0 is simply absent
+        hb.greedy_run(slim, 0xE, ALL, "pcc", 0.999, 1024.0, 5)
+
+
 def test_greedy_run_batch_equals_single_runs():
     xs = [gen("normal_bf16", s, (256, 256)) for s in range(5)]
     st = np.stack([orc.tile_stats(x, ALL) for x in xs])

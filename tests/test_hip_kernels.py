@@ -288,6 +288,30 @@ def test_full_size_parity_and_properties():
     assert np.array_equal(gl.view(np.uint64), orc.tile_stats(xl.float().numpy(), ["bfp8", "bfp4", "bfp2"]).view(np.uint64))
 
 
+def test_streamed_pipeline_matches_oracle():
+    """GreedyPipeline (what bench.py times): chunked K1 launches, records over PCIe, threaded host scans.  bf16 storage takes
+    the 17-double records + identity bf16 (MTQ_MASK_BF16_IDENTITY), float32 storage the full records; maps, counts and
+    columns equal the oracle's greedy search tensor by tensor, with per-tensor seeds."""
+    from quantization_analysis_amd.pipeline import GreedyPipeline
+
+    for kind, shape, bf16 in (("normal_bf16", (128, 256), True), ("heavy_bf16", (96, 160), True), ("heavy_f32", (96, 160), False)):
+        xs = np.stack([gen(kind, 30 + i, shape) for i in range(5)])
+        seeds = [11, 12, 13, 14, 15]
+        pipe = GreedyPipeline(ALL, "pcc", 0.998, 123, chunk=2, workers=3)
+        try:
+            res = pipe.run(dev(xs, bf16=bf16), seeds=seeds)
+            res2 = pipe.run(dev(xs, bf16=bf16), seeds=seeds)   # buffers are reused: same answer again
+        finally:
+            pipe.close()
+        assert [r.index for r in res] == list(range(5))
+        for i, r in enumerate(res):
+            a, counts, st = orc.greedy(xs[i], ALL, "pcc", 0.998, seeds[i])
+            assert np.array_equal(r.assignment, a) and r.counts == counts, (kind, i)
+            pcc, mae, atol = orc.columns_from_stats(st["stats"], orc.mask_slots(0xF), a, xs[i].size)
+            assert (r.pcc, r.mae, r.atol) == (pcc, mae, atol), (kind, i)
+            assert np.array_equal(res2[i].assignment, a)
+
+
 def test_fast_kernel_strided_view_and_batch_stride():
     """The exact-integer kernel on a column window of a wider matrix (ld > cols) and on a batch whose tensors are
     padded apart (stride > rows*cols): same records as the oracle on the dense copies."""
