@@ -75,6 +75,15 @@ static inline int slot_of(uint32_t mask, int f)
 }
 static inline bool slot_ok(int slot) { return slot >= 0 || slot == kVirtualSlot; }
 
+// The same five sums by value (registers): what the scan's inner loop uses.
+struct Sums5 { double y, y2, xy, ab, mx; };
+static inline Sums5 load5(const double *r, int slot)
+{
+    if (slot >= 0) { const double *b = r + 2 + 5 * slot; return {b[0], b[1], b[2], b[3], b[4]}; }
+    const double z = std::fabs(r[0]) * 0.0;
+    return {r[0], r[1], r[1], z, z};
+}
+
 // The 5 sums (Σy, Σy², Σxy, Σ|d|, max|d|) of one format of record r: a pointer into the record, or — identity bf16 —
 // the values K1 writes for bf16 storage (y == x), built in buf.
 static inline const double *sums5(const double *r, int slot, double buf[5])
@@ -216,7 +225,6 @@ extern "C" int mtq_greedy_pass(mtq_greedy *g, int fmt, const int64_t *order, int
     const int slot = slot_of(g->mask, fmt);
     if (!slot_ok(slot)) return fail(MTQ_ERR_INVALID, "format is not in the handle's fmt_mask");
     const double thr = g->thr, N = g->n;
-    double vcur[5], vq[5];
     constexpr int64_t kAhead = 12; // the visiting order is random and a record is 2–3 cache lines: fetch ahead of the dependent arithmetic
     for (int64_t k = 0; k < n; ++k) {
         const int64_t t = order[k];
@@ -234,8 +242,6 @@ extern "C" int mtq_greedy_pass(mtq_greedy *g, int fmt, const int64_t *order, int
         }
         const int prev = g->assign[(size_t)t];
         const double *rt = g->stats + t * g->rec;
-        const double *cur = sums5(rt, g->slot4[prev], vcur); // sums of the tile's CURRENT format
-        const double *q = sums5(rt, slot, vq);               // … and of the candidate format
         bool accept;
         if (g->metric == MTQ_METRIC_PCC) {
             if (prev == fmt) { // :237-241 — current_value is a pure function of the running sums: reuse it until a move is accepted
@@ -246,10 +252,11 @@ extern "C" int mtq_greedy_pass(mtq_greedy *g, int fmt, const int64_t *order, int
                 if (!is_good(g->cur_value, MTQ_METRIC_PCC, thr)) g->fixed[(size_t)t] = 1;
                 continue;
             }
-            const double cy = g->sum_y + (q[0] - cur[0]);   // :259
-            const double cy2 = g->sum_y2 + (q[1] - cur[1]); // :260
-            const double cxy = g->sum_xy + (q[2] - cur[2]); // :261
-            const double cab = g->sum_abs + (q[3] - cur[3]); // :262
+            const Sums5 cur = load5(rt, g->slot4[prev]), q = load5(rt, slot); // the tile's CURRENT format and the candidate
+            const double cy = g->sum_y + (q.y - cur.y);     // :259
+            const double cy2 = g->sum_y2 + (q.y2 - cur.y2); // :260
+            const double cxy = g->sum_xy + (q.xy - cur.xy); // :261
+            const double cab = g->sum_abs + (q.ab - cur.ab); // :262
             accept = is_good(pcc_hoisted(N, g->mean_x, g->am2, cy, cy2, cxy, cab), MTQ_METRIC_PCC, thr);
             if (accept) { g->sum_y = cy; g->sum_y2 = cy2; g->sum_xy = cxy; g->sum_abs = cab; g->cur_valid = false; }
         } else if (g->metric == MTQ_METRIC_MAE) {
@@ -257,7 +264,7 @@ extern "C" int mtq_greedy_pass(mtq_greedy *g, int fmt, const int64_t *order, int
                 if (!is_good(N != 0.0 ? g->sum_abs / N : 0.0, MTQ_METRIC_MAE, thr)) g->fixed[(size_t)t] = 1;
                 continue;
             }
-            const double cab = g->sum_abs + (q[3] - cur[3]); // :293
+            const double cab = g->sum_abs + (load5(rt, slot).ab - load5(rt, g->slot4[prev]).ab); // :293
             accept = is_good(N != 0.0 ? cab / N : 0.0, MTQ_METRIC_MAE, thr);
             if (accept) g->sum_abs = cab;
         } else {
@@ -265,7 +272,7 @@ extern "C" int mtq_greedy_pass(mtq_greedy *g, int fmt, const int64_t *order, int
                 if (!is_good(g->max_abs, MTQ_METRIC_ATOL, thr)) g->fixed[(size_t)t] = 1;
                 continue;
             }
-            const double new_max = q[4], old_max = cur[4];
+            const double new_max = load5(rt, slot).mx, old_max = load5(rt, g->slot4[prev]).mx;
             double cand_max = g->max_abs;
             int64_t cand_count = g->max_count;
             if (new_max > g->max_abs) { // :322-324
