@@ -13,6 +13,11 @@
 #include <cstring>
 #include <algorithm>
 #include <atomic>
+#include <condition_variable>
+#include <deque>
+#include <functional>
+#include <memory>
+#include <mutex>
 #include <new>
 #include <string>
 #include <thread>
@@ -633,7 +638,57 @@ extern "C" int mtq_greedy_run(const double *stats, int64_t tiles, uint32_t fmt_m
     return rc;
 }
 
-// mtq_greedy_run over `count` equally sized tensors on `n_threads` host threads (tensors are independent).
+// Process-wide pool of scan threads.  The streamed driver calls mtq_greedy_run_batch once per chunk of tensors, a few
+// calls in flight at a time; spawning and joining a thread per worker per call cost about as much as scanning a tensor
+// (≈ 0.35 ms per call with 8–16 workers), so the threads are created once, sleep on a condition variable between
+// batches and are never joined (the singleton is leaked on purpose: no destructor runs at process exit).
+namespace {
+class ScanPool {
+public:
+    static ScanPool &instance() { static ScanPool *p = new ScanPool(); return *p; }
+    void ensure(int n)
+    {
+        std::lock_guard<std::mutex> lock(mu_);
+        while ((int)threads_ < n) { std::thread([this] { loop(); }).detach(); ++threads_; }
+    }
+    void submit(std::function<void()> fn)
+    {
+        { std::lock_guard<std::mutex> lock(mu_); queue_.push_back(std::move(fn)); }
+        cv_.notify_one();
+    }
+private:
+    void loop()
+    {
+        for (;;) {
+            std::function<void()> fn;
+            {
+                std::unique_lock<std::mutex> lock(mu_);
+                cv_.wait(lock, [this] { return !queue_.empty(); });
+                fn = std::move(queue_.front());
+                queue_.pop_front();
+            }
+            fn();
+        }
+    }
+    std::mutex mu_;
+    std::condition_variable cv_;
+    std::deque<std::function<void()>> queue_;
+    size_t threads_ = 0;
+};
+
+struct BatchState {
+    std::atomic<int64_t> next{0};
+    std::atomic<int> first_error{MTQ_OK};
+    std::mutex mu;
+    std::condition_variable cv;
+    int active = 0;      // helpers inside work()
+    bool closed = false; // set by the caller once every tensor has been claimed: helpers that start later return at once
+    std::string message;
+};
+} // namespace
+
+// mtq_greedy_run over `count` equally sized tensors on up to `n_threads` host threads (tensors are independent): the
+// calling thread and n_threads − 1 pool threads pull tensor indices from a shared counter.
 extern "C" int mtq_greedy_run_batch(const double *stats, int64_t count, int64_t tiles, uint32_t fmt_mask, const int *formats,
                                     int n_formats, int metric, double threshold, double elem_count, const uint64_t *seeds,
                                     int8_t *maps, int64_t *counts, double *outs, int n_threads)
@@ -642,28 +697,43 @@ extern "C" int mtq_greedy_run_batch(const double *stats, int64_t count, int64_t 
     if (count <= 0 || tiles <= 0) return fail(MTQ_ERR_INVALID, "count and tiles must be positive");
     const int rec = 2 + 5 * popcount4(fmt_mask);
     const int nt = (int)std::max<int64_t>(1, std::min<int64_t>(n_threads, count));
-    std::atomic<int64_t> next(0);
-    std::atomic<int> first_error(MTQ_OK);
-    std::vector<std::string> msgs((size_t)nt);
-    auto work = [&](int tid) {
+    auto st = std::make_shared<BatchState>();
+    auto work = [=]() {
         for (;;) {
-            const int64_t i = next.fetch_add(1);
+            const int64_t i = st->next.fetch_add(1);
             if (i >= count) break;
             const int rc = mtq_greedy_run(stats + i * tiles * rec, tiles, fmt_mask, formats, n_formats, metric, threshold, elem_count,
                                           seeds[i], maps + i * tiles, counts ? counts + 4 * i : nullptr, outs ? outs + 9 * i : nullptr);
             if (rc != MTQ_OK) {
                 int expected = MTQ_OK;
-                if (first_error.compare_exchange_strong(expected, rc)) msgs[(size_t)tid] = mtq_last_error();
+                if (st->first_error.compare_exchange_strong(expected, rc)) {
+                    std::lock_guard<std::mutex> lock(st->mu);
+                    st->message = mtq_last_error();
+                }
             }
         }
     };
-    std::vector<std::thread> pool;
-    for (int t = 1; t < nt; ++t) pool.emplace_back(work, t);
-    work(0);
-    for (auto &th : pool) th.join();
-    if (first_error.load() != MTQ_OK) {
-        for (auto &m : msgs) if (!m.empty()) return fail(first_error.load(), m.c_str());
-        return fail(first_error.load(), "mtq_greedy_run_batch failed");
+    if (nt > 1) {
+        ScanPool &pool = ScanPool::instance();
+        pool.ensure(nt - 1);
+        for (int t = 1; t < nt; ++t)
+            pool.submit([st, work]() {
+                {
+                    std::lock_guard<std::mutex> lock(st->mu);
+                    if (st->closed) return;          // the batch finished before this helper got a thread: the buffers may be gone
+                    ++st->active;
+                }
+                work();
+                std::lock_guard<std::mutex> lock(st->mu);
+                if (--st->active == 0) st->cv.notify_all();
+            });
     }
+    work();                                           // returns when every tensor has been claimed
+    {
+        std::unique_lock<std::mutex> lock(st->mu);
+        st->closed = true;
+        st->cv.wait(lock, [&] { return st->active == 0; });
+    }
+    if (st->first_error.load() != MTQ_OK) return fail(st->first_error.load(), st->message.empty() ? "mtq_greedy_run_batch failed" : st->message.c_str());
     return MTQ_OK;
 }

@@ -9,7 +9,8 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 128
 workers = int(sys.argv[2]) if len(sys.argv) > 2 else 16
 hb.require_gpu()
 batch = bench.make_batch(n, 0, torch.device('cuda', 0))
-pipe = pl.GreedyPipeline(bench.FORMATS, bench.METRIC, bench.THRESHOLD, bench.SEED, chunk=16, workers=workers)
+chunk = int(sys.argv[3]) if len(sys.argv) > 3 else 16
+pipe = pl.GreedyPipeline(bench.FORMATS, bench.METRIC, bench.THRESHOLD, bench.SEED, chunk=chunk, workers=workers)
 for _ in range(2): pipe.run(batch)
 torch.cuda.synchronize()
 
