@@ -288,6 +288,38 @@ def test_full_size_parity_and_properties():
     assert np.array_equal(gl.view(np.uint64), orc.tile_stats(xl.float().numpy(), ["bfp8", "bfp4", "bfp2"]).view(np.uint64))
 
 
+def test_sparse_tensors_and_concurrent_streams():
+    """(1) Pruned weights: half of the shared-exponent groups, some whole tiles and one whole tensor are zero — zero groups
+    must not send tiles to the literal fix-up, and the records stay bit-identical.  (2) K1 launches racing on four streams
+    (each launch claims its units from its own slot of the device counter ring) give the same records as serial launches."""
+    rng = np.random.default_rng(17)
+    x = gen("normal_bf16", 9, (128, 512)).copy()
+    keep = rng.random((128, 32)) < 0.5
+    x *= np.repeat(keep, 16, axis=1)
+    x[32:64, 128:192] = 0.0
+    want = orc.tile_stats(x, ALL)
+    got = hb.tile_stats(dev(x, bf16=True), 0xF).cpu().numpy()
+    assert np.array_equal(got.view(np.uint64), want.view(np.uint64))
+    zeros = torch.zeros((64, 256), dtype=torch.bfloat16, device="cuda")
+    assert not hb.tile_stats(zeros, 0xF).cpu().numpy().any()
+    assert not hb.tile_stats(zeros.float(), 0xF).cpu().numpy().any()
+
+    xs = [dev(gen("heavy_bf16", 40 + i, (256, 512)), bf16=True) for i in range(4)]
+    xf = [dev(gen("heavy_f32", 50 + i, (160, 224))) for i in range(4)]
+    serial = [hb.tile_stats(t, 0xF).cpu().numpy() for t in xs + xf]
+    streams = [torch.cuda.Stream() for _ in range(4)]
+    outs = [None] * 8
+    torch.cuda.synchronize()
+    for rep in range(6):
+        for k, st in enumerate(streams):
+            with torch.cuda.stream(st):
+                outs[k] = hb.tile_stats(xs[k], 0xF)
+                outs[4 + k] = hb.tile_stats(xf[k], 0xF)
+        torch.cuda.synchronize()
+        for k in range(8):
+            assert np.array_equal(outs[k].cpu().numpy().view(np.uint64), serial[k].view(np.uint64)), (rep, k)
+
+
 def test_streamed_pipeline_matches_oracle():
     """GreedyPipeline (what bench.py times): chunked K1 launches, records over PCIe, threaded host scans.  bf16 storage takes
     the 17-double records + identity bf16 (MTQ_MASK_BF16_IDENTITY), float32 storage the full records; maps, counts and
