@@ -60,6 +60,29 @@ def cpu_baseline(sample: torch.Tensor) -> dict:
             "sample": f"{len(xs)} of the step's 4096x4096 bf16 tensors, oracle/mtq_oracle.c greedy (1 thread), {dt:.1f} s"}
 
 
+def cpu_budget() -> int:
+    """Hardware threads this process may really use: the cgroup CPU quota when there is one (a gpurun box shows 256
+    hardware threads but runs under a 16-CPU quota; exceeding a CFS quota stalls every thread of the job for the rest of
+    the 100 ms period), else the affinity mask."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(quota) // int(period)))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+def default_workers() -> int:
+    """Scan threads per rank: the rank's share of the CPU budget minus the driver's own threads (main + chunk tasks),
+    at most 32; MTQ_SCAN_WORKERS overrides."""
+    if "MTQ_SCAN_WORKERS" in os.environ:
+        return int(os.environ["MTQ_SCAN_WORKERS"])
+    local = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")))
+    return max(4, min(32, cpu_budget() // max(local, 1) - 3))
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -67,7 +90,7 @@ def main() -> None:
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--tensors", type=int, default=128, help="4096x4096 bf16 tensors per step per GPU (128 = 4 GiB, SURVEY §8(d) M1 stream)")
     ap.add_argument("--chunk", type=int, default=16, help="tensors per K1 launch")
-    ap.add_argument("--workers", type=int, default=int(os.environ.get("MTQ_SCAN_WORKERS", str(max(4, min(32, (os.cpu_count() or 64) // 16))))), help="host scan threads per rank (default: 1/16 of the host's hardware threads, i.e. one physical core each when 8 ranks share a 2-way-SMT node)")
+    ap.add_argument("--workers", type=int, default=default_workers(), help="host scan threads per rank (default: this rank's share of the cgroup CPU quota / affinity mask, minus the driver's threads, at most 32)")
     ap.add_argument("--cpu-sample", type=int, default=12, help="tensors timed on the CPU port (0 = skip)")
     args = ap.parse_args()
 
@@ -108,8 +131,7 @@ def main() -> None:
 
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        res = pipe.run(batch)
+    res = pipe.run_steps(batch for _ in range(args.steps))  # every step fully processed; step s+1's GPU work overlaps step s's scan tail
     barrier()
     dt = time.perf_counter() - t0
     pipe.timing.drain()

@@ -2,9 +2,9 @@
 
 A model's matched tensors are independent (reference wq:655 loop), so a rank streams its share:
   K1 (batched launch over a chunk of equally shaped tensors, HIP stream A)
-    → stats D2H into pinned host memory (stream A, event)
-    → per-tensor sequential greedy scan on host worker threads (C++ in libmtq_hip.so, GIL released)
-while the next chunk's K1 is already running.  y is not materialised here (assignment maps + pcc/mae/atol
+    → stats D2H into pinned host memory (stream B, event)
+    → per-tensor sequential greedy scan on host worker threads (C++ scan pool in libmtq_hip.so, GIL released)
+while the next chunk's K1 is already running; `run_steps` also overlaps consecutive batches (two record slots).  y is not materialised here (assignment maps + pcc/mae/atol
 are the outputs the north star names); use compression_algorithms.* for the drop-in run() that returns y.
 """
 from __future__ import annotations
@@ -79,19 +79,26 @@ class GreedyPipeline:
         self.copy_stream = torch.cuda.Stream()   # records D2H, overlapped with the next chunk's K1
         self.timing = KernelTiming()
         self._bufs = {}
+        self._open = []        # enqueued, not yet finished (oldest first)
+        self._next_slot = 0
 
-    def _buffers(self, count: int, tiles: int, rec: int, device):
-        """Records of a whole batch: device buffer + pinned host mirror (scans read the pinned memory in place)."""
-        key = (count, tiles, rec)
-        if key not in self._bufs:
+    def _buffers(self, slot: int, count: int, tiles: int, rec: int, device):
+        """Records of a whole batch: device buffer + pinned host mirror (scans read the pinned memory in place).  Two slots
+        alternate so that a batch can be on the GPU / the PCIe link while the previous one is still being scanned."""
+        key = (count, tiles, rec, str(device))
+        if self._bufs.get(slot, (None,))[0] != key:
             torch = self.torch
             dev = torch.empty((count, tiles, rec), dtype=torch.float64, device=device)
             host = torch.empty((count, tiles, rec), dtype=torch.float64, pin_memory=True)
-            self._bufs = {key: (dev, host, host.numpy())}
-        return self._bufs[key]
+            self._bufs[slot] = (key, dev, host, host.numpy())
+        return self._bufs[slot][1:]
 
-    def run(self, x3d, seeds=None) -> list[TensorResult]:
+    def enqueue(self, x3d, seeds=None) -> dict:
+        """GPU half of a batch, non-blocking: per chunk K1 on the launch stream and the records' D2H on the copy stream.
+        At most two batches may be enqueued and not yet finished (two record slots)."""
         torch = self.torch
+        if len(self._open) >= 2:
+            raise RuntimeError("finish() an enqueued batch before enqueuing a third one")
         count, rows, cols = x3d.shape
         th, tw = hb.tiles_hw(rows, cols)
         # bf16 storage: the bf16 candidate is the identity, its record slot would be [Σx, Σx², Σx², 0, 0]; K1 then writes
@@ -100,8 +107,9 @@ class GreedyPipeline:
         k1_mask = self.mask & 0xE if identity else self.mask
         host_mask = k1_mask | hb.MASK_BF16_IDENTITY if identity else self.mask
         tiles, rec = th * tw, hb.record_doubles(k1_mask)
-        numel = rows * cols
-        dev, host, host_np = self._buffers(count, tiles, rec, x3d.device)
+        slot = self._next_slot
+        self._next_slot ^= 1
+        dev, host, host_np = self._buffers(slot, count, tiles, rec, x3d.device)
         pending = []  # (event, first_index, n)
         self.stream.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(self.stream):
@@ -116,16 +124,52 @@ class GreedyPipeline:
                 self.copy_stream.wait_event(e1)
                 with torch.cuda.stream(self.copy_stream):
                     host[first:first + n].copy_(dev[first:first + n], non_blocking=True)
-                    done = torch.cuda.Event()
+                    done = torch.cuda.Event(blocking=True)   # the driver thread sleeps while it waits: spinning would burn a core of the scan budget
                     done.record(self.copy_stream)
                 pending.append((done, first, n))
+        enq = {"pending": pending, "host_np": host_np, "host_mask": host_mask, "tiles_hw": (th, tw), "numel": rows * cols,
+               "seeds": seeds, "x": x3d}
+        self._open.append(enq)
+        return enq
+
+    def finish(self, enq: dict) -> list[TensorResult]:
+        """Host half: as each chunk's records land, its scans go to the scan pool; returns when all of them are done.
+        The GPU meanwhile works on whatever was enqueued after this batch."""
+        if not self._open or self._open[0] is not enq:
+            raise RuntimeError("batches finish in the order they were enqueued")
         futures = []
-        for evt, first, n in pending:      # scans of chunk k run while chunks k+1.. are still on the GPU / the PCIe link
+        for evt, first, n in enq["pending"]:
             evt.synchronize()
+            seeds = enq["seeds"]
             sd = [self.seed] * n if seeds is None else [int(v) for v in seeds[first:first + n]]
-            futures.append(self.pool.submit(_scan_chunk, first, host_np[first:first + n], host_mask, (th, tw), numel, self.tile_formats,
-                                            self.metric, self.threshold, sd, self.workers))
+            futures.append(self.pool.submit(_scan_chunk, first, enq["host_np"][first:first + n], enq["host_mask"], enq["tiles_hw"],
+                                            enq["numel"], self.tile_formats, self.metric, self.threshold, sd, self.workers))
         results = [r for f in futures for r in f.result()]
+        self._open.pop(0)
+        enq["x"] = None
+        return results
+
+    def run(self, x3d, seeds=None) -> list[TensorResult]:
+        """One batch, start to end (enqueue + finish)."""
+        torch = self.torch
+        results = self.finish(self.enqueue(x3d, seeds))
+        torch.cuda.current_stream().wait_stream(self.stream)
+        torch.cuda.current_stream().wait_stream(self.copy_stream)
+        return results
+
+    def run_steps(self, batches) -> list[TensorResult]:
+        """A sequence of batches with the next batch's GPU work enqueued before the current batch's scans are collected
+        (the first chunk's latency and the last chunk's scan tail of every batch hide behind its neighbours).  Returns the
+        LAST batch's results; every batch is fully processed."""
+        torch = self.torch
+        results, prev = [], None
+        for x3d in batches:
+            cur = self.enqueue(x3d)
+            if prev is not None:
+                results = self.finish(prev)
+            prev = cur
+        if prev is not None:
+            results = self.finish(prev)
         torch.cuda.current_stream().wait_stream(self.stream)
         torch.cuda.current_stream().wait_stream(self.copy_stream)
         return results

@@ -342,6 +342,21 @@ def test_streamed_pipeline_matches_oracle():
             pcc, mae, atol = orc.columns_from_stats(st["stats"], orc.mask_slots(0xF), a, xs[i].size)
             assert (r.pcc, r.mae, r.atol) == (pcc, mae, atol), (kind, i)
             assert np.array_equal(res2[i].assignment, a)
+    # overlapped batches (two record slots): the last batch's results, each batch its own tensors
+    b1 = dev(np.stack([gen("normal_bf16", 70 + i, (128, 256)) for i in range(4)]), bf16=True)
+    b2x = np.stack([gen("heavy_bf16", 80 + i, (128, 256)) for i in range(4)])
+    pipe = GreedyPipeline(ALL, "pcc", 0.998, 123, chunk=3, workers=2)
+    try:
+        last = pipe.run_steps([b1, dev(b2x, bf16=True), b1, dev(b2x, bf16=True)])
+        with pytest.raises(RuntimeError):
+            e1, e2 = pipe.enqueue(b1), pipe.enqueue(b1)
+            pipe.enqueue(b1)
+        pipe.finish(e1), pipe.finish(e2)
+    finally:
+        pipe.close()
+    for i, r in enumerate(last):
+        a, counts, _st = orc.greedy(b2x[i], ALL, "pcc", 0.998, 123)
+        assert np.array_equal(r.assignment, a) and r.counts == counts, i
 
 
 def test_fast_kernel_strided_view_and_batch_stride():

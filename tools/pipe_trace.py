@@ -30,3 +30,14 @@ for rep in range(3):
     for kind, first, a, b in sorted(marks, key=lambda m: m[2]):
         print(f"   {kind:5s} {'' if first is None else first:>4} start {(a-T0)*1e3:7.2f}  end {(b-T0)*1e3:7.2f}  dur {(b-a)*1e3:6.2f}")
 pipe.close()
+
+# overlapped steps (run_steps): scans of batch s against the GPU work of batch s+1
+pipe = pl.GreedyPipeline(bench.FORMATS, bench.METRIC, bench.THRESHOLD, bench.SEED, chunk=chunk, workers=workers)
+pipe.run_steps(batch for _ in range(2))
+torch.cuda.synchronize()
+marks.clear()
+T0 = time.perf_counter(); pipe.run_steps(batch for _ in range(4)); torch.cuda.synchronize(); T1 = time.perf_counter()
+print(f"run_steps x4: {(T1-T0)*1e3:.2f} ms  ({(T1-T0)*1e3/4:.2f} ms/step)")
+for kind, first, a, b in sorted(marks, key=lambda m: m[2]):
+    print(f"   {kind:5s} {'' if first is None else first:>4} start {(a-T0)*1e3:7.2f}  end {(b-T0)*1e3:7.2f}  dur {(b-a)*1e3:6.2f}")
+pipe.close()
