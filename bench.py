@@ -124,8 +124,8 @@ def main() -> None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        res = pipe.run(batch)
+    pipe.reserve(batch)  # record buffers of both slots + scan threads: allocations, not steps
+    res = pipe.run_steps(batch for _ in range(args.warmup))
     pipe.timing.drain()
     pipe.timing.__init__()
 

@@ -93,6 +93,19 @@ class GreedyPipeline:
             self._bufs[slot] = (key, dev, host, host.numpy())
         return self._bufs[slot][1:]
 
+    def reserve(self, x3d) -> None:
+        """Allocate both record slots (device + pinned host) for batches shaped like x3d and start the scan threads, so that
+        no allocation or thread creation lands in a timed region."""
+        torch = self.torch
+        count, rows, cols = x3d.shape
+        th, tw = hb.tiles_hw(rows, cols)
+        identity = x3d.dtype == torch.bfloat16 and (self.mask & 1) and (self.mask & 0xE)
+        rec = hb.record_doubles(self.mask & 0xE if identity else self.mask)
+        for slot in (0, 1):
+            self._buffers(slot, count, th * tw, rec, x3d.device)[1].zero_()   # touch the pinned pages
+        hb.greedy_run_batch(np.zeros((self.workers, 1, hb.record_doubles(0xF))), 0xF, ["bf16"], self.metric, self.threshold, 1024.0,
+                            [1] * self.workers, self.workers)
+
     def enqueue(self, x3d, seeds=None) -> dict:
         """GPU half of a batch, non-blocking: per chunk K1 on the launch stream and the records' D2H on the copy stream.
         At most two batches may be enqueued and not yet finished (two record slots)."""
