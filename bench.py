@@ -60,6 +60,19 @@ def cpu_baseline(sample: torch.Tensor) -> dict:
             "sample": f"{len(xs)} of the step's 4096x4096 bf16 tensors, oracle/mtq_oracle.c greedy (1 thread), {dt:.1f} s"}
 
 
+def gather_summary(rows: torch.Tensor, seconds: float, dist, rank: int, world: int):
+    """The job's only data-path collective: every rank's fixed-width float64 summary rows to rank 0, and the
+    MAX over ranks of the timed region.  → (all rows as ndarray on rank 0 else None, max seconds).  Works on any backend
+    (RCCL for the GPU job, gloo in the CPU test)."""
+    t_max = torch.tensor([seconds], dtype=torch.float64, device=rows.device)
+    if dist is None:
+        return rows.cpu().numpy(), seconds
+    gathered = [torch.empty_like(rows) for _ in range(world)] if rank == 0 else None
+    dist.gather(rows, gathered, dst=0)
+    dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
+    return (torch.cat(gathered).cpu().numpy() if rank == 0 else None), float(t_max.item())
+
+
 def cpu_budget() -> int:
     """Hardware threads this process may really use: the cgroup CPU quota when there is one (a gpurun box shows 256
     hardware threads but runs under a 16-CPU quota; exceeding a CFS quota stalls every thread of the job for the rest of
@@ -140,15 +153,7 @@ def main() -> None:
     # the rows of the LAST step are gathered so the multi-GPU path is exercised end to end.
     rows = torch.tensor([[r.index, ROWS * COLS, r.pcc, r.mae, r.atol, r.tile_bytes, r.counts["bf16"], r.counts["bfp8"],
                           r.counts["bfp4"], r.counts["bfp2"], 0.0] for r in res], dtype=torch.float64, device=device)
-    t_max = torch.tensor([dt], dtype=torch.float64, device=device)
-    if dist is not None:
-        gathered = [torch.empty_like(rows) for _ in range(world)] if rank == 0 else None
-        dist.gather(rows, gathered, dst=0)
-        dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
-        all_rows = torch.cat(gathered).cpu().numpy() if rank == 0 else None
-    else:
-        all_rows = rows.cpu().numpy()
-    dt = float(t_max.item())
+    all_rows, dt = gather_summary(rows, dt, dist, rank, world)
 
     if rank == 0:
         kt = pipe.timing

@@ -159,6 +159,36 @@ def test_wq_two_ranks_gloo_matches_single_process(tmp_path):
         assert np.array_equal(np.load(d1 / rel), np.load(d2 / rel)), rel
 
 
+def test_bench_gather_two_ranks_gloo(tmp_path):
+    """bench.py's multi-rank tail (one gather of summary rows + MAX of the timed region) on a world_size-2 gloo job."""
+    script = tmp_path / "g.py"
+    script.write_text(
+        "import os, sys, json\n"
+        f"sys.path.insert(0, {str(ROOT)!r})\n"
+        "import torch, torch.distributed as dist\n"
+        "import bench\n"
+        "dist.init_process_group('gloo')\n"
+        "rank, world = dist.get_rank(), dist.get_world_size()\n"
+        "rows = torch.full((3, 11), float(rank), dtype=torch.float64); rows[:, 0] = torch.arange(3) + 10 * rank\n"
+        "allr, dt = bench.gather_summary(rows, 1.0 + rank, dist, rank, world)\n"
+        "assert dt == 2.0\n"
+        "if rank == 0:\n"
+        "    assert allr.shape == (6, 11) and allr[:, 0].tolist() == [0, 1, 2, 10, 11, 12] and allr[3:, 1].tolist() == [1, 1, 1]\n"
+        "    print('GATHER_OK')\n"
+        "else:\n"
+        "    assert allr is None\n"
+        "dist.barrier(); dist.destroy_process_group()\n")
+    env = dict(os.environ, PYTHONPATH=str(ROOT), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(_free_port()), str(script)], cwd=tmp_path, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "GATHER_OK" in r.stdout, r.stderr[-2000:]
+    import bench
+
+    assert bench.cpu_budget() >= 1 and bench.default_workers() >= 4
+    lone, dt = bench.gather_summary(__import__("torch").ones((2, 11), dtype=__import__("torch").float64), 0.5, None, 0, 1)
+    assert lone.shape == (2, 11) and dt == 0.5
+
+
 @pytest.mark.gpu
 def test_wq_hip_backend(tmp_path, monkeypatch):
     monkeypatch.chdir(tmp_path)

@@ -58,6 +58,34 @@ def test_sweep_script_cli(tmp_path):
     assert r.returncode == 0 and "Matched 5 tensor(s)" in r.stdout
 
 
+def test_sweep_script_two_ranks_gloo(tmp_path):
+    """The sweep under torch.distributed.run with 2 CPU ranks (gloo): tensors are sharded over the ranks, every rank writes
+    the CSVs of its tensors, the Pareto frontiers are gathered to rank 0 for the overlay figures; same CSVs as one process."""
+    import os
+    import socket
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    script = str(ROOT / "scripts" / "sweep_mixed_tile_threshold.py")
+    common = ["synthetic:tiny", "layers", "--steps", "5", "--lowest-metric-val", "0.95"]
+    env = dict(os.environ, PYTHONPATH=str(ROOT), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    one = subprocess.run([sys.executable, script, *common, "--out-dir", str(tmp_path / "one")], capture_output=True, text=True, timeout=600, env=env)
+    assert one.returncode == 0, one.stderr[-2000:]
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", str(port), script, *common, "--out-dir", str(tmp_path / "two")],
+                         capture_output=True, text=True, timeout=600, env=env)
+    assert two.returncode == 0, two.stderr[-2000:]
+    csv1 = sorted(p.relative_to(tmp_path / "one").as_posix() for p in (tmp_path / "one").rglob("sweep_results.csv"))
+    csv2 = sorted(p.relative_to(tmp_path / "two").as_posix() for p in (tmp_path / "two").rglob("sweep_results.csv"))
+    assert csv1 == csv2 and len(csv1) == 5
+    for rel in csv1:
+        assert (tmp_path / "one" / rel).read_text() == (tmp_path / "two" / rel).read_text(), rel
+    assert (tmp_path / "two" / "weight_overlays.png").exists() and (tmp_path / "two" / "layer_overlays.png").exists()
+    assert "[rank 1]" in two.stdout and "[rank 0]" in two.stdout
+
+
 def test_reconstruct_script(tmp_path):
     from oracle import mtq_oracle as orc
     from quantization_analysis_amd import model_source
