@@ -199,44 +199,62 @@ __global__ __launch_bounds__(256) void dequant_fp8_scalar(const uint8_t *__restr
 
 // ---------------------------------------------------------------------------------------------
 // K2 / K3, coalesced form: one lane per 4 elements — 8-byte (bf16) or 16-byte (fp32) loads and 16-byte
-// stores, every wave instruction touching one contiguous 512 B / 1 KiB span; the 4 lanes of a
-// shared-exponent group agree on the exponent with two DPP-class lane exchanges.  Needs cols % 16 == 0
-// and 16-byte aligned rows; anything else takes quantize_groups.
+// stores, every wave instruction touching one contiguous 512 B / 1 KiB span; rows on blockIdx.y (no per-thread
+// division); the 4 lanes of a shared-exponent group agree on the exponent with two lane exchanges.
+// BFP values come from the float-domain form of the reference's rounding (mtq_direct.hip): truncate x to the group's
+// 24-bit window (scale, v_trunc, scale back), add and subtract C = 1.5·2^(E−103−M) — RNE to the format's step, ties to
+// the even multiple — and clamp to ±(2^M − 1) steps; the result IS the float the reference assembles from sign, exp_out
+// and shifted mantissa whenever 24 <= E <= 231 (every constant normal, no exponent wrap).  Groups outside that range
+// (denormal-only, Inf/NaN, huge) take the literal uint32 route; the two agree bit for bit on the F1/F2 vectors.
+// Needs cols % 16 == 0 and 16-byte aligned rows; anything else takes quantize_groups.
 // ---------------------------------------------------------------------------------------------
 template <typename T>
-__global__ __launch_bounds__(256) void quantize_quads(const T *__restrict__ x, int64_t rows, int64_t cols, int64_t ld, int quads_w,
-                                                      int tiles_w, int fmt, const int8_t *__restrict__ map,
-                                                      float *__restrict__ y, int64_t ldy)
+__global__ __launch_bounds__(256) void quantize_quads(const T *__restrict__ x, int64_t rows, uint32_t cols, int64_t ld, int tiles_w,
+                                                      int fmt, const int8_t *__restrict__ map, float *__restrict__ y, int64_t ldy)
 {
-    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t row = q / quads_w;
-    const bool live = row < rows;                                        // the whole group is live or not (cols % 16 == 0)
-    const int64_t col0 = live ? (q - row * quads_w) * 4 : 0;
-    uint32_t u[4] = {0u, 0u, 0u, 0u};
-    if (live) {
-        if constexpr (sizeof(T) == 2) {
-            const uint2 v = *reinterpret_cast<const uint2 *>(x + row * ld + col0);
-            u[0] = v.x << 16; u[1] = v.x & 0xFFFF0000u; u[2] = v.y << 16; u[3] = v.y & 0xFFFF0000u;
-        } else {
-            const uint4 v = *reinterpret_cast<const uint4 *>(x + row * ld + col0);
-            u[0] = v.x; u[1] = v.y; u[2] = v.z; u[3] = v.w;
+    const uint32_t col0 = (blockIdx.x * 256u + threadIdx.x) * 4u;
+    const bool live = col0 < cols;                                       // the whole group is live or not (cols % 16 == 0)
+    for (int64_t row = blockIdx.y; row < rows; row += gridDim.y) {
+        uint32_t u[4] = {0u, 0u, 0u, 0u};
+        if (live) {
+            if constexpr (sizeof(T) == 2) {
+                const uint2 v = *reinterpret_cast<const uint2 *>(x + row * ld + col0);
+                u[0] = v.x << 16; u[1] = v.x & 0xFFFF0000u; u[2] = v.y << 16; u[3] = v.y & 0xFFFF0000u;
+            } else {
+                const uint4 v = *reinterpret_cast<const uint4 *>(x + row * ld + col0);
+                u[0] = v.x; u[1] = v.y; u[2] = v.z; u[3] = v.w;
+            }
         }
+        uint32_t m = max(max(u[0] & 0x7F800000u, u[1] & 0x7F800000u), max(u[2] & 0x7F800000u, u[3] & 0x7F800000u));
+        m = max(m, (uint32_t)__shfl_xor((int)m, 1, 64));                 // lanes 4k..4k+3 hold one group
+        m = max(m, (uint32_t)__shfl_xor((int)m, 2, 64));
+        if (!live) continue;
+        const uint32_t shared = m >> 23;
+        const int f = fmt >= 0 ? fmt : (int)map[(row / kTile) * tiles_w + col0 / kTile];   // K2: launch-wide; K3: the tile's own
+        uint4 o;
+        if (f == 0) {                                                    // bf16: RNE on the raw word (:29-45), no group state
+            o = make_uint4(bf16_round_bits(u[0]), bf16_round_bits(u[1]), bf16_round_bits(u[2]), bf16_round_bits(u[3]));
+        } else if (f >= 1 && f <= 3 && shared - 24u <= 207u) {           // BFP, exponent in the float-domain range
+            const uint32_t M = f == 1 ? 7u : (f == 2 ? 3u : 1u);
+            const float k_align = __uint_as_float((277u - shared) << 23), k_back = __uint_as_float((shared - 23u) << 23);
+            const float C = __uint_as_float(((shared + 24u - M) << 23) | 0x400000u);
+            const float ymax = __uint_as_float((shared + 1u) << 23) - __uint_as_float((shared + 1u - M) << 23); // (2^M − 1)·2^(E−127−(M−1))
+            uint32_t r[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float xs = __builtin_truncf(__uint_as_float(u[i]) * k_align) * k_back;
+                r[i] = __float_as_uint(__builtin_amdgcn_fmed3f((xs + C) - C, -ymax, ymax));
+            }
+            o = make_uint4(r[0], r[1], r[2], r[3]);
+        } else if (fmt >= 0) {
+            o.x = quant_elem_bits(f, u[0], shared); o.y = quant_elem_bits(f, u[1], shared);
+            o.z = quant_elem_bits(f, u[2], shared); o.w = quant_elem_bits(f, u[3], shared);
+        } else {
+            o.x = quant_elem_bits_mixed(f, u[0], shared); o.y = quant_elem_bits_mixed(f, u[1], shared);
+            o.z = quant_elem_bits_mixed(f, u[2], shared); o.w = quant_elem_bits_mixed(f, u[3], shared);
+        }
+        *reinterpret_cast<uint4 *>(y + row * ldy + col0) = o;
     }
-    uint32_t m = max(max(u[0] & 0x7F800000u, u[1] & 0x7F800000u), max(u[2] & 0x7F800000u, u[3] & 0x7F800000u));
-    m = max(m, (uint32_t)__shfl_xor((int)m, 1, 64));                     // lanes 4k..4k+3 hold one group
-    m = max(m, (uint32_t)__shfl_xor((int)m, 2, 64));
-    if (!live) return;
-    const uint32_t shared = m >> 23;
-    uint4 o;
-    if (fmt >= 0) { // K2: one format for the whole launch (uniform branch)
-        o.x = quant_elem_bits(fmt, u[0], shared); o.y = quant_elem_bits(fmt, u[1], shared);
-        o.z = quant_elem_bits(fmt, u[2], shared); o.w = quant_elem_bits(fmt, u[3], shared);
-    } else {        // K3: the tile's own format, evaluated without divergence
-        const int f = map[(row / kTile) * tiles_w + col0 / kTile];
-        o.x = quant_elem_bits_mixed(f, u[0], shared); o.y = quant_elem_bits_mixed(f, u[1], shared);
-        o.z = quant_elem_bits_mixed(f, u[2], shared); o.w = quant_elem_bits_mixed(f, u[3], shared);
-    }
-    *reinterpret_cast<uint4 *>(y + row * ldy + col0) = o;
 }
 
 static bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
@@ -369,14 +387,13 @@ static int launch_quantize(const void *x, int in_dtype, int64_t rows, int64_t co
     const int vec_ok_y = aligned16(y) && (ldy * 4) % 16 == 0;
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (vec_ok && vec_ok_y && cols % kGroup == 0 && (in_dtype == MTQ_DTYPE_F32 || aligned16(x))) { // coalesced quad form
-        const int64_t qw = cols / 4, quads = rows * qw;
-        const int64_t qblocks = (quads + 255) / 256;
+        const dim3 qgrid((unsigned)((cols + 1023) / 1024), (unsigned)(rows < 65535 ? rows : 65535));
         if (in_dtype == MTQ_DTYPE_BF16)
-            hipLaunchKernelGGL(quantize_quads<uint16_t>, dim3((unsigned)qblocks), dim3(256), 0, s, static_cast<const uint16_t *>(x), rows, cols,
-                               ld, (int)qw, (int)tw, fmt, map, y, ldy);
+            hipLaunchKernelGGL(quantize_quads<uint16_t>, qgrid, dim3(256), 0, s, static_cast<const uint16_t *>(x), rows, (uint32_t)cols, ld,
+                               (int)tw, fmt, map, y, ldy);
         else
-            hipLaunchKernelGGL(quantize_quads<float>, dim3((unsigned)qblocks), dim3(256), 0, s, static_cast<const float *>(x), rows, cols, ld,
-                               (int)qw, (int)tw, fmt, map, y, ldy);
+            hipLaunchKernelGGL(quantize_quads<float>, qgrid, dim3(256), 0, s, static_cast<const float *>(x), rows, (uint32_t)cols, ld, (int)tw,
+                               fmt, map, y, ldy);
         return check_launch(what);
     }
     const int64_t blocks = (groups + 255) / 256;
