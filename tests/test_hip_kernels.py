@@ -56,6 +56,39 @@ def test_quantize_layouts(golden_dir):
             assert np.array_equal(y.view(np.uint32), want.view(np.uint32)), (name, fmt)
 
 
+def test_quantize_exponent_range_borders():
+    """K2/K3's float-domain rounding applies for shared exponents 24..231 and the literal uint32 route outside: groups
+    sitting on both sides of both borders, wide in-group spreads, exact ties and saturating values — y bits equal the
+    oracle's for every format, through K2 (one format) and K3 (a map mixing all four)."""
+    rng = np.random.default_rng(23)
+    rows = []
+    for e in (1, 2, 7, 22, 23, 24, 25, 26, 60, 127, 200, 229, 230, 231, 232, 233, 253, 254):
+        for rep in range(2):
+            man = (1.0 + rng.random(16)).astype(np.float32)
+            spread = rng.integers(0, 26, size=16)
+            spread[rng.integers(0, 16)] = 0                      # one element carries the shared exponent
+            sign = np.where(rng.random(16) < 0.5, -1.0, 1.0)
+            g = np.ldexp(man * sign, (e - 127) - spread).astype(np.float32)
+            if rep:                                               # ties / saturation / zeros inside the group
+                g[1] = np.ldexp(np.float32(1.9999999), e - 127)
+                g[2] = np.ldexp(np.float32(1.5), e - 127 - 7)
+                g[3] = 0.0
+                g[4] = np.ldexp(np.float32(-1.0078125), e - 127)
+            rows.append(g)
+    with np.errstate(all="ignore"):
+        x = np.stack(rows).astype(np.float32).reshape(-1, 16)
+        x = np.tile(x, (1, 2))                                    # 32 columns: one tile wide, 36 rows
+        want = {f: orc.quantize_weight_values(x, f).view(np.uint32) for f in ALL}
+    for f in ALL:
+        assert np.array_equal(bits(hb.quantize(dev(x), f)), want[f]), f
+    amap = rng.integers(0, 4, size=(2, 1)).astype(np.int8)
+    amap[0, 0], amap[1, 0] = 1, 3
+    y = bits(hb.apply_assignment(dev(x), amap))
+    for tr in range(2):
+        sl = slice(32 * tr, min(32 * (tr + 1), x.shape[0]))
+        assert np.array_equal(y[sl], want[ALL[int(amap[tr, 0])]][sl]), tr
+
+
 @pytest.mark.parametrize("kind,shape", [
     ("normal_bf16", (256, 256)), ("heavy_bf16", (192, 160)), ("normal_f32", (130, 200)), ("heavy_f32", (50, 70)),
     ("heavy_f32", (33, 17)), ("normal_f32", (1, 1)), ("heavy_bf16", (257, 95)), ("normal_bf16", (64, 4096)),
