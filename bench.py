@@ -88,12 +88,12 @@ def cpu_budget() -> int:
 
 
 def default_workers() -> int:
-    """Scan threads per rank: the rank's share of the CPU budget minus the driver's own threads (main + chunk tasks),
-    at most 32; MTQ_SCAN_WORKERS overrides."""
+    """Scan threads per rank: the rank's share of the CPU budget (the driver's own threads mostly sleep), at most 32;
+    MTQ_SCAN_WORKERS overrides."""
     if "MTQ_SCAN_WORKERS" in os.environ:
         return int(os.environ["MTQ_SCAN_WORKERS"])
     local = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")))
-    return max(4, min(32, cpu_budget() // max(local, 1) - 3))
+    return max(4, min(32, cpu_budget() // max(local, 1)))
 
 
 def main() -> None:
@@ -103,7 +103,7 @@ def main() -> None:
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--tensors", type=int, default=128, help="4096x4096 bf16 tensors per step per GPU (128 = 4 GiB, SURVEY §8(d) M1 stream)")
     ap.add_argument("--chunk", type=int, default=16, help="tensors per K1 launch")
-    ap.add_argument("--workers", type=int, default=default_workers(), help="host scan threads per rank (default: this rank's share of the cgroup CPU quota / affinity mask, minus the driver's threads, at most 32)")
+    ap.add_argument("--workers", type=int, default=default_workers(), help="host scan threads per rank (default: this rank's share of the cgroup CPU quota / affinity mask, at most 32)")
     ap.add_argument("--cpu-sample", type=int, default=24, help="tensors timed on the CPU port, ~0.5 s each (0 = skip)")
     args = ap.parse_args()
 
@@ -142,6 +142,12 @@ def main() -> None:
     pipe.timing.drain()
     pipe.timing.__init__()
 
+    # a generation-2 collection of the interpreter's heap (torch's module graph: ~40 ms here) would land inside a 7 ms
+    # step every few dozen steps: collect now and move what exists to the permanent generation
+    import gc
+
+    gc.collect()
+    gc.freeze()
     barrier()
     t0 = time.perf_counter()
     res = pipe.run_steps(batch for _ in range(args.steps))  # every step fully processed; step s+1's GPU work overlaps step s's scan tail

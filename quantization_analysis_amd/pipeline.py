@@ -102,7 +102,10 @@ class GreedyPipeline:
         identity = x3d.dtype == torch.bfloat16 and (self.mask & 1) and (self.mask & 0xE)
         rec = hb.record_doubles(self.mask & 0xE if identity else self.mask)
         for slot in (0, 1):
-            self._buffers(slot, count, th * tw, rec, x3d.device)[1].zero_()   # touch the pinned pages
+            dev, host, _np = self._buffers(slot, count, th * tw, rec, x3d.device)
+            dev.zero_()
+            host.copy_(dev, non_blocking=True)   # first DMA into the pinned pages (mappings are set up lazily)
+        torch.cuda.synchronize()
         hb.greedy_run_batch(np.zeros((self.workers, 1, hb.record_doubles(0xF))), 0xF, ["bf16"], self.metric, self.threshold, 1024.0,
                             [1] * self.workers, self.workers)
 
