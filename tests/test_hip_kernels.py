@@ -271,6 +271,41 @@ def test_direct_kernel_mid_size_f32_and_batched():
         assert np.array_equal(got[i].view(np.uint64), orc.tile_stats(xs[i], ALL).view(np.uint64)), i
 
 
+def test_direct_kernel_full_size_properties():
+    """A DeepSeek-R1 layer-0 shape at full size (q_b_proj 24576 x 1536, float32 after the fp8 x scale dequantisation;
+    BASELINE.json configs[2]): size-independent properties of the float32 route — checksum of checksums, power-of-two
+    homogeneity bit for bit, row-block independence, batched == single — plus the oracle on a 1024-row crop."""
+    g = torch.Generator().manual_seed(3)
+    rows, cols = 24576, 1536
+    m, e = torch.frexp(torch.randn((rows, cols), generator=g))
+    base = torch.ldexp(torch.round(m * 16) / 16, e)                          # fp8-e4m3-like significands
+    scale = torch.exp(torch.randn((rows // 128, cols // 128), generator=g)) * 0.01
+    x = (base * scale.repeat_interleave(128, 0).repeat_interleave(128, 1)).float().contiguous()
+    xd = x.cuda()
+    got = hb.tile_stats(xd, 0xF).cpu().numpy()
+    assert got.shape == (rows // 32 * (cols // 32), 22) and not np.isnan(got).any()
+    x64 = x.double()
+    assert abs(got[:, 0].sum() - float(x64.sum())) <= 1e-9 * float(x64.abs().sum())
+    assert abs(got[:, 1].sum() - float((x64 * x64).sum())) <= 1e-7 * float((x64 * x64).sum())   # each x*x is a float32 product
+    crop = x[4096:5120].numpy()
+    th = cols // 32
+    want = orc.tile_stats(crop, ALL)
+    assert np.array_equal(got[128 * th:160 * th].view(np.uint64), want.view(np.uint64))   # tile rows 128..159 = rows 4096..5119
+    got4 = hb.tile_stats(xd * 4.0, 0xF).cpu().numpy()                        # x·2^k is exact: moments scale by 2^k / 4^k
+    sc = np.ones(22)
+    sc[[0, 2, 5, 6, 7, 10, 11, 12, 15, 16, 17, 20, 21]] = 4.0
+    sc[[1, 3, 4, 8, 9, 13, 14, 18, 19]] = 16.0
+    assert np.array_equal(got4, got * sc)
+    xs = xd.clone()
+    xs[0:32], xs[320:352] = xd[320:352], xd[0:32]                             # swap two tile rows: their records swap
+    gs = hb.tile_stats(xs, 0xF).cpu().numpy().reshape(rows // 32, th, 22)
+    g0 = got.reshape(rows // 32, th, 22)
+    assert np.array_equal(gs[0], g0[10]) and np.array_equal(gs[10], g0[0]) and np.array_equal(gs[11:], g0[11:])
+    gb = hb.tile_stats_batched(torch.stack([xd[:2048], xs[:2048]]), 0xE).cpu().numpy()
+    assert np.array_equal(gb[0], hb.tile_stats(xd[:2048], 0xE).cpu().numpy())
+    assert np.array_equal(gb[1], hb.tile_stats(xs[:2048], 0xE).cpu().numpy())
+
+
 def test_fast_and_generic_kernels_agree_batched():
     xs = np.stack([gen("normal_bf16", s, (64, 256)) for s in range(6)])
     got = hb.tile_stats_batched(dev(xs, bf16=True), 0xF).cpu().numpy()
