@@ -116,6 +116,9 @@ def main() -> None:
         raise SystemExit("bench.py needs an MI355X; there is no CPU fallback")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
+    from quantization_analysis_amd.hip_backend import bind_to_gpu_numa_node
+
+    numa = bind_to_gpu_numa_node(local_rank)
     dist = None
     if "RANK" in os.environ:  # launched by torch.distributed.run (any N, also N = 1): one process per GPU over RCCL
         import torch.distributed as dist
@@ -184,7 +187,7 @@ def main() -> None:
             "config": {"workload": f"{args.tensors} x 4096x4096 bf16 N(0,0.02^2) per GPU per step, mixed-tile-greedy "
                                    f"{{bf16,bfp8,bfp4,bfp2}} pcc>=0.999 seed 123 (BASELINE.json configs[1], streamed)",
                        "tensors_per_step_per_gpu": args.tensors, "tiles_per_step_per_gpu": tiles_per_step,
-                       "k1_chunk": args.chunk, "scan_workers": args.workers, "sharding": f"tensors x{world}, RCCL gather of summary rows"},
+                       "k1_chunk": args.chunk, "scan_workers": args.workers, "numa_bind": numa, "sharding": f"tensors x{world}, RCCL gather of summary rows"},
             "roofline": {"bound": "hbm", "kernel": "tile_stats (K1)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "launch_ms": k_ms, "tiles_per_launch": tiles_per_launch, "launches": kt.launches,

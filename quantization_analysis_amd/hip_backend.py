@@ -119,6 +119,40 @@ def mask_formats(mask: int) -> list[str]:
 MASK_BF16_IDENTITY = 0x10  # include/mtq.h MTQ_MASK_BF16_IDENTITY (host functions only)
 
 
+def parse_cpulist(text: str) -> set:
+    """'0-63,128-191' (sysfs cpulist) → set of CPU numbers."""
+    cpus = set()
+    for part in text.strip().split(","):
+        if part:
+            lo, _, hi = part.partition("-")
+            cpus.update(range(int(lo), int(hi or lo) + 1))
+    return cpus
+
+
+def bind_to_gpu_numa_node(device_index: int) -> str:
+    """Restrict this process (and the threads it creates later: scan pool, pinned-memory allocation) to the CPUs of the NUMA
+    node its GPU hangs off, read from sysfs through the device's PCI address.  The records are DMA-written into pinned host
+    memory and then read by the scan threads: on a two-socket host both want that memory on the GPU's socket.  Returns a
+    short description; does nothing (and says so) when the topology cannot be read.  MTQ_NUMA_BIND=0 disables it."""
+    if os.environ.get("MTQ_NUMA_BIND", "1") == "0" or not hasattr(os, "sched_setaffinity"):
+        return "off"
+    try:
+        p = _torch().cuda.get_device_properties(device_index)
+        bdf = f"{p.pci_domain_id:04x}:{p.pci_bus_id:02x}:{p.pci_device_id:02x}.0"
+        with open(f"/sys/bus/pci/devices/{bdf}/numa_node") as f:
+            node = int(f.read())
+        if node < 0:
+            return f"{bdf}: no NUMA node reported"
+        with open(f"/sys/devices/system/node/node{node}/cpulist") as f:
+            allowed = parse_cpulist(f.read()) & os.sched_getaffinity(0)
+        if not allowed:
+            return f"{bdf}: node {node} has no allowed CPU"
+        os.sched_setaffinity(0, allowed)
+        return f"{bdf} -> NUMA node {node} ({len(allowed)} CPUs)"
+    except (OSError, ValueError, AttributeError, RuntimeError) as exc:
+        return f"unavailable ({type(exc).__name__})"
+
+
 def record_doubles(mask: int) -> int:
     return 2 + 5 * bin(mask & 0xF).count("1")
 

@@ -3,6 +3,7 @@ without a GPU, and its HOST decision functions (greedy scan, threshold assign, c
 oracle when fed the oracle's stats records."""
 import ctypes
 import json
+import os
 import re
 from pathlib import Path
 
@@ -161,6 +162,13 @@ def test_greedy_run_equals_numpy_driven_scan(golden_dir):
         assert np.array_equal(a_c.reshape(d[f"{name}_assign"].shape), d[f"{name}_assign"]), name
     with pytest.raises(hb.MtqError):
         hb.greedy_run(stats, mask, ["bf16"], "pcc", 0.9, 1.0, 0)  # seed 0 must be resolved by the caller
+
+
+def test_numa_binding_helpers():
+    assert hb.parse_cpulist("0-3,8,10-11\n") == {0, 1, 2, 3, 8, 10, 11} and hb.parse_cpulist("") == set()
+    before = os.sched_getaffinity(0)
+    msg = hb.bind_to_gpu_numa_node(0)          # no GPU here: must say so and leave the affinity alone
+    assert isinstance(msg, str) and (os.sched_getaffinity(0) == before or "NUMA node" in msg)
 
 
 def test_identity_bf16_mask_equals_full_records():
