@@ -309,6 +309,9 @@ def run(argv=None) -> int:
 
         if torch.cuda.is_available():
             torch.cuda.set_device(local_rank)
+            from .hip_backend import bind_to_gpu_numa_node
+
+            bind_to_gpu_numa_node(local_rank)  # host threads and pinned memory next to this rank's GPU
     if world > 1:
         import torch
         import torch.distributed as dist
