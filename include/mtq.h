@@ -199,6 +199,33 @@ int mtq_threshold_assign(const double *stats, int64_t tiles, uint32_t fmt_mask,
  */
 int mtq_columns_from_stats(const double *stats, int64_t tiles, uint32_t fmt_mask, const int8_t *map,
                            double elem_count, double out[9]);
+/* The same columns from the seven sums themselves (Σx, Σx², Σy, Σy², Σxy, Σ|d|, max|d|), e.g. those of
+ * mtq_column_sums_device copied to the host. */
+int mtq_columns_from_sums(const double sums[7], double elem_count, double out[9]);
+
+/* ------------------------------------------------------------------ DEVICE: decisions on device-resident records */
+
+/*
+ * The functions above read HOST copies of the records (the greedy scan is sequential and lives there).  The threshold
+ * rule, the per-tile scores and the moments of a map are per-tile / reduction work and have DEVICE forms that read the
+ * records where K1 wrote them: nothing but maps (1 B/tile), flags and a handful of doubles crosses PCIe.  Same arithmetic
+ * (csrc/mtq_decide.hpp), same bits as the host forms — except the column sums, which add in a fixed tree order.
+ * All pointers are device pointers; calls are asynchronous on `stream`.
+ */
+
+/* mtq_tile_scores on the device: scores[formats][tiles] (device), rows as documented for mtq_tile_scores. */
+int mtq_tile_scores_device(const double *stats, int64_t tiles, uint32_t fmt_mask, int metric, double *scores, void *stream);
+
+/* K4: mtq_threshold_assign on the device.  map: int8[tiles]; knife: uint8[tiles], 1 where a looked-at format's score is
+ * within `band` of float32(threshold) (the caller re-scores those tiles with the literal float32 expression). */
+int mtq_threshold_assign_device(const double *stats, int64_t tiles, uint32_t fmt_mask, const int *formats, int n_formats,
+                                int metric, double threshold, double band, int8_t *map, uint8_t *knife, void *stream);
+
+/* Σx, Σx², Σy, Σy², Σxy, Σ|d|, max|d| of the reconstruction `map` implies → scratch[0..6] (device).  scratch must hold
+ * mtq_columns_scratch_doubles() doubles.  Σx is NaN when the map names a format that is not available.  The caller
+ * turns the seven values into pcc / mae / atol with the formulas of mtq_columns_from_stats. */
+size_t mtq_columns_scratch_doubles(void);
+int mtq_column_sums_device(const double *stats, int64_t tiles, uint32_t fmt_mask, const int8_t *map, double *scratch, void *stream);
 
 #ifdef __cplusplus
 }

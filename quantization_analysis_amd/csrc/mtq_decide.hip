@@ -1,0 +1,146 @@
+// mtq_decide.hip — K4 and the column sums on the DEVICE: decisions of the threshold algorithm, per-tile scores (sweep)
+// and the tensor-level moments of a reconstruction (columns) taken directly from device-resident stats records, so that
+// these algorithms never move the records (176 B/tile) over PCIe: a map is 1 B/tile, scores are 8 B/tile/format, the
+// moments of a map are 7 doubles.  The arithmetic is mtq_decide.hpp, shared with the host functions: same IEEE
+// operations, same bits (the column sums are the exception: a fixed tree order instead of the host's tile order —
+// deterministic, equal to the host's to ~1e-16 relative).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/mtq.h"
+#include "mtq_decide.hpp"
+#include "mtq_error.hpp"
+
+namespace mtq {
+
+struct SlotTable { int slot[MTQ_NUM_TILE_FORMATS]; };   // record slot per format code (−1 absent, kVirtualSlot identity bf16)
+
+__global__ __launch_bounds__(256) void tile_scores_dev(const double *__restrict__ stats, int64_t tiles, int rec, SlotTable st, int metric,
+                                                       double *__restrict__ scores)
+{
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= tiles) return;
+    const double *r = stats + t * rec;
+    int64_t row = 0;
+#pragma unroll
+    for (int f = 0; f < MTQ_NUM_TILE_FORMATS; ++f) {
+        if (!slot_ok(st.slot[f])) continue;                 // launch-uniform
+        scores[row * tiles + t] = tile_score(r, st.slot[f], metric);
+        ++row;
+    }
+}
+
+__global__ __launch_bounds__(256) void threshold_assign_dev(const double *__restrict__ stats, int64_t tiles, int rec, ThresholdPlan plan,
+                                                            int metric, double thr32, double band, int8_t *__restrict__ map,
+                                                            uint8_t *__restrict__ knife)
+{
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= tiles) return;
+    bool k;
+    map[t] = (int8_t)threshold_decide(stats + t * rec, plan, metric, thr32, band, k);
+    knife[t] = k ? 1u : 0u;
+}
+
+constexpr int kColBlocks = 256, kColVals = 7;   // Σx, Σx², Σy, Σy², Σxy, Σ|d|, max|d|
+
+// Stage 1: block b sums tiles b*256 + tid, + 256*blocks, … per thread in that order, then a fixed LDS tree over the 256
+// threads.  Stage 2 (one block): the same tree over the block partials.  A map entry naming an unavailable format
+// poisons the sums with NaN (the host wrapper reports it).
+__global__ __launch_bounds__(256) void columns_partial_dev(const double *__restrict__ stats, int64_t tiles, int rec, SlotTable st,
+                                                           const int8_t *__restrict__ map, double *__restrict__ partial)
+{
+    __shared__ double red[kColVals][256];
+    double v[kColVals] = {0, 0, 0, 0, 0, 0, 0};
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < tiles; t += (int64_t)gridDim.x * 256) {
+        const double *r = stats + t * rec;
+        const int f = map[t];
+        const int slot = (f >= 0 && f < MTQ_NUM_TILE_FORMATS) ? st.slot[f] : -1;
+        if (!slot_ok(slot)) { v[0] = __builtin_nan(""); continue; }
+        const Sums5 b = load5(r, slot);
+        v[0] += r[0]; v[1] += r[1]; v[2] += b.y; v[3] += b.y2; v[4] += b.xy; v[5] += b.ab;
+        v[6] = nanmax(v[6], b.mx);
+    }
+#pragma unroll
+    for (int k = 0; k < kColVals; ++k) red[k][threadIdx.x] = v[k];
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) {
+#pragma unroll
+            for (int k = 0; k < kColVals - 1; ++k) red[k][threadIdx.x] = red[k][threadIdx.x] + red[k][threadIdx.x + s];
+            red[6][threadIdx.x] = nanmax(red[6][threadIdx.x], red[6][threadIdx.x + s]);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x < kColVals) partial[(int64_t)blockIdx.x * kColVals + threadIdx.x] = red[threadIdx.x][0];
+}
+
+__global__ __launch_bounds__(256) void columns_final_dev(const double *__restrict__ partial, int blocks, double *__restrict__ out)
+{
+    __shared__ double red[kColVals][256];
+#pragma unroll
+    for (int k = 0; k < kColVals; ++k) red[k][threadIdx.x] = (int)threadIdx.x < blocks ? partial[(int64_t)threadIdx.x * kColVals + k] : 0.0;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) {
+#pragma unroll
+            for (int k = 0; k < kColVals - 1; ++k) red[k][threadIdx.x] = red[k][threadIdx.x] + red[k][threadIdx.x + s];
+            red[6][threadIdx.x] = nanmax(red[6][threadIdx.x], red[6][threadIdx.x + s]);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x < kColVals) out[threadIdx.x] = red[threadIdx.x][0];
+}
+
+static SlotTable slot_table(uint32_t fmt_mask)
+{
+    SlotTable st;
+    for (int f = 0; f < MTQ_NUM_TILE_FORMATS; ++f) st.slot[f] = slot_of(fmt_mask, f);
+    return st;
+}
+
+} // namespace mtq
+
+using namespace mtq;
+
+extern "C" int mtq_tile_scores_device(const double *stats, int64_t tiles, uint32_t fmt_mask, int metric, double *scores, void *stream)
+{
+    if (!stats || !scores) return fail(MTQ_ERR_INVALID, "null argument");
+    if (tiles <= 0 || tiles > ((int64_t)1 << 38)) return fail(MTQ_ERR_INVALID, "tiles out of range");
+    if (metric < MTQ_METRIC_PCC || metric > MTQ_METRIC_ATOL) return fail(MTQ_ERR_INVALID, "unknown metric");
+    if (int rc = require_device()) return rc;
+    const int rec = 2 + 5 * popcount4(fmt_mask);
+    hipLaunchKernelGGL(tile_scores_dev, dim3((unsigned)((tiles + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), stats, tiles, rec,
+                       slot_table(fmt_mask), metric, scores);
+    return check_launch("mtq_tile_scores_device");
+}
+
+extern "C" int mtq_threshold_assign_device(const double *stats, int64_t tiles, uint32_t fmt_mask, const int *formats, int n_formats,
+                                           int metric, double threshold, double band, int8_t *map, uint8_t *knife, void *stream)
+{
+    if (!stats || !formats || !map || !knife) return fail(MTQ_ERR_INVALID, "null argument");
+    if (tiles <= 0 || tiles > ((int64_t)1 << 38)) return fail(MTQ_ERR_INVALID, "tiles out of range");
+    if (n_formats <= 0 || n_formats > MTQ_NUM_TILE_FORMATS) return fail(MTQ_ERR_INVALID, "n_formats must be 1..4");
+    if (metric < MTQ_METRIC_PCC || metric > MTQ_METRIC_ATOL) return fail(MTQ_ERR_INVALID, "unknown metric");
+    ThresholdPlan plan;
+    if (!plan_threshold(fmt_mask, formats, n_formats, plan)) return fail(MTQ_ERR_INVALID, "a requested format is not in fmt_mask");
+    if (int rc = require_device()) return rc;
+    const int rec = 2 + 5 * popcount4(fmt_mask);
+    hipLaunchKernelGGL(threshold_assign_dev, dim3((unsigned)((tiles + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), stats, tiles,
+                       rec, plan, metric, (double)(float)threshold, band, map, knife);
+    return check_launch("mtq_threshold_assign_device");
+}
+
+extern "C" size_t mtq_columns_scratch_doubles(void) { return (size_t)kColVals * (kColBlocks + 1); }
+
+extern "C" int mtq_column_sums_device(const double *stats, int64_t tiles, uint32_t fmt_mask, const int8_t *map, double *scratch, void *stream)
+{
+    if (!stats || !map || !scratch) return fail(MTQ_ERR_INVALID, "null argument");
+    if (tiles <= 0 || tiles > ((int64_t)1 << 38)) return fail(MTQ_ERR_INVALID, "tiles out of range");
+    if (int rc = require_device()) return rc;
+    const int rec = 2 + 5 * popcount4(fmt_mask);
+    const int blocks = (int)((tiles + 255) / 256 < kColBlocks ? (tiles + 255) / 256 : kColBlocks);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(columns_partial_dev, dim3((unsigned)blocks), dim3(256), 0, st, stats, tiles, rec, slot_table(fmt_mask), map, scratch + kColVals);
+    hipLaunchKernelGGL(columns_final_dev, dim3(1), dim3(256), 0, st, scratch + kColVals, blocks, scratch);
+    return check_launch("mtq_column_sums_device");
+}

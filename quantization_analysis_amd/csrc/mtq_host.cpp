@@ -24,6 +24,7 @@
 #include <vector>
 
 #include "../../include/mtq.h"
+#include "mtq_decide.hpp"
 #include "mtq_error.hpp"
 
 namespace mtq {
@@ -66,57 +67,13 @@ int check_launch(const char *what)
 
 // ------------------------------------------------------------------------------------------------
 
-static inline int popcount4(uint32_t m) { return __builtin_popcount(m & MTQ_MASK_ALL); }
-
-constexpr int kVirtualSlot = -2; // bf16 as the identity (MTQ_MASK_BF16_IDENTITY): no record slot, sums come from Σx, Σx²
-
-// slot of format f among the set bits of mask, kVirtualSlot for the identity bf16, or -1 when f is not available
-static inline int slot_of(uint32_t mask, int f)
-{
-    if (f < 0 || f >= MTQ_NUM_TILE_FORMATS) return -1;
-    if (f == 0 && (mask & MTQ_MASK_BF16_IDENTITY) && !(mask & 1u)) return kVirtualSlot;
-    if (!(mask & (1u << f))) return -1;
-    return __builtin_popcount(mask & ((1u << f) - 1u));
-}
-static inline bool slot_ok(int slot) { return slot >= 0 || slot == kVirtualSlot; }
-
-// The same five sums by value (registers): what the scan's inner loop uses.
-struct Sums5 { double y, y2, xy, ab, mx; };
-static inline Sums5 load5(const double *r, int slot)
-{
-    if (slot >= 0) { const double *b = r + 2 + 5 * slot; return {b[0], b[1], b[2], b[3], b[4]}; }
-    const double z = std::fabs(r[0]) * 0.0;
-    return {r[0], r[1], r[1], z, z};
-}
-
-// The 5 sums (Σy, Σy², Σxy, Σ|d|, max|d|) of one format of record r: a pointer into the record, or — identity bf16 —
-// the values K1 writes for bf16 storage (y == x), built in buf.
+// sums5: pointer form of load5 (mtq_decide.hpp) for loops that want the record slot in place.
 static inline const double *sums5(const double *r, int slot, double buf[5])
 {
     if (slot >= 0) return r + 2 + 5 * slot;
     const double z = std::fabs(r[0]) * 0.0; // 0, or NaN when Σx is not finite (what the kernel stores)
     buf[0] = r[0]; buf[1] = r[1]; buf[2] = r[1]; buf[3] = z; buf[4] = z;
     return buf;
-}
-
-static inline double nanmax(double m, double d) { return (d > m || d != d) ? d : m; }
-
-// metrics.py:30-33
-static inline bool is_good(double v, int metric, double thr) { return metric == MTQ_METRIC_PCC ? v >= thr : v <= thr; }
-
-// mixed_tile_greedy.py:176-190; every operation individually rounded, evaluation order as written there.
-static inline double pcc_from_moments(double n, double sx, double sx2, double sy, double sy2, double sxy, double sab)
-{
-    if (n == 0.0) return 1.0;
-    const double mean_x = sx / n;
-    const double mean_y = sy / n;
-    double am2 = sx2 - n * mean_x * mean_x;
-    double bm2 = sy2 - n * mean_y * mean_y;
-    if (am2 < 0.0) am2 = 0.0;
-    if (bm2 < 0.0) bm2 = 0.0;
-    const double denom = std::sqrt(am2 * bm2);
-    if (denom == 0.0) return sab == 0.0 ? 1.0 : 0.0;
-    return (sxy - n * mean_x * mean_y) / denom;
 }
 
 // pcc_value (:176-190) with the x-only subexpressions (mean_x, am2) taken from the handle: the same IEEE operations
@@ -343,16 +300,6 @@ extern "C" int mtq_greedy_value(const mtq_greedy *g, double *value)
 
 extern "C" void mtq_greedy_destroy(mtq_greedy *g) { delete g; }
 
-// Per-tile score of one record slot, n = 1024 (tile_utils.py:46-57 on the raw sums).
-static inline double tile_score(const double *r, int slot, int metric)
-{
-    double vb[5];
-    const double *b = sums5(r, slot, vb);
-    if (metric == MTQ_METRIC_MAE) return b[3] / 1024.0;
-    if (metric == MTQ_METRIC_ATOL) return b[4];
-    return pcc_from_moments(1024.0, r[0], r[1], b[0], b[1], b[2], b[3]);
-}
-
 extern "C" int mtq_tile_scores(const double *stats, int64_t tiles, uint32_t fmt_mask, int metric, double *scores)
 {
     if (!stats || !scores) return fail(MTQ_ERR_INVALID, "null argument");
@@ -375,33 +322,14 @@ extern "C" int mtq_threshold_assign(const double *stats, int64_t tiles, uint32_t
     if (!stats || !formats || !map) return fail(MTQ_ERR_INVALID, "null argument");
     if (n_formats <= 0 || n_formats > MTQ_NUM_TILE_FORMATS) return fail(MTQ_ERR_INVALID, "n_formats must be 1..4");
     if (metric < MTQ_METRIC_PCC || metric > MTQ_METRIC_ATOL) return fail(MTQ_ERR_INVALID, "unknown metric");
-    // MIXED_TILE_BYTES_PER_ELEM (tile_utils.py:9-14)
-    static const double bytes_per_elem[MTQ_NUM_TILE_FORMATS] = {2.0, 1.088, 0.50097, 0.25097};
-    int order[MTQ_NUM_TILE_FORMATS], slots[MTQ_NUM_TILE_FORMATS];
-    for (int i = 0; i < n_formats; ++i) {
-        if (!slot_ok(slot_of(fmt_mask, formats[i]))) return fail(MTQ_ERR_INVALID, "a requested format is not in fmt_mask");
-        order[i] = formats[i];
-    }
-    // stable sort ascending bytes (mixed_tile_threshold.py:112-114); best_precision = FIRST max in that order (:115)
-    for (int i = 1; i < n_formats; ++i)
-        for (int j = i; j > 0 && bytes_per_elem[order[j]] < bytes_per_elem[order[j - 1]]; --j) { int tmp = order[j]; order[j] = order[j - 1]; order[j - 1] = tmp; }
-    int best = order[0];
-    for (int i = 1; i < n_formats; ++i) if (bytes_per_elem[order[i]] > bytes_per_elem[best]) best = order[i];
-    for (int i = 0; i < n_formats; ++i) slots[i] = slot_of(fmt_mask, order[i]);
+    ThresholdPlan plan;
+    if (!plan_threshold(fmt_mask, formats, n_formats, plan)) return fail(MTQ_ERR_INVALID, "a requested format is not in fmt_mask");
     const int rec = 2 + 5 * popcount4(fmt_mask);
-    // NumPy >= 2 compares np.float32 score with float32(threshold) (metrics.py:30-33 under NEP 50).
-    const double thr32 = (double)(float)threshold;
+    const double thr32 = (double)(float)threshold; // NumPy >= 2 compares np.float32 score with float32(threshold) (metrics.py:30-33, NEP 50)
     int64_t nk = 0;
     for (int64_t t = 0; t < tiles; ++t) {
-        const double *r = stats + t * rec;
-        int chosen = best;
-        bool knife = false;
-        for (int i = 0; i < n_formats; ++i) {
-            const double s = tile_score(r, slots[i], metric);
-            if (std::fabs(s - thr32) <= band) knife = true; // decision of this format is within the float32 noise band
-            if (is_good((double)(float)s, metric, thr32)) { chosen = order[i]; break; }
-        }
-        map[t] = (int8_t)chosen;
+        bool knife;
+        map[t] = (int8_t)threshold_decide(stats + t * rec, plan, metric, thr32, band, knife);
         if (knife) {
             if (knife_ids && nk < knife_cap) knife_ids[nk] = t;
             ++nk;
@@ -425,10 +353,17 @@ extern "C" int mtq_columns_from_stats(const double *stats, int64_t tiles, uint32
         sx += r[0]; sx2 += r[1]; sy += b[0]; sy2 += b[1]; sxy += b[2]; sab += b[3];
         mx = nanmax(mx, b[4]);
     }
-    out[0] = pcc_from_moments(elem_count, sx, sx2, sy, sy2, sxy, sab);
-    out[1] = elem_count != 0.0 ? sab / elem_count : 0.0;
-    out[2] = mx;
-    out[3] = sx; out[4] = sx2; out[5] = sy; out[6] = sy2; out[7] = sxy; out[8] = sab;
+    const double sums[7] = {sx, sx2, sy, sy2, sxy, sab, mx};
+    return mtq_columns_from_sums(sums, elem_count, out);
+}
+
+extern "C" int mtq_columns_from_sums(const double sums[7], double elem_count, double out[9])
+{
+    if (!sums || !out) return fail(MTQ_ERR_INVALID, "null argument");
+    out[0] = pcc_from_moments(elem_count, sums[0], sums[1], sums[2], sums[3], sums[4], sums[5]);
+    out[1] = elem_count != 0.0 ? sums[5] / elem_count : 0.0;
+    out[2] = sums[6];
+    for (int k = 0; k < 6; ++k) out[3 + k] = sums[k];
     return MTQ_OK;
 }
 

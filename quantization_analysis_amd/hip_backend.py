@@ -28,7 +28,8 @@ EXPORTS = [
     "mtq_tile_stats", "mtq_tile_stats_batched", "mtq_quantize", "mtq_apply_assignment", "mtq_dequant_fp8_block",
     "mtq_greedy_create", "mtq_greedy_pass", "mtq_greedy_assignment", "mtq_greedy_fixed",
     "mtq_greedy_counts", "mtq_greedy_value", "mtq_greedy_destroy",
-    "mtq_tile_scores", "mtq_threshold_assign", "mtq_columns_from_stats",
+    "mtq_tile_scores", "mtq_threshold_assign", "mtq_columns_from_stats", "mtq_columns_from_sums", "mtq_tile_scores_device",
+    "mtq_threshold_assign_device", "mtq_columns_scratch_doubles", "mtq_column_sums_device",
     "mtq_rng_create", "mtq_rng_permutation", "mtq_rng_integers", "mtq_rng_destroy", "mtq_greedy_run", "mtq_greedy_run_batch",
 ]
 
@@ -87,6 +88,12 @@ def lib() -> ctypes.CDLL:
     L.mtq_tile_scores.argtypes = [vp, i64, u32, ci, vp]
     L.mtq_threshold_assign.argtypes = [vp, i64, u32, vp, ci, ci, dbl, dbl, vp, vp, i64, ctypes.POINTER(i64)]
     L.mtq_columns_from_stats.argtypes = [vp, i64, u32, vp, dbl, vp]
+    L.mtq_columns_from_sums.argtypes = [vp, dbl, vp]
+    L.mtq_tile_scores_device.argtypes = [vp, i64, u32, ci, vp, vp]
+    L.mtq_threshold_assign_device.argtypes = [vp, i64, u32, vp, ci, ci, dbl, dbl, vp, vp, vp]
+    L.mtq_columns_scratch_doubles.argtypes = []
+    L.mtq_columns_scratch_doubles.restype = ctypes.c_size_t
+    L.mtq_column_sums_device.argtypes = [vp, i64, u32, vp, vp, vp]
     L.mtq_rng_create.argtypes = [ctypes.POINTER(vp), ctypes.c_uint64]
     L.mtq_rng_permutation.argtypes = [vp, i64, vp]
     L.mtq_rng_integers.argtypes = [vp, i64, i64, vp]
@@ -431,6 +438,55 @@ def threshold_assign(stats: np.ndarray, mask: int, formats, metric: str, thresho
     check(lib().mtq_threshold_assign(stats.ctypes.data, T, mask, fm, len(formats), METRIC_CODE[metric], float(threshold), float(band),
                                      amap.ctypes.data, knife.ctypes.data, T, ctypes.byref(nk)))
     return amap, knife[: min(nk.value, T)].copy()
+
+
+def _score_rows(mask: int) -> int:
+    return bin(mask & 0xF).count("1") + (1 if (mask & MASK_BF16_IDENTITY) and not (mask & 1) else 0)
+
+
+def tile_scores_device(stats_dev, mask: int, metric: str):
+    """mtq_tile_scores on device-resident records [tiles, rec] → device float64 [formats, tiles] (async on the current stream)."""
+    torch = _torch()
+    require_gpu()
+    T = stats_dev.shape[0]
+    out = torch.empty((_score_rows(mask), T), dtype=torch.float64, device=stats_dev.device)
+    check(lib().mtq_tile_scores_device(stats_dev.data_ptr(), T, mask, METRIC_CODE[metric], out.data_ptr(), _stream_ptr()))
+    return out
+
+
+def threshold_assign_device(stats_dev, mask: int, formats, metric: str, threshold: float, band: float = 2e-6):
+    """K4 on device-resident records → (int8[T] map on the host, knife-edge tile ids): only T + T bytes cross PCIe."""
+    torch = _torch()
+    require_gpu()
+    T = stats_dev.shape[0]
+    fm = (ctypes.c_int * len(formats))(*[MIXED_TILE_FORMATS.index(f) for f in formats])
+    both = torch.empty((2, T), dtype=torch.int8, device=stats_dev.device)   # row 0: map, row 1: knife flags
+    check(lib().mtq_threshold_assign_device(stats_dev.data_ptr(), T, mask, fm, len(formats), METRIC_CODE[metric], float(threshold), float(band),
+                                            both[0].data_ptr(), both[1].data_ptr(), _stream_ptr()))
+    host = both.cpu().numpy()
+    return host[0].copy(), np.nonzero(host[1])[0].astype(np.int64)
+
+
+def columns_from_stats_device(stats_dev, mask: int, assignment, elem_count: float) -> dict:
+    """Tensor-level pcc / mae / atol of the reconstruction `assignment` implies, summed on the device from device-resident
+    records (fixed tree order); the map goes up (1 B/tile), seven doubles come back."""
+    torch = _torch()
+    require_gpu()
+    T = stats_dev.shape[0]
+    if isinstance(assignment, np.ndarray):
+        amap = torch.from_numpy(np.ascontiguousarray(assignment, dtype=np.int8).reshape(-1)).to(stats_dev.device)
+    else:
+        amap = assignment.reshape(-1).to(device=stats_dev.device, dtype=torch.int8).contiguous()
+    if amap.numel() != T:
+        raise MtqError("assignment has the wrong number of tiles")
+    scratch = torch.empty(int(lib().mtq_columns_scratch_doubles()), dtype=torch.float64, device=stats_dev.device)
+    check(lib().mtq_column_sums_device(stats_dev.data_ptr(), T, mask, amap.data_ptr(), scratch.data_ptr(), _stream_ptr()))
+    sums = np.ascontiguousarray(scratch[:7].cpu().numpy())
+    if np.isnan(sums[0]) and not np.isnan(sums[1]):
+        raise MtqError("map names a format that is not in fmt_mask")
+    out = (ctypes.c_double * 9)()
+    check(lib().mtq_columns_from_sums(sums.ctypes.data, float(elem_count), out))
+    return {"pcc": out[0], "mae": out[1], "atol": out[2], "sums": tuple(out[3:9])}
 
 
 def columns_from_stats(stats: np.ndarray, mask: int, assignment: np.ndarray, elem_count: float) -> dict:

@@ -388,6 +388,49 @@ def test_sparse_tensors_and_concurrent_streams():
             assert np.array_equal(outs[k].cpu().numpy().view(np.uint64), serial[k].view(np.uint64)), (rep, k)
 
 
+def test_device_decisions_equal_host_decisions(golden_dir):
+    """K4 / per-tile scores / column sums evaluated on the device from device-resident records: the same double
+    arithmetic as the host functions (csrc/mtq_decide.hpp) — scores and maps bit for bit, knife-edge sets equal, the
+    tree-ordered column sums within 1e-13 relative of the tile-ordered host sums."""
+    meta = json.loads((golden_dir / "golden_meta.json").read_text())["f5"]
+    d = np.load(golden_dir / "f5_threshold.npz")
+    for name, m in meta.items():
+        x = d[f"{name}_x"]
+        x2d, _info = hb.to_device_2d(x)
+        fm = [f for f in ALL if f in m["formats"]]
+        mask = hb.fmt_mask(fm)
+        sdev = hb.tile_stats(x2d, mask)
+        shost = sdev.cpu().numpy()
+        for metric in ("pcc", "mae", "atol"):
+            got = hb.tile_scores_device(sdev, mask, metric).cpu().numpy()
+            want = hb.tile_scores(shost, mask, metric)
+            both_nan = np.isnan(got) & np.isnan(want)
+            assert np.array_equal(np.where(both_nan, 0, got.view(np.uint64)), np.where(both_nan, 0, want.view(np.uint64))), (name, metric)
+        a_dev, k_dev = hb.threshold_assign_device(sdev, mask, m["formats"], m["metric"], m["threshold"], 2e-6)
+        a_host, k_host = hb.threshold_assign(shost, mask, m["formats"], m["metric"], m["threshold"], 2e-6)
+        assert np.array_equal(a_dev, a_host) and np.array_equal(k_dev, k_host), name
+        amap = d[f"{name}_assign"].reshape(-1)
+        c_dev = hb.columns_from_stats_device(sdev, mask, amap, float(x.size))
+        c_host = hb.columns_from_stats(shost, mask, amap, float(x.size))
+        assert c_dev["atol"] == c_host["atol"]
+        for key in ("pcc", "mae"):
+            assert abs(c_dev[key] - c_host[key]) <= 1e-13 * max(1.0, abs(c_host[key])), (name, key)
+    # a big one: 4096x4096 bf16, identity records (BFP slots only)
+    g = torch.Generator().manual_seed(5)
+    xb = (torch.randn((4096, 4096), generator=g) * 0.02).to(torch.bfloat16).cuda()
+    sdev = hb.tile_stats(xb, 0xE)
+    ident = 0xE | hb.MASK_BF16_IDENTITY
+    got = hb.tile_scores_device(sdev, ident, "pcc").cpu().numpy()
+    want = hb.tile_scores(sdev.cpu().numpy(), ident, "pcc")
+    assert got.shape == (4, 16384) and np.array_equal(got.view(np.uint64), want.view(np.uint64))
+    thr = float(np.median(got[2]))                         # the median bfp4 tile score: a mixed map with knife-edge tiles
+    a_dev, k_dev = hb.threshold_assign_device(sdev, ident, ALL, "pcc", thr, 2e-6)
+    a_host, k_host = hb.threshold_assign(sdev.cpu().numpy(), ident, ALL, "pcc", thr, 2e-6)
+    assert np.array_equal(a_dev, a_host) and np.array_equal(k_dev, k_host) and len(set(a_dev.tolist())) >= 2 and k_dev.size > 0
+    with pytest.raises(hb.MtqError):
+        hb.columns_from_stats_device(hb.tile_stats(xb[:64, :128], 0x2), 0x2, np.full(8, 3, dtype=np.int8), 8192.0)
+
+
 def test_streamed_pipeline_matches_oracle():
     """GreedyPipeline (what bench.py times): chunked K1 launches, records over PCIe, threaded host scans.  bf16 storage takes
     the 17-double records + identity bf16 (MTQ_MASK_BF16_IDENTITY), float32 storage the full records; maps, counts and
