@@ -165,7 +165,7 @@ def _none_rows_hip(x, formats, quantizer):
     """`none` baseline on the hip backend: pcc/mae/atol of every pure mixed-tile format come from ONE
     K1 pass (sum the per-tile records); fp0 from three device reductions.  y is not materialised or cached."""
     from . import hip_backend as hb
-    from .compression_algorithms.tile_search import compute_tile_stats
+    from .compression_algorithms.tile_search import columns_from_stats, compute_tile_stats
 
     out = {}
     mixed = [f for f in formats if f in MIXED_TILE_FORMATS]
@@ -173,7 +173,7 @@ def _none_rows_hip(x, formats, quantizer):
         ts = compute_tile_stats(x, mixed, quantizer)
         for f in mixed:
             amap = np.full(ts.tiles, MIXED_TILE_FORMATS.index(f), dtype=np.int8)
-            c = hb.columns_from_stats(ts.stats, ts.mask, amap, float(ts.numel))
+            c = columns_from_stats(ts, amap)
             out[f] = (c["pcc"], c["mae"], c["atol"])
     if "fp0" in formats:
         ax = x.float().abs()

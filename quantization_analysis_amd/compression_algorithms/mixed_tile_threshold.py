@@ -3,7 +3,8 @@
 Per tile: the lowest-bytes format whose per-tile metric passes, else the highest-bytes one.
 The reference scores tiles with a float32 two-pass Pearson / mean / max (tile_utils.py:46-57) and, under
 NumPy >= 2, compares that np.float32 with the float32-rounded threshold (metrics.py:30-33, NEP 50).
-Here scores come from the float64 stats records (K1 on the GPU for backend "hip"); tiles whose score
+Here scores come from the float64 stats records (K1 on the GPU for backend "hip", where K4 — the rule below — also
+runs on the device and only the map and the knife-edge flags come back); tiles whose score
 lies within `knife_band` of the threshold are re-scored with the literal float32 expression so that the
 map is the reference's map.
 """
@@ -27,7 +28,10 @@ def threshold_assign(ts: TileStats, tile_formats: list[str], metric: str, thresh
     """reference :111-123 on a TileStats → (int8 (tiles_h, tiles_w) map, number of re-scored tiles)."""
     from .. import hip_backend as hb
 
-    amap, knife = hb.threshold_assign(ts.stats, ts.mask, tile_formats, metric, threshold, band)
+    if ts.on_device and ts.host_stats is None:  # K4 on the device: the records stay where K1 wrote them
+        amap, knife = hb.threshold_assign_device(ts.stats_dev, ts.mask, tile_formats, metric, threshold, band)
+    else:
+        amap, knife = hb.threshold_assign(ts.stats, ts.mask, tile_formats, metric, threshold, band)
     if knife.size:
         by_prec = sorted(tile_formats, key=lambda f: MIXED_TILE_BYTES_PER_ELEM.get(f, 0.0))  # :112-114
         best = max(by_prec, key=lambda f: MIXED_TILE_BYTES_PER_ELEM.get(f, 0.0))             # :115

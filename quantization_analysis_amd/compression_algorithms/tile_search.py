@@ -15,6 +15,7 @@ valid-region sums (mixed_tile_greedy.py:122-131) — SURVEY §8(c).
 from __future__ import annotations
 
 from dataclasses import dataclass
+from typing import Optional
 
 import numpy as np
 
@@ -42,7 +43,6 @@ def slot_of(mask: int, fmt: str) -> int:
 
 @dataclass
 class TileStats:
-    stats: np.ndarray          # host float64 [tiles, 2+5F]
     mask: int
     tiles_h: int
     tiles_w: int
@@ -51,6 +51,20 @@ class TileStats:
     x2d: object                # host ndarray (emulation) or device tensor (hip), the 2-D flatten of xf
     backend: str
     input_was_numpy: bool
+    host_stats: Optional[np.ndarray] = None   # float64 [tiles, 2+5F] on the host
+    stats_dev: object = None                  # the same records where K1 wrote them (hip backend)
+
+    @property
+    def stats(self) -> np.ndarray:
+        """Host copy of the records; for the hip backend it is made on first use — the sequential greedy scan needs it,
+        the per-tile / reduction decisions (threshold rule, scores, column sums) read the device copy instead."""
+        if self.host_stats is None:
+            self.host_stats = self.stats_dev.cpu().numpy()
+        return self.host_stats
+
+    @property
+    def on_device(self) -> bool:
+        return self.stats_dev is not None
 
     @property
     def tiles(self) -> int:
@@ -116,15 +130,13 @@ def compute_tile_stats(xf, formats: list[str], quantizer: Quantizer) -> TileStat
         x2d, info = hb.to_device_2d(xf)
         numel = int(np.asarray(xf).size) if was_np else int(xf.numel())
         th, tw = hb.tiles_hw(*x2d.shape)
-        stats = hb.tile_stats(x2d, mask).cpu().numpy()
-        return TileStats(stats, mask, th, tw, numel, info, x2d, "hip", was_np)
+        return TileStats(mask, th, tw, numel, info, x2d, "hip", was_np, stats_dev=hb.tile_stats(x2d, mask))
     if _is_torch(xf):
         xf = xf.detach().to("cpu").float().numpy()
     xf = np.asarray(xf, dtype=np.float32)
     x2d, info = flatten_2d(xf)
     th, tw = -(-x2d.shape[0] // TILE), -(-x2d.shape[1] // TILE)
-    stats = host_tile_stats(x2d, fm, quantizer)
-    return TileStats(stats, mask, th, tw, int(xf.size), info, x2d, quantizer.backend, True)
+    return TileStats(mask, th, tw, int(xf.size), info, x2d, quantizer.backend, True, host_stats=host_tile_stats(x2d, fm, quantizer))
 
 
 def reconstruct(ts: TileStats, assignment: np.ndarray, quantizer: Quantizer):
@@ -146,21 +158,45 @@ def reconstruct(ts: TileStats, assignment: np.ndarray, quantizer: Quantizer):
 
 
 def gather_tiles(ts: TileStats, tile_ids: np.ndarray) -> np.ndarray:
-    """Zero-padded (k,32,32) float32 host copies of the named tiles of x (for knife-edge re-scoring)."""
-    out = np.zeros((len(tile_ids), TILE, TILE), dtype=np.float32)
+    """Zero-padded (k,32,32) float32 host copies of the named tiles of x (for knife-edge re-scoring).  On the hip backend
+    the tiles are gathered on the device with one indexed read and come over in one copy."""
+    ids = np.asarray(tile_ids, dtype=np.int64).reshape(-1)
     h, w = ts.x2d.shape
-    for k, t in enumerate(tile_ids):
+    if ts.backend == "hip" and ids.size:
+        torch = __import__("torch")
+        dev = ts.x2d.device
+        t = torch.from_numpy(ids).to(dev)
+        ar = torch.arange(TILE, device=dev)
+        rows = (t // ts.tiles_w)[:, None] * TILE + ar            # (k, 32)
+        cols = (t % ts.tiles_w)[:, None] * TILE + ar
+        vals = ts.x2d[rows.clamp(max=h - 1)[:, :, None], cols.clamp(max=w - 1)[:, None, :]].float()
+        inside = (rows < h)[:, :, None] & (cols < w)[:, None, :]
+        return torch.where(inside, vals, torch.zeros((), dtype=torch.float32, device=dev)).cpu().numpy()
+    out = np.zeros((ids.size, TILE, TILE), dtype=np.float32)
+    for k, t in enumerate(ids):
         tr, tc = divmod(int(t), ts.tiles_w)
         r0, c0 = tr * TILE, tc * TILE
         blk = ts.x2d[r0:min(r0 + TILE, h), c0:min(c0 + TILE, w)]
-        if ts.backend == "hip":
-            blk = blk.float().cpu().numpy()
         out[k, : blk.shape[0], : blk.shape[1]] = blk
     return out
 
 
 def columns_from_stats(ts: TileStats, assignment: np.ndarray) -> dict:
-    """Tensor-level pcc / mae / atol of the reconstruction, from the float64 raw sums."""
+    """Tensor-level pcc / mae / atol of the reconstruction, from the float64 raw sums — summed on the device when the records
+    live there and have not been brought to the host anyway (1 B/tile up, seven doubles back)."""
     from .. import hip_backend as hb
 
-    return hb.columns_from_stats(ts.stats, ts.mask, np.asarray(assignment, dtype=np.int8).reshape(-1), float(ts.numel))
+    amap = np.asarray(assignment, dtype=np.int8).reshape(-1)
+    if ts.on_device and ts.host_stats is None:
+        return hb.columns_from_stats_device(ts.stats_dev, ts.mask, amap, float(ts.numel))
+    return hb.columns_from_stats(ts.stats, ts.mask, amap, float(ts.numel))
+
+
+def tile_scores(ts: TileStats, metric: str) -> np.ndarray:
+    """float64 [formats in mask order, tiles] per-tile scores (tile_utils.py:46-57 on the raw sums); computed where the
+    records are."""
+    from .. import hip_backend as hb
+
+    if ts.on_device and ts.host_stats is None:
+        return hb.tile_scores_device(ts.stats_dev, ts.mask, metric).cpu().numpy()
+    return hb.tile_scores(ts.stats, ts.mask, metric)

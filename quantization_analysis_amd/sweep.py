@@ -13,7 +13,7 @@ import numpy as np
 from . import hip_backend as hb
 from .compression_algorithms.mixed_tile_threshold import KNIFE_BAND, _quantize_tiles
 from .compression_algorithms.quantizer import Quantizer
-from .compression_algorithms.tile_search import compute_tile_stats, gather_tiles, slot_of
+from .compression_algorithms.tile_search import columns_from_stats, compute_tile_stats, gather_tiles, slot_of, tile_scores
 from .compression_algorithms.tile_utils import MIXED_TILE_BYTES_PER_ELEM, MIXED_TILE_FORMATS, mixed_tile_total_bytes, tile_metrics
 
 
@@ -59,7 +59,7 @@ def sweep_tensor(xf, formats: list[str], metric: str, lowest_metric_val: float, 
     by_prec = sorted(formats, key=lambda f: MIXED_TILE_BYTES_PER_ELEM.get(f, 0.0))   # :652
     highest = max(by_prec, key=lambda f: MIXED_TILE_BYTES_PER_ELEM.get(f, 0.0))      # :653
     mask_order = [f for f in MIXED_TILE_FORMATS if f in formats]
-    s64_all = hb.tile_scores(ts.stats, ts.mask, metric)                               # [F mask order, T]
+    s64_all = tile_scores(ts, metric)                                                 # [F mask order, T]
     s64 = np.stack([s64_all[mask_order.index(f)] for f in by_prec])                   # asc bytes
     s32 = s64.astype(np.float32)
 
@@ -105,7 +105,7 @@ def sweep_tensor(xf, formats: list[str], metric: str, lowest_metric_val: float, 
     baselines = []
     for f in formats:                                                                 # :688-715
         amap = np.full(ts.tiles, MIXED_TILE_FORMATS.index(f), dtype=np.int8)
-        c = hb.columns_from_stats(ts.stats, ts.mask, amap, float(ts.numel))
+        c = columns_from_stats(ts, amap)
         mv = c[metric]
         if (metric == "pcc" and mv < lowest_metric_val) or (metric != "pcc" and mv > lowest_metric_val):
             continue
@@ -119,7 +119,7 @@ def sweep_tensor(xf, formats: list[str], metric: str, lowest_metric_val: float, 
         if last is not None and np.array_equal(a_idx, last):
             m = last_metrics
         else:
-            c = hb.columns_from_stats(ts.stats, ts.mask, fmt_code[a_idx], float(ts.numel))
+            c = columns_from_stats(ts, fmt_code[a_idx])
             raw = np.bincount(a_idx, minlength=len(by_prec))
             counts = {f: 0 for f in MIXED_TILE_FORMATS}
             for i, f in enumerate(by_prec):

@@ -42,12 +42,12 @@ def main(argv=None) -> int:
 
         x2d, info = hb.to_device_2d(x)
         th, tw = hb.tiles_hw(*x2d.shape)
-        ts = TileStats(None, 0, th, tw, int(x.numel()), info, x2d, "hip", True)
+        ts = TileStats(0, th, tw, int(x.numel()), info, x2d, "hip", True)
     else:
         xf = x.float().numpy()
         x2d, info = flatten_2d(xf)
         th, tw = -(-x2d.shape[0] // 32), -(-x2d.shape[1] // 32)
-        ts = TileStats(None, 0, th, tw, int(xf.size), info, x2d, args.backend, True)
+        ts = TileStats(0, th, tw, int(xf.size), info, x2d, args.backend, True)
     if a.size != th * tw:
         print(f"error: assignment has {a.size} entries, tensor has {th}x{tw} tiles")
         return 1
