@@ -1,5 +1,5 @@
 set -o pipefail
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/final; mkdir -p $O
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/final; rm -rf $O; mkdir -p $O
 cd $R
 timeout -k 10 500 python -m pytest tests -x -q -m gpu > $O/gpu_tests.log 2>&1; echo "gpu tests rc=$?"; tail -2 $O/gpu_tests.log
 python __graft_entry__.py smoke > $O/smoke.log 2>&1; echo "smoke rc=$?"
