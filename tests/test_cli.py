@@ -208,3 +208,23 @@ def test_wq_hip_backend(tmp_path, monkeypatch):
     a = numbers((rdir / "table.txt").read_text())
     b = numbers((run_dir(tmp_path / "results_emu") / "table.txt").read_text())
     assert len(a) == len(b) > 0 and max(abs(x - y) for x, y in zip(a, b)) <= 2e-5  # table prints 5 decimals / 3 significant digits
+
+
+@pytest.mark.gpu
+def test_wq_hip_threshold_and_random(tmp_path, monkeypatch):
+    """The other two mixed-tile algorithms through `wq --backend hip` (records stay on the device: K4 / column sums there):
+    maps equal the oracle's, artifacts and PNGs are written."""
+    monkeypatch.chdir(tmp_path)
+    idx = model_source.build_model_index("synthetic:tiny")
+    names = model_source.resolve_selected_tensors(idx, None)
+    cfg = write_cfg(tmp_path, algo="mixed-tile-threshold", seed=None, params={"metric": "pcc", "threshold": 0.99})
+    assert cli.run(["synthetic:tiny", "--compression-config", cfg, "--backend", "hip", "--results-dir", str(tmp_path / "rt")]) == 0
+    rdir = run_dir(tmp_path / "rt")
+    check_maps_against_oracle(rdir, "mixed_tile_threshold", names, idx, lambda x: orc.threshold(x, ALL, "pcc", 0.99)[0])
+    assert len(list(rdir.rglob("size_vs_accuracy.png"))) == len(names)
+    cfg = write_cfg(tmp_path, algo="mixed-tile-random", seed=5, params={"metric": "pcc", "threshold": 0.97, "iters": 6})
+    assert cli.run(["synthetic:tiny", "model.layers.1", "--compression-config", cfg, "--backend", "hip", "--results-dir", str(tmp_path / "rr")]) == 0
+    rdir = run_dir(tmp_path / "rr")
+    for name in ("model.layers.1.attn.q.weight", "model.layers.1.mlp.up.weight"):
+        want = orc.random_search(idx.load(name).float().numpy(), ALL, "pcc", 0.97, 6, 5)[0]
+        assert np.array_equal(np.load(rdir / "mixed_tile_random" / f"{cli._slug(name)}_assignment.npy"), want), name

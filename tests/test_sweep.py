@@ -108,3 +108,26 @@ def test_sweep_hip_backend(golden_dir):
 
     _check(golden_dir, Quantizer("hip"))
     _check(golden_dir, Quantizer("hip"), to_input=lambda x: torch.from_numpy(x).cuda())
+
+
+@pytest.mark.gpu
+def test_sweep_and_reconstruct_scripts_hip(tmp_path):
+    """The two scripts with --backend hip produce the same CSV rows / reconstruction as with the host backend (counts,
+    thresholds and sizes exactly; float columns to 1e-6)."""
+    import csv as _csv
+
+    outs = {}
+    for backend in ("emulation", "hip"):
+        out = tmp_path / backend
+        r = subprocess.run([sys.executable, str(ROOT / "scripts" / "sweep_mixed_tile_threshold.py"), "synthetic:tiny", r"layers\.1\..*weight$",
+                            "--steps", "6", "--lowest-metric-val", "0.95", "--backend", backend, "--out-dir", str(out), "--no-plots"],
+                           capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs[backend] = {p.parent.name: list(_csv.reader(p.open())) for p in out.rglob("sweep_results.csv")}
+    assert outs["emulation"].keys() == outs["hip"].keys() and len(outs["hip"]) == 2
+    for k in outs["hip"]:
+        a, b = outs["emulation"][k], outs["hip"][k]
+        assert a[0] == b[0] and len(a) == len(b) == 7
+        for ra, rb in zip(a[1:], b[1:]):
+            assert ra[:3] == rb[:3] and ra[6:] == rb[6:]                                    # step, threshold, size_bytes, tile counts
+            assert all(abs(float(x) - float(y)) <= 1e-6 for x, y in zip(ra[3:6], rb[3:6]))  # pcc, mae, atol
