@@ -226,6 +226,10 @@ int mtq_threshold_assign_device(const double *stats, int64_t tiles, uint32_t fmt
  * turns the seven values into pcc / mae / atol with the formulas of mtq_columns_from_stats. */
 size_t mtq_columns_scratch_doubles(void);
 int mtq_column_sums_device(const double *stats, int64_t tiles, uint32_t fmt_mask, const int8_t *map, double *scratch, void *stream);
+/* The same for `count` equally sized tensors in one launch pair: records [count][tiles][rec], maps [count][tiles], scratch
+ * [count][mtq_columns_scratch_doubles()] — tensor i's seven sums at scratch[i * mtq_columns_scratch_doubles()]. */
+int mtq_column_sums_device_batched(const double *stats, int64_t count, int64_t tiles, uint32_t fmt_mask, const int8_t *maps,
+                                   double *scratch, void *stream);
 
 #ifdef __cplusplus
 }

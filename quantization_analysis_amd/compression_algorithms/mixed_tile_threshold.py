@@ -32,20 +32,28 @@ def threshold_assign(ts: TileStats, tile_formats: list[str], metric: str, thresh
         amap, knife = hb.threshold_assign_device(ts.stats_dev, ts.mask, tile_formats, metric, threshold, band)
     else:
         amap, knife = hb.threshold_assign(ts.stats, ts.mask, tile_formats, metric, threshold, band)
-    if knife.size:
-        by_prec = sorted(tile_formats, key=lambda f: MIXED_TILE_BYTES_PER_ELEM.get(f, 0.0))  # :112-114
-        best = max(by_prec, key=lambda f: MIXED_TILE_BYTES_PER_ELEM.get(f, 0.0))             # :115
-        x_tiles = gather_tiles(ts, knife)
-        scores = {f: tile_metrics(x_tiles, np.asarray(_quantize_tiles(x_tiles, f, quantizer), dtype=np.float32), metric)
-                  for f in by_prec}
-        for k, t in enumerate(knife):
-            chosen = best
-            for f in by_prec:
-                if metric_is_good(scores[f][k], metric, threshold):  # np.float32 vs Python float, as the reference
-                    chosen = f
-                    break
-            amap[t] = MIXED_TILE_FORMATS.index(chosen)
+    rescore_knife_tiles(ts, amap, knife, tile_formats, metric, threshold, quantizer)
     return amap.reshape(ts.tiles_h, ts.tiles_w), int(knife.size)
+
+
+def rescore_knife_tiles(ts: TileStats, amap: np.ndarray, knife: np.ndarray, tile_formats: list[str], metric: str, threshold: float,
+                        quantizer: Quantizer) -> None:
+    """Decide the tiles in `knife` again with the literal float32 per-tile score of the reference (tile_utils.py:46-57 on y
+    tiles quantized through the selected backend) and patch the flat int8 map `amap` in place."""
+    if not knife.size:
+        return
+    by_prec = sorted(tile_formats, key=lambda f: MIXED_TILE_BYTES_PER_ELEM.get(f, 0.0))  # :112-114
+    best = max(by_prec, key=lambda f: MIXED_TILE_BYTES_PER_ELEM.get(f, 0.0))             # :115
+    x_tiles = gather_tiles(ts, knife)
+    scores = {f: tile_metrics(x_tiles, np.asarray(_quantize_tiles(x_tiles, f, quantizer), dtype=np.float32), metric)
+              for f in by_prec}
+    for k, t in enumerate(knife):
+        chosen = best
+        for f in by_prec:
+            if metric_is_good(scores[f][k], metric, threshold):  # np.float32 vs Python float, as the reference
+                chosen = f
+                break
+        amap[t] = MIXED_TILE_FORMATS.index(chosen)
 
 
 def _quantize_tiles(x_tiles: np.ndarray, fmt: str, quantizer: Quantizer) -> np.ndarray:

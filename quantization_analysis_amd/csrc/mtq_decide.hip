@@ -46,10 +46,14 @@ constexpr int kColBlocks = 256, kColVals = 7;   // Σx, Σx², Σy, Σy², Σxy,
 // Stage 1: block b sums tiles b*256 + tid, + 256*blocks, … per thread in that order, then a fixed LDS tree over the 256
 // threads.  Stage 2 (one block): the same tree over the block partials.  A map entry naming an unavailable format
 // poisons the sums with NaN (the host wrapper reports it).
+// blockIdx.y = tensor of a batch (records, maps and scratch areas of equal size back to back).
 __global__ __launch_bounds__(256) void columns_partial_dev(const double *__restrict__ stats, int64_t tiles, int rec, SlotTable st,
-                                                           const int8_t *__restrict__ map, double *__restrict__ partial)
+                                                           const int8_t *__restrict__ map, double *__restrict__ partial, int64_t scratch_stride)
 {
     __shared__ double red[kColVals][256];
+    stats += (int64_t)blockIdx.y * tiles * rec;
+    map += (int64_t)blockIdx.y * tiles;
+    partial += (int64_t)blockIdx.y * scratch_stride;
     double v[kColVals] = {0, 0, 0, 0, 0, 0, 0};
     for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < tiles; t += (int64_t)gridDim.x * 256) {
         const double *r = stats + t * rec;
@@ -74,9 +78,12 @@ __global__ __launch_bounds__(256) void columns_partial_dev(const double *__restr
     if (threadIdx.x < kColVals) partial[(int64_t)blockIdx.x * kColVals + threadIdx.x] = red[threadIdx.x][0];
 }
 
-__global__ __launch_bounds__(256) void columns_final_dev(const double *__restrict__ partial, int blocks, double *__restrict__ out)
+__global__ __launch_bounds__(256) void columns_final_dev(const double *__restrict__ partial, int blocks, double *__restrict__ out,
+                                                         int64_t scratch_stride)
 {
     __shared__ double red[kColVals][256];
+    partial += (int64_t)blockIdx.y * scratch_stride;
+    out += (int64_t)blockIdx.y * scratch_stride;
 #pragma unroll
     for (int k = 0; k < kColVals; ++k) red[k][threadIdx.x] = (int)threadIdx.x < blocks ? partial[(int64_t)threadIdx.x * kColVals + k] : 0.0;
     __syncthreads();
@@ -132,15 +139,23 @@ extern "C" int mtq_threshold_assign_device(const double *stats, int64_t tiles, u
 
 extern "C" size_t mtq_columns_scratch_doubles(void) { return (size_t)kColVals * (kColBlocks + 1); }
 
-extern "C" int mtq_column_sums_device(const double *stats, int64_t tiles, uint32_t fmt_mask, const int8_t *map, double *scratch, void *stream)
+extern "C" int mtq_column_sums_device_batched(const double *stats, int64_t count, int64_t tiles, uint32_t fmt_mask, const int8_t *maps,
+                                              double *scratch, void *stream)
 {
-    if (!stats || !map || !scratch) return fail(MTQ_ERR_INVALID, "null argument");
-    if (tiles <= 0 || tiles > ((int64_t)1 << 38)) return fail(MTQ_ERR_INVALID, "tiles out of range");
+    if (!stats || !maps || !scratch) return fail(MTQ_ERR_INVALID, "null argument");
+    if (tiles <= 0 || tiles > ((int64_t)1 << 38) || count <= 0 || count > 65535) return fail(MTQ_ERR_INVALID, "tiles / count out of range");
     if (int rc = require_device()) return rc;
     const int rec = 2 + 5 * popcount4(fmt_mask);
     const int blocks = (int)((tiles + 255) / 256 < kColBlocks ? (tiles + 255) / 256 : kColBlocks);
+    const int64_t stride = (int64_t)kColVals * (kColBlocks + 1);
     hipStream_t st = static_cast<hipStream_t>(stream);
-    hipLaunchKernelGGL(columns_partial_dev, dim3((unsigned)blocks), dim3(256), 0, st, stats, tiles, rec, slot_table(fmt_mask), map, scratch + kColVals);
-    hipLaunchKernelGGL(columns_final_dev, dim3(1), dim3(256), 0, st, scratch + kColVals, blocks, scratch);
+    hipLaunchKernelGGL(columns_partial_dev, dim3((unsigned)blocks, (unsigned)count), dim3(256), 0, st, stats, tiles, rec, slot_table(fmt_mask), maps,
+                       scratch + kColVals, stride);
+    hipLaunchKernelGGL(columns_final_dev, dim3(1, (unsigned)count), dim3(256), 0, st, scratch + kColVals, blocks, scratch, stride);
     return check_launch("mtq_column_sums_device");
+}
+
+extern "C" int mtq_column_sums_device(const double *stats, int64_t tiles, uint32_t fmt_mask, const int8_t *map, double *scratch, void *stream)
+{
+    return mtq_column_sums_device_batched(stats, 1, tiles, fmt_mask, map, scratch, stream);
 }

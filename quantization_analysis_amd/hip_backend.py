@@ -29,7 +29,7 @@ EXPORTS = [
     "mtq_greedy_create", "mtq_greedy_pass", "mtq_greedy_assignment", "mtq_greedy_fixed",
     "mtq_greedy_counts", "mtq_greedy_value", "mtq_greedy_destroy",
     "mtq_tile_scores", "mtq_threshold_assign", "mtq_columns_from_stats", "mtq_columns_from_sums", "mtq_tile_scores_device",
-    "mtq_threshold_assign_device", "mtq_columns_scratch_doubles", "mtq_column_sums_device",
+    "mtq_threshold_assign_device", "mtq_columns_scratch_doubles", "mtq_column_sums_device", "mtq_column_sums_device_batched",
     "mtq_rng_create", "mtq_rng_permutation", "mtq_rng_integers", "mtq_rng_destroy", "mtq_greedy_run", "mtq_greedy_run_batch",
 ]
 
@@ -94,6 +94,7 @@ def lib() -> ctypes.CDLL:
     L.mtq_columns_scratch_doubles.argtypes = []
     L.mtq_columns_scratch_doubles.restype = ctypes.c_size_t
     L.mtq_column_sums_device.argtypes = [vp, i64, u32, vp, vp, vp]
+    L.mtq_column_sums_device_batched.argtypes = [vp, i64, i64, u32, vp, vp, vp]
     L.mtq_rng_create.argtypes = [ctypes.POINTER(vp), ctypes.c_uint64]
     L.mtq_rng_permutation.argtypes = [vp, i64, vp]
     L.mtq_rng_integers.argtypes = [vp, i64, i64, vp]
@@ -454,17 +455,31 @@ def tile_scores_device(stats_dev, mask: int, metric: str):
     return out
 
 
-def threshold_assign_device(stats_dev, mask: int, formats, metric: str, threshold: float, band: float = 2e-6):
-    """K4 on device-resident records → (int8[T] map on the host, knife-edge tile ids): only T + T bytes cross PCIe."""
+def threshold_assign_device_raw(stats_dev, mask: int, formats, metric: str, threshold: float, band: float = 2e-6):
+    """K4 on device-resident records [T, rec] (any number of tensors' tiles back to back) → device int8 [2, T]: row 0 the
+    map, row 1 the knife-edge flags; asynchronous on the current stream."""
     torch = _torch()
     require_gpu()
     T = stats_dev.shape[0]
     fm = (ctypes.c_int * len(formats))(*[MIXED_TILE_FORMATS.index(f) for f in formats])
-    both = torch.empty((2, T), dtype=torch.int8, device=stats_dev.device)   # row 0: map, row 1: knife flags
+    both = torch.empty((2, T), dtype=torch.int8, device=stats_dev.device)
     check(lib().mtq_threshold_assign_device(stats_dev.data_ptr(), T, mask, fm, len(formats), METRIC_CODE[metric], float(threshold), float(band),
                                             both[0].data_ptr(), both[1].data_ptr(), _stream_ptr()))
-    host = both.cpu().numpy()
+    return both
+
+
+def threshold_assign_device(stats_dev, mask: int, formats, metric: str, threshold: float, band: float = 2e-6):
+    """K4 on device-resident records → (int8[T] map on the host, knife-edge tile ids): only T + T bytes cross PCIe."""
+    host = threshold_assign_device_raw(stats_dev, mask, formats, metric, threshold, band).cpu().numpy()
     return host[0].copy(), np.nonzero(host[1])[0].astype(np.int64)
+
+
+def columns_from_sums(sums7: np.ndarray, elem_count: float) -> dict:
+    """pcc / mae / atol from Σx, Σx², Σy, Σy², Σxy, Σ|d|, max|d| (mtq_columns_from_sums)."""
+    sums = np.ascontiguousarray(sums7, dtype=np.float64)
+    out = (ctypes.c_double * 9)()
+    check(lib().mtq_columns_from_sums(sums.ctypes.data, float(elem_count), out))
+    return {"pcc": out[0], "mae": out[1], "atol": out[2], "sums": tuple(out[3:9])}
 
 
 def columns_from_stats_device(stats_dev, mask: int, assignment, elem_count: float) -> dict:

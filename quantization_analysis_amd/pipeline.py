@@ -192,3 +192,93 @@ class GreedyPipeline:
 
     def close(self) -> None:
         self.pool.shutdown(wait=True)
+
+
+class ThresholdPipeline:
+    """mixed-tile-threshold over a (count, rows, cols) device tensor of equally shaped matrices, records never leaving
+    the GPU: per chunk K1 (batched) → K4 on the device over all of the chunk's tiles at once → map + knife-edge flags to
+    the host (2 B/tile) → the few knife-edge tiles re-scored with the literal float32 expression (as
+    compression_algorithms.mixed_tile_threshold does for one tensor) → patched maps back up → column sums on the device.
+    There is no host scan: the GPU is the pacing resource."""
+
+    def __init__(self, tile_formats=None, metric: str = "pcc", threshold: float = 0.999, chunk: int = 16, band: float = 2e-6):
+        import torch
+
+        from .compression_algorithms.quantizer import Quantizer
+
+        hb.require_gpu()
+        self.torch = torch
+        self.tile_formats = list(tile_formats or MIXED_TILE_FORMATS)
+        self.mask = hb.fmt_mask(self.tile_formats)
+        self.metric, self.threshold, self.band = metric, float(threshold), float(band)
+        self.chunk = int(chunk)
+        self.quantizer = Quantizer("hip")
+        self.knife_tiles = 0
+
+    def _rescore_chunk(self, xc, maps: np.ndarray, jj: np.ndarray, tt: np.ndarray, tiles_w: int) -> None:
+        """The knife-edge tiles of a whole chunk at once: one indexed gather on the device, one K2 call per format, the
+        reference's literal float32 tile score (tile_utils.py:46-57), maps patched in place (reference :117-123)."""
+        from .compression_algorithms.metrics import metric_is_good
+        from .compression_algorithms.tile_utils import MIXED_TILE_BYTES_PER_ELEM, tile_metrics
+
+        torch = self.torch
+        n, h, w = xc.shape
+        dev = xc.device
+        j = torch.from_numpy(jj.astype(np.int64)).to(dev)
+        t = torch.from_numpy(tt.astype(np.int64)).to(dev)
+        ar = torch.arange(32, device=dev)
+        rows = (t // tiles_w)[:, None] * 32 + ar
+        cols = (t % tiles_w)[:, None] * 32 + ar
+        vals = xc[j[:, None, None], rows.clamp(max=h - 1)[:, :, None], cols.clamp(max=w - 1)[:, None, :]].float()
+        inside = (rows < h)[:, :, None] & (cols < w)[:, None, :]
+        x_dev = torch.where(inside, vals, torch.zeros((), dtype=torch.float32, device=dev)).contiguous()   # (k, 32, 32), pads zero
+        x_tiles = x_dev.cpu().numpy()
+        k = x_tiles.shape[0]
+        by_prec = sorted(self.tile_formats, key=lambda f: MIXED_TILE_BYTES_PER_ELEM.get(f, 0.0))
+        best = max(by_prec, key=lambda f: MIXED_TILE_BYTES_PER_ELEM.get(f, 0.0))
+        scores = {f: tile_metrics(x_tiles, hb.quantize(x_dev.view(k * 32, 32), f).cpu().numpy().reshape(k, 32, 32), self.metric) for f in by_prec}
+        for i in range(k):
+            chosen = best
+            for f in by_prec:
+                if metric_is_good(scores[f][i], self.metric, self.threshold):
+                    chosen = f
+                    break
+            maps[jj[i], tt[i]] = MIXED_TILE_FORMATS.index(chosen)
+
+    def run(self, x3d) -> list[TensorResult]:
+        torch = self.torch
+        count, rows, cols = x3d.shape
+        th, tw = hb.tiles_hw(rows, cols)
+        tiles, numel = th * tw, rows * cols
+        identity = x3d.dtype == torch.bfloat16 and (self.mask & 1) and (self.mask & 0xE)
+        k1_mask = self.mask & 0xE if identity else self.mask
+        dec_mask = k1_mask | hb.MASK_BF16_IDENTITY if identity else self.mask
+        scratch_n = int(hb.lib().mtq_columns_scratch_doubles())
+        results: list[TensorResult] = []
+        launched = []  # (first, n, records, map+flags on the device, their host copy in flight)
+        for first in range(0, count, self.chunk):
+            n = min(self.chunk, count - first)
+            recs = hb.tile_stats_batched(x3d[first:first + n], k1_mask)                       # [n, tiles, rec] on the device
+            both = hb.threshold_assign_device_raw(recs.view(n * tiles, -1), dec_mask, self.tile_formats, self.metric, self.threshold, self.band)
+            launched.append((first, n, recs, both, both.to("cpu", non_blocking=True)))
+        torch.cuda.current_stream().synchronize()
+        for first, n, recs, both, host in launched:
+            maps = host[0].numpy().reshape(n, tiles).copy()
+            flags = host[1].numpy().reshape(n, tiles)
+            jj, tt = np.nonzero(flags)                                                         # knife-edge (tensor, tile) pairs of the chunk (few)
+            dirty = jj.size > 0
+            if dirty:
+                self._rescore_chunk(x3d[first:first + n], maps, jj, tt, tw)
+                self.knife_tiles += int(jj.size)
+            dmaps = torch.from_numpy(maps).to(x3d.device) if dirty else both[0].view(n, tiles)
+            scratch = torch.empty((n, scratch_n), dtype=torch.float64, device=x3d.device)
+            dmaps = dmaps.contiguous()
+            hb.check(hb.lib().mtq_column_sums_device_batched(recs.data_ptr(), n, tiles, dec_mask, dmaps.data_ptr(), scratch.data_ptr(), hb._stream_ptr()))
+            sums = scratch[:, :7].cpu().numpy()
+            for j in range(n):
+                cols_j = hb.columns_from_sums(sums[j], float(numel))
+                bc = np.bincount(maps[j], minlength=len(MIXED_TILE_FORMATS))
+                counts = {f: int(bc[i]) for i, f in enumerate(MIXED_TILE_FORMATS)}
+                results.append(TensorResult(first + j, maps[j].reshape(th, tw), counts, mixed_tile_total_bytes(counts), cols_j["pcc"], cols_j["mae"],
+                                            cols_j["atol"], cols_j[self.metric]))
+        return results

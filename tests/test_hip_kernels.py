@@ -431,6 +431,30 @@ def test_device_decisions_equal_host_decisions(golden_dir):
         hb.columns_from_stats_device(hb.tile_stats(xb[:64, :128], 0x2), 0x2, np.full(8, 3, dtype=np.int8), 8192.0)
 
 
+def test_threshold_pipeline_matches_oracle():
+    """ThresholdPipeline (records never leave the GPU): maps and counts equal the oracle's threshold search tensor by tensor,
+    columns within 1e-6 of the float32 reference columns; a threshold placed on a tile score exercises the knife-edge path."""
+    from quantization_analysis_amd.pipeline import ThresholdPipeline
+
+    for kind, shape, bf16 in (("normal_bf16", (128, 256), True), ("heavy_f32", (96, 160), False)):
+        xs = np.stack([gen(kind, 60 + i, shape) for i in range(5)])
+        s4 = orc.threshold_scores(xs[0], ALL, "pcc")["bfp4"]
+        for thr in (0.99, float(np.sort(s4)[len(s4) // 2])):          # the second one IS a tile's float32 score
+            pipe = ThresholdPipeline(ALL, "pcc", thr, chunk=2)
+            res = pipe.run(dev(xs, bf16=bf16))
+            assert [r.index for r in res] == list(range(5))
+            for i, r in enumerate(res):
+                a, counts, _sc = orc.threshold(xs[i], ALL, "pcc", thr)
+                assert np.array_equal(r.assignment, a) and r.counts == counts, (kind, thr, i)
+                y = orc.apply_assignment(xs[i], a)
+                # float64 moments against a float64 two-pass Pearson (1e-7: the float32 products inside the sums), and
+                # against the reference's own float32 value (its BLAS noise is ~1e-6 on a 32K-element tensor)
+                assert abs(r.pcc - orc.pearson_corr_f64(xs[i], y)) <= 1e-7 and abs(r.pcc - orc.pearson_corr(xs[i], y)) <= 3e-6
+                assert abs(r.mae - float(np.mean(np.abs(xs[i] - y)))) <= 1e-6
+                assert r.atol == float(np.max(np.abs(xs[i] - y)))
+        assert pipe.knife_tiles >= 1
+
+
 def test_streamed_pipeline_matches_oracle():
     """GreedyPipeline (what bench.py times): chunked K1 launches, records over PCIe, threaded host scans.  bf16 storage takes
     the 17-double records + identity bf16 (MTQ_MASK_BF16_IDENTITY), float32 storage the full records; maps, counts and
