@@ -188,7 +188,7 @@ __device__ __forceinline__ void direct_group(const uint32_t (&u)[kGroup], double
 template <typename T, uint32_t FM>
 __global__ __launch_bounds__(kDirectWaves * 64, MTQ_DIRECT_WAVES_PER_SIMD) void tile_stats_direct(
     const T *__restrict__ x, int64_t stride, int64_t rows, int64_t cols, int64_t ld, uint32_t tiles_w, uint32_t tiles,
-    uint32_t total_tiles, double *__restrict__ stats, int vec_ok, unsigned *__restrict__ work)
+    uint32_t total_tiles, double *__restrict__ stats, int vec_ok, unsigned *__restrict__ work, unsigned launch_id)
 {
     constexpr int nf = popc4(FM), nsum = 2 + 4 * nf, pad = direct_pad(FM), rec = 2 + 5 * nf;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -252,7 +252,10 @@ __global__ __launch_bounds__(kDirectWaves * 64, MTQ_DIRECT_WAVES_PER_SIMD) void 
         double *out = stats + (int64_t)gt * rec;
         if (lane < nsum) {
             const int slot = lane < 2 ? lane : 2 + 5 * ((lane - 2) >> 2) + ((lane - 2) & 3);
-            if (tile_bad && lane == 0) r = __longlong_as_double((long long)kRedoMagicDirect);
+            if (tile_bad && lane == 0) {
+                r = __longlong_as_double((long long)kRedoMagicDirect);
+                work[kWorkStamp] = launch_id;                                     // tells the follow-up kernel there is something to redo
+            }
             out[slot] = r;
         } else if (lane >= 32 && lane < 32 + nf) {
             float v = mx[0];
@@ -266,12 +269,12 @@ __global__ __launch_bounds__(kDirectWaves * 64, MTQ_DIRECT_WAVES_PER_SIMD) void 
 
 template <typename T>
 static void launch_direct(uint32_t fm, dim3 grid, hipStream_t st, const T *x, int64_t stride, int64_t rows, int64_t cols, int64_t ld,
-                          uint32_t tiles_w, uint32_t tiles, uint32_t total, double *stats, int vec_ok, unsigned *work)
+                          uint32_t tiles_w, uint32_t tiles, uint32_t total, double *stats, int vec_ok, unsigned *work, unsigned launch_id)
 {
     const dim3 block(kDirectWaves * 64);
 #define MTQ_LAUNCH_DIRECT(M) \
     case M: hipLaunchKernelGGL((tile_stats_direct<T, M>), grid, block, (size_t)kDirectWaves * 64 * direct_pad(M) * sizeof(double), st, x, \
-                               stride, rows, cols, ld, tiles_w, tiles, total, stats, vec_ok, work); break;
+                               stride, rows, cols, ld, tiles_w, tiles, total, stats, vec_ok, work, launch_id); break;
     switch (fm) { // one instantiation per requested format subset: unrequested formats cost nothing
         MTQ_LAUNCH_DIRECT(1u) MTQ_LAUNCH_DIRECT(2u) MTQ_LAUNCH_DIRECT(3u) MTQ_LAUNCH_DIRECT(4u) MTQ_LAUNCH_DIRECT(5u)
         MTQ_LAUNCH_DIRECT(6u) MTQ_LAUNCH_DIRECT(7u) MTQ_LAUNCH_DIRECT(8u) MTQ_LAUNCH_DIRECT(9u) MTQ_LAUNCH_DIRECT(10u)
@@ -288,7 +291,7 @@ using namespace mtq;
 // Launcher used by mtq_tile_stats_batched for every input the bf16 LDS-staged kernel does not take (mtq_kernels.hip
 // decides and follows up with tile_stats_redo_flagged).  fmt_mask != 0, count * tiles < 2^31.
 extern "C" int mtq_launch_tile_stats_direct(const void *x, int in_dtype, int64_t count, int64_t stride_elems, int64_t rows, int64_t cols,
-                                            int64_t ld, uint32_t fmt_mask, double *stats, int vec_ok, void *stream, unsigned **work_out)
+                                            int64_t ld, uint32_t fmt_mask, double *stats, int vec_ok, void *stream, unsigned **work_out, unsigned launch_id)
 {
     const int64_t th = (rows + kTile - 1) / kTile, tw = (cols + kTile - 1) / kTile, tiles = th * tw, total = count * tiles;
     if (total >= ((int64_t)1 << 31) || (fmt_mask & MTQ_MASK_ALL) == 0) return fail(MTQ_ERR_INVALID, "direct tile_stats launch out of range");
@@ -308,9 +311,9 @@ extern "C" int mtq_launch_tile_stats_direct(const void *x, int in_dtype, int64_t
     *work_out = work;
     if (in_dtype == MTQ_DTYPE_BF16)
         launch_direct<uint16_t>(fmt_mask & MTQ_MASK_ALL, grid, st, static_cast<const uint16_t *>(x), stride_elems, rows, cols, ld, (uint32_t)tw,
-                                (uint32_t)tiles, (uint32_t)total, stats, vec_ok, work);
+                                (uint32_t)tiles, (uint32_t)total, stats, vec_ok, work, launch_id);
     else
         launch_direct<float>(fmt_mask & MTQ_MASK_ALL, grid, st, static_cast<const float *>(x), stride_elems, rows, cols, ld, (uint32_t)tw,
-                             (uint32_t)tiles, (uint32_t)total, stats, vec_ok, work);
+                             (uint32_t)tiles, (uint32_t)total, stats, vec_ok, work, launch_id);
     return check_launch("mtq_tile_stats (direct)");
 }

@@ -13,6 +13,10 @@ int require_device();
 // (tile_stats_redo_flagged) sets the slot back to zero, so no memset sits on the stream.  nullptr when the ring cannot
 // be allocated.
 constexpr int kWorkGroups = 64, kWorkStride = 32, kWorkSlots = 128;
+// Word 1 of a slot carries the id of the last launch that marked a tile for the literal fix-up (ids are unique per launch,
+// so the word never needs resetting): the follow-up kernel returns at once unless it finds its own launch's id there.
+constexpr int kWorkStamp = 1;
+unsigned next_launch_id();
 unsigned *work_counter_slot();
 // hipGetLastError() → MTQ_OK / MTQ_ERR_HIP with the kernel name in the message.
 int check_launch(const char *what);

@@ -229,7 +229,7 @@ __device__ __forceinline__ void glds16(const void *sbase, uint32_t voff, uint32_
 template <uint32_t BFP>
 __global__ __launch_bounds__(kFastWaves * 64, MTQ_ROLLED_WAVES_PER_SIMD) void tile_stats_bf16_rolled(
     const uint16_t *__restrict__ x, int64_t stride, int64_t ld, int tiles_w, int64_t tiles, int units_w, int units_per_tensor,
-    int total_units, uint32_t fmt_mask, int rec, double *__restrict__ stats, unsigned *__restrict__ work)
+    int total_units, uint32_t fmt_mask, int rec, double *__restrict__ stats, unsigned *__restrict__ work, unsigned launch_id)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int lane = threadIdx.x & 63;
@@ -359,7 +359,10 @@ __global__ __launch_bounds__(kFastWaves * 64, MTQ_ROLLED_WAVES_PER_SIMD) void ti
             if (fmt_mask & 8u) rec_t[o2 + 4] = (double)mx[2];
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (tile_bad && j == 0) rec_t[0] = __longlong_as_double((long long)kRedoMagic);
+        if (tile_bad && j == 0) {
+            rec_t[0] = __longlong_as_double((long long)kRedoMagic);
+            work[kWorkStamp] = launch_id;                                         // tells the follow-up kernel there is something to redo
+        }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 
         int b, tr, uc;
@@ -383,7 +386,7 @@ using namespace mtq;
 
 // Launcher used by mtq_tile_stats_batched when the input qualifies (mtq_kernels.hip decides).
 extern "C" int mtq_launch_tile_stats_bf16_fast(const void *x, int64_t count, int64_t stride_elems, int64_t rows, int64_t cols,
-                                               int64_t ld, uint32_t fmt_mask, double *stats, void *stream, unsigned **work_out)
+                                               int64_t ld, uint32_t fmt_mask, double *stats, void *stream, unsigned **work_out, unsigned launch_id)
 {
     const int64_t th = rows / kTile, tw = cols / kTile, tiles = th * tw;
     const int64_t units_w = cols / kUnitCols, upt = th * units_w, total = count * upt;
@@ -407,7 +410,7 @@ extern "C" int mtq_launch_tile_stats_bf16_fast(const void *x, int64_t count, int
     if (!work) return fail(MTQ_ERR_HIP, "could not allocate the work counters");
     *work_out = work;
 #define MTQ_LAUNCH_FAST(B) \
-    hipLaunchKernelGGL(tile_stats_bf16_rolled<B>, grid, block, lds_bytes, st, xp, stride_elems, ld, (int)tw, tiles, (int)units_w, (int)upt, (int)total, fmt_mask, rec, stats, work)
+    hipLaunchKernelGGL(tile_stats_bf16_rolled<B>, grid, block, lds_bytes, st, xp, stride_elems, ld, (int)tw, tiles, (int)units_w, (int)upt, (int)total, fmt_mask, rec, stats, work, launch_id)
     switch ((fmt_mask >> 1) & 7u) { // one instantiation per requested BFP subset: unrequested formats cost nothing
     case 1: MTQ_LAUNCH_FAST(1u); break;
     case 2: MTQ_LAUNCH_FAST(2u); break;

@@ -89,9 +89,10 @@ template <typename T>
 __global__ __launch_bounds__(256) void tile_stats_redo_flagged(const T *__restrict__ x, int64_t count, int64_t stride,
                                                                int64_t rows, int64_t cols, int64_t ld, int tiles_w,
                                                                int64_t tiles, uint32_t fmt_mask, int rec,
-                                                               double *__restrict__ stats, int vec_ok, unsigned *__restrict__ work)
+                                                               double *__restrict__ stats, int vec_ok, unsigned *__restrict__ work, unsigned launch_id)
 {
     if (blockIdx.x == 0 && threadIdx.x < kWorkGroups) work[threadIdx.x * kWorkStride] = 0u; // the launch's unit counters, ready for their next user
+    if (work[kWorkStamp] != launch_id) return;                          // no tile of this launch was marked (the usual case): nothing to read
     const int lane = threadIdx.x & 63;
     const int64_t first = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 64;
     const int64_t mine = first + lane;
@@ -274,9 +275,16 @@ static int check_matrix(const void *x, int in_dtype, int64_t rows, int64_t cols,
 using namespace mtq;
 
 extern "C" int mtq_launch_tile_stats_bf16_fast(const void *x, int64_t count, int64_t stride_elems, int64_t rows, int64_t cols,
-                                               int64_t ld, uint32_t fmt_mask, double *stats, void *stream, unsigned **work_out);
+                                               int64_t ld, uint32_t fmt_mask, double *stats, void *stream, unsigned **work_out, unsigned launch_id);
 extern "C" int mtq_launch_tile_stats_direct(const void *x, int in_dtype, int64_t count, int64_t stride_elems, int64_t rows, int64_t cols,
-                                            int64_t ld, uint32_t fmt_mask, double *stats, int vec_ok, void *stream, unsigned **work_out);
+                                            int64_t ld, uint32_t fmt_mask, double *stats, int vec_ok, void *stream, unsigned **work_out, unsigned launch_id);
+
+unsigned mtq::next_launch_id()
+{
+    static std::atomic<unsigned> id{1u};
+    unsigned v = id.fetch_add(1u);
+    return v ? v : id.fetch_add(1u);   // 0 is what a fresh slot holds
+}
 
 // Per-device ring of zeroed unit counters (mtq_error.hpp).  A slot is handed to one K1 launch and set back to zero by
 // that launch's follow-up kernel on the same stream; kWorkSlots launches would have to be pending for a slot to be shared.
@@ -336,24 +344,26 @@ extern "C" int mtq_tile_stats_batched(const void *x, int in_dtype, int64_t count
     // bf16 storage, whole 32x128 units, 16-byte aligned rows, at least one BFP format → exact-integer fast kernel
     if (in_dtype == MTQ_DTYPE_BF16 && vec_ok && rows % kTile == 0 && cols % 128 == 0 && (fmt_mask & 0xEu) != 0 && !force_generic()) {
         unsigned *work = nullptr;
-        if (int rc = mtq_launch_tile_stats_bf16_fast(x, count, stride_elems, rows, cols, ld, fmt_mask, stats, stream, &work)) return rc;
+        const unsigned launch_id = next_launch_id();
+        if (int rc = mtq_launch_tile_stats_bf16_fast(x, count, stride_elems, rows, cols, ld, fmt_mask, stats, stream, &work, launch_id)) return rc;
         const int64_t waves = (count * tiles + 63) / 64;
         hipLaunchKernelGGL(tile_stats_redo_flagged<uint16_t>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, static_cast<hipStream_t>(stream),
-                           static_cast<const uint16_t *>(x), count, stride_elems, rows, cols, ld, (int)tw, tiles, fmt_mask, rec, stats, vec_ok, work);
+                           static_cast<const uint16_t *>(x), count, stride_elems, rows, cols, ld, (int)tw, tiles, fmt_mask, rec, stats, vec_ok, work, launch_id);
         return finish_counter_launch(work, static_cast<hipStream_t>(stream));
     }
     hipStream_t s = static_cast<hipStream_t>(stream);
     // float32 storage, ragged or unaligned bf16: one wave per tile on the reduced-arithmetic route (mtq_direct.hip)
     if ((fmt_mask & MTQ_MASK_ALL) != 0 && count * tiles < ((int64_t)1 << 31) && !force_generic()) {
         unsigned *work = nullptr;
-        if (int rc = mtq_launch_tile_stats_direct(x, in_dtype, count, stride_elems, rows, cols, ld, fmt_mask, stats, vec_ok, stream, &work)) return rc;
+        const unsigned launch_id = next_launch_id();
+        if (int rc = mtq_launch_tile_stats_direct(x, in_dtype, count, stride_elems, rows, cols, ld, fmt_mask, stats, vec_ok, stream, &work, launch_id)) return rc;
         const dim3 rgrid((unsigned)(((count * tiles + 63) / 64 + 3) / 4));
         if (in_dtype == MTQ_DTYPE_BF16)
             hipLaunchKernelGGL(tile_stats_redo_flagged<uint16_t>, rgrid, dim3(256), 0, s, static_cast<const uint16_t *>(x), count, stride_elems,
-                               rows, cols, ld, (int)tw, tiles, fmt_mask, rec, stats, vec_ok, work);
+                               rows, cols, ld, (int)tw, tiles, fmt_mask, rec, stats, vec_ok, work, launch_id);
         else
             hipLaunchKernelGGL(tile_stats_redo_flagged<float>, rgrid, dim3(256), 0, s, static_cast<const float *>(x), count, stride_elems, rows,
-                               cols, ld, (int)tw, tiles, fmt_mask, rec, stats, vec_ok, work);
+                               cols, ld, (int)tw, tiles, fmt_mask, rec, stats, vec_ok, work, launch_id);
         return finish_counter_launch(work, s);
     }
     const int64_t blocks = (count * tiles + 3) / 4;
