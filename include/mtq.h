@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define MTQ_VERSION 100 /* 0.1.0 */
+#define MTQ_VERSION 120 /* 0.1.2: + mtq_rng_integers, identity-bf16 mask, device-side decisions */
 
 typedef enum {
     MTQ_OK = 0,

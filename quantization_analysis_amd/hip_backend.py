@@ -102,7 +102,7 @@ def lib() -> ctypes.CDLL:
     L.mtq_rng_destroy.restype = None
     L.mtq_greedy_run.argtypes = [vp, i64, u32, vp, ci, ci, dbl, dbl, ctypes.c_uint64, vp, vp, vp]
     L.mtq_greedy_run_batch.argtypes = [vp, i64, i64, u32, vp, ci, ci, dbl, dbl, vp, vp, vp, vp, ci]
-    if L.mtq_version() < 100:
+    if L.mtq_version() < 120:
         raise MtqError("libmtq_hip.so is older than this package")
     _lib = L
     return L
