@@ -441,7 +441,8 @@ void rng_seed(mtq_rng *r, uint64_t seed)
 // draw by draw (an unpredictable rejection branch per element), so the draws of a block are generated first and then
 // consumed without branches: a rejected draw swaps an element with itself and leaves i where it is.  Draws generated
 // beyond the last one consumed are handed back by replaying the generator from the block's start.
-void rng_shuffle(mtq_rng *r, int64_t n, int64_t *arr)
+template <bool kSwap>
+void rng_shuffle_impl(mtq_rng *r, int64_t n, int64_t *arr)
 {
     if (n < 2) return;
     int64_t i = n - 1;
@@ -452,7 +453,7 @@ void rng_shuffle(mtq_rng *r, int64_t n, int64_t *arr)
             uint64_t v;
             if ((uint64_t)i <= 0xFFFFFFFFull) { while ((v = (pcg_next32(r) & mask)) > (uint64_t)i) {} }
             else { while ((v = (pcg_next64(r) & mask)) > (uint64_t)i) {} }
-            const int64_t t = arr[i]; arr[i] = arr[(int64_t)v]; arr[(int64_t)v] = t;
+            if (kSwap) { const int64_t t = arr[i]; arr[i] = arr[(int64_t)v]; arr[(int64_t)v] = t; }
         }
         return;
     }
@@ -469,9 +470,11 @@ void rng_shuffle(mtq_rng *r, int64_t n, int64_t *arr)
         while (p < cnt && ii >= 1u) {
             const uint32_t v = buf[p++] & m32;
             const bool ok = v <= ii;
-            const uint32_t j = ok ? v : ii;           // rejected: swap with itself
-            const int64_t a = arr[ii], b = arr[j];
-            arr[ii] = b; arr[j] = a;
+            if (kSwap) {
+                const uint32_t j = ok ? v : ii;       // rejected: swap with itself
+                const int64_t a = arr[ii], b = arr[j];
+                arr[ii] = b; arr[j] = a;
+            }
             ii -= ok ? 1u : 0u;
             m32 = ((m32 >> 1) >= ii) ? (m32 >> 1) : m32; // smallest 2^k − 1 >= ii: one step at most per decrement (harmless at ii == 0)
         }
@@ -487,6 +490,10 @@ void rng_shuffle(mtq_rng *r, int64_t n, int64_t *arr)
         r->u32 = (uint32_t)(last >> 32);
     }
 }
+
+void rng_shuffle(mtq_rng *r, int64_t n, int64_t *arr) { rng_shuffle_impl<true>(r, n, arr); }
+// The same draws without the array: advances the generator exactly as a shuffle of n elements would.
+void rng_skip_shuffle(mtq_rng *r, int64_t n) { rng_shuffle_impl<false>(r, n, nullptr); }
 
 void rng_permutation(mtq_rng *r, int64_t n, int64_t *out)
 {
@@ -561,6 +568,15 @@ extern "C" int mtq_greedy_run(const double *stats, int64_t tiles, uint32_t fmt_m
         int64_t n = 0;
         for (int64_t t = 0; t < tiles; ++t) if (!g->fixed[(size_t)t]) cand[(size_t)n++] = t; // np.where(~fixed)[0], :228
         if (n == 0) break;                                                                     // :229-230
+        if (f == 0 && n == tiles) {
+            // The pass of the base format: every tile already has it, so each visit only asks whether the current value passes
+            // (:237-241) — the same answer for all of them, whatever the order.  The generator still advances as the
+            // permutation would have (the later passes' orders depend on it).
+            rng_skip_shuffle(&rng, n);
+            rc = mtq_greedy_pass(g, formats[0], cand.data(), 1);              // evaluates the current value once, on tile 0
+            if (rc == MTQ_OK && g->fixed[0]) std::fill(g->fixed.begin(), g->fixed.end(), (uint8_t)1);
+            continue;
+        }
         rng_shuffle(&rng, n, cand.data());                                                    // order = rng.permutation(candidates), :231
         rc = mtq_greedy_pass(g, formats[f], cand.data(), n);
     }
