@@ -10,6 +10,7 @@ are the outputs the north star names); use compression_algorithms.* for the drop
 from __future__ import annotations
 
 import concurrent.futures as cf
+import os
 from dataclasses import dataclass, field
 
 import numpy as np
@@ -99,7 +100,7 @@ class GreedyPipeline:
         torch = self.torch
         count, rows, cols = x3d.shape
         th, tw = hb.tiles_hw(rows, cols)
-        identity = x3d.dtype == torch.bfloat16 and (self.mask & 1) and (self.mask & 0xE)
+        identity = x3d.dtype == torch.bfloat16 and (self.mask & 1) and (self.mask & 0xE) and os.environ.get("MTQ_IDENTITY_RECORDS", "1") != "0"
         rec = hb.record_doubles(self.mask & 0xE if identity else self.mask)
         for slot in (0, 1):
             dev, host, _np = self._buffers(slot, count, th * tw, rec, x3d.device)
@@ -119,7 +120,7 @@ class GreedyPipeline:
         th, tw = hb.tiles_hw(rows, cols)
         # bf16 storage: the bf16 candidate is the identity, its record slot would be [Σx, Σx², Σx², 0, 0]; K1 then writes
         # the BFP slots only and the host scan synthesises format 0 (MTQ_MASK_BF16_IDENTITY): 23 % fewer bytes over PCIe
-        identity = x3d.dtype == torch.bfloat16 and (self.mask & 1) and (self.mask & 0xE)
+        identity = x3d.dtype == torch.bfloat16 and (self.mask & 1) and (self.mask & 0xE) and os.environ.get("MTQ_IDENTITY_RECORDS", "1") != "0"
         k1_mask = self.mask & 0xE if identity else self.mask
         host_mask = k1_mask | hb.MASK_BF16_IDENTITY if identity else self.mask
         tiles, rec = th * tw, hb.record_doubles(k1_mask)
