@@ -54,6 +54,11 @@ enum { MTQ_FMT_BF16 = 0, MTQ_FMT_BFP8 = 1, MTQ_FMT_BFP4 = 2, MTQ_FMT_BFP2 = 3, M
  * K1's bf16 slot is [Σx, Σx², Σx², |Σx|·0, |Σx|·0].  Set together with a mask WITHOUT bit 0 (records written by K1 for
  * mask & 0xE: 17 instead of 22 doubles per tile cross PCIe); format 0 is then synthesised from Σx, Σx² on the host. */
 #define MTQ_MASK_BF16_IDENTITY 0x10u
+/* mtq_greedy_* with metric pcc only: "slim" records [Σx, Σx², {Σy, Σy², Σxy} per format bit] — 3 instead of 5 doubles per
+ * format (written by mtq_pack_slim_records from K1's records).  Σ|x−y| and max|x−y| feed no pcc decision except the
+ * degenerate zero-variance case: a scan that reaches it fails with MTQ_ERR_UNSUPPORTED and the caller repeats that tensor
+ * with full records; the mae / atol columns of the result come from mtq_column_sums_device on the full device records. */
+#define MTQ_MASK_SLIM 0x20u
 
 /* metrics (compression_algorithms/metrics.py:19-39) */
 enum { MTQ_METRIC_PCC = 0, MTQ_METRIC_MAE = 1, MTQ_METRIC_ATOL = 2 };
@@ -67,7 +72,7 @@ int mtq_device_count(int *count);
 
 /* ------------------------------------------------------------------ DEVICE: kernels */
 
-/* Doubles per tile record for a format mask: 2 + 5 * popcount(mask & 0xF). */
+/* Doubles per tile record for a format mask: 2 + 5 * popcount(mask & 0xF); 2 + 3 * popcount under MTQ_MASK_SLIM. */
 size_t mtq_stats_record_doubles(uint32_t fmt_mask);
 
 /*
@@ -120,6 +125,13 @@ int mtq_apply_assignment(const void *x, int in_dtype, int64_t rows, int64_t cols
  */
 int mtq_dequant_fp8_block(const void *w, const float *scale_inv, int64_t rows, int64_t cols, int64_t ldw,
                           int64_t scale_rows, int64_t scale_cols, float *out, int64_t ldo, void *stream);
+
+/*
+ * Slim copy of K1's records for the pcc greedy scan (MTQ_MASK_SLIM): out[t] = [Σx, Σx², {Σy, Σy², Σxy} per format bit of
+ * fmt_mask], 2 + 3F doubles per tile, for `tiles` records back to back (any number of tensors).  Device to device; what
+ * crosses PCIe afterwards is 88 instead of 136 B/tile at F = 3.
+ */
+int mtq_pack_slim_records(const double *stats, int64_t tiles, uint32_t fmt_mask, double *out, void *stream);
 
 /* ------------------------------------------------------------------ HOST: decisions on stats records */
 

@@ -67,6 +67,14 @@ int check_launch(const char *what)
 
 // ------------------------------------------------------------------------------------------------
 
+// load5 for a handle's slot width: slim records carry Σy, Σy², Σxy only (Σ|d| and max read as 0).
+static inline Sums5 load5w(const double *r, int slot, int w)
+{
+    if (w == 5 || slot < 0) return load5(r, slot);
+    const double *b = r + 2 + 3 * slot;
+    return {b[0], b[1], b[2], 0.0, 0.0};
+}
+
 // sums5: pointer form of load5 (mtq_decide.hpp) for loops that want the record slot in place.
 static inline const double *sums5(const double *r, int slot, double buf[5])
 {
@@ -78,14 +86,14 @@ static inline const double *sums5(const double *r, int slot, double buf[5])
 
 // pcc_value (:176-190) with the x-only subexpressions (mean_x, am2) taken from the handle: the same IEEE operations
 // in the same order, evaluated once instead of at every step.
-static inline double pcc_hoisted(double n, double mean_x, double am2, double sy, double sy2, double sxy, double sab)
+static inline double pcc_hoisted(double n, double mean_x, double am2, double sy, double sy2, double sxy, double sab, bool *degenerate)
 {
     if (n == 0.0) return 1.0;
     const double mean_y = sy / n;
     double bm2 = sy2 - n * mean_y * mean_y;
     if (bm2 < 0.0) bm2 = 0.0;
     const double denom = std::sqrt(am2 * bm2);
-    if (denom == 0.0) return sab == 0.0 ? 1.0 : 0.0;
+    if (denom == 0.0) { *degenerate = true; return sab == 0.0 ? 1.0 : 0.0; } // the one place Σ|d| decides (slim records do not carry it)
     return (sxy - n * mean_x * mean_y) / denom;
 }
 
@@ -106,6 +114,8 @@ struct mtq_greedy {
     double mean_x, am2; // mean_x = sum_x / n and am2 = max(sum_x2 - n*mean_x*mean_x, 0): constant during the scan (:179,181,183)
     double max_abs;
     int64_t max_count;
+    int w;              // doubles per format slot: 5, or 3 for slim records (MTQ_MASK_SLIM: no Σ|d|, no max)
+    bool degenerate;    // slim records only: a decision needed Σ|d| (zero-variance case) — the result is not valid
     int slot4[MTQ_NUM_TILE_FORMATS]; // record slot of every format (−1: not in mask)
     std::vector<int8_t> assign;  // the CURRENT format of every tile; its sums are stats[t][2 + 5*slot4[assign[t]] ..]
     std::vector<uint8_t> fixed;
@@ -140,7 +150,10 @@ extern "C" int mtq_greedy_create(mtq_greedy **out, const double *stats, int64_t 
     if (!g) return fail(MTQ_ERR_INVALID, "out of memory");
     g->T = tiles;
     g->mask = fmt_mask & (MTQ_MASK_ALL | MTQ_MASK_BF16_IDENTITY);
-    g->rec = 2 + 5 * popcount4(fmt_mask);
+    g->w = (fmt_mask & MTQ_MASK_SLIM) ? 3 : 5;
+    g->degenerate = false;
+    if (g->w == 3 && metric != MTQ_METRIC_PCC) { delete g; return fail(MTQ_ERR_INVALID, "slim records serve the pcc metric only"); }
+    g->rec = 2 + g->w * popcount4(fmt_mask);
     g->metric = metric;
     g->thr = threshold;
     g->n = elem_count;
@@ -154,13 +167,14 @@ extern "C" int mtq_greedy_create(mtq_greedy **out, const double *stats, int64_t 
     // running globals accumulated in tile order (:147-174, :195-204, :208-218)
     double vb[5];
     for (int64_t t = 0; t < tiles; ++t) {
-        const double *r = stats + t * g->rec, *b = sums5(r, bslot, vb);
+        const double *r = stats + t * g->rec;
+        const Sums5 b = load5w(r, bslot, g->w);
         g->sum_x += r[0];
         g->sum_x2 += r[1];
-        g->sum_y += b[0];
-        g->sum_y2 += b[1];
-        g->sum_xy += b[2];
-        g->sum_abs += b[3];
+        g->sum_y += b.y;
+        g->sum_y2 += b.y2;
+        g->sum_xy += b.xy;
+        g->sum_abs += b.ab;
     }
     g->cur_valid = false;
     g->cur_value = 0.0;
@@ -195,7 +209,7 @@ extern "C" int mtq_greedy_pass(mtq_greedy *g, int fmt, const int64_t *order, int
             const int64_t ta = order[k + kAhead];
             if (ta >= 0 && ta < g->T && g->assign[(size_t)ta] != fmt) { // a tile already in this format is decided without its record
                 const double *ra = g->stats + ta * g->rec;      // the identity slot lives in the record's first two doubles
-                const int sa = slot >= 0 ? 2 + 5 * slot : 0, pa = g->slot4[g->assign[(size_t)ta]] >= 0 ? 2 + 5 * g->slot4[g->assign[(size_t)ta]] : 0;
+                const int sa = slot >= 0 ? 2 + g->w * slot : 0, pa = g->slot4[g->assign[(size_t)ta]] >= 0 ? 2 + g->w * g->slot4[g->assign[(size_t)ta]] : 0;
                 __builtin_prefetch(ra + sa);
                 __builtin_prefetch(ra + sa + 4);
                 __builtin_prefetch(ra + pa);
@@ -208,18 +222,18 @@ extern "C" int mtq_greedy_pass(mtq_greedy *g, int fmt, const int64_t *order, int
         if (g->metric == MTQ_METRIC_PCC) {
             if (prev == fmt) { // :237-241 — current_value is a pure function of the running sums: reuse it until a move is accepted
                 if (!g->cur_valid) {
-                    g->cur_value = pcc_hoisted(N, g->mean_x, g->am2, g->sum_y, g->sum_y2, g->sum_xy, g->sum_abs);
+                    g->cur_value = pcc_hoisted(N, g->mean_x, g->am2, g->sum_y, g->sum_y2, g->sum_xy, g->sum_abs, &g->degenerate);
                     g->cur_valid = true;
                 }
                 if (!is_good(g->cur_value, MTQ_METRIC_PCC, thr)) g->fixed[(size_t)t] = 1;
                 continue;
             }
-            const Sums5 cur = load5(rt, g->slot4[prev]), q = load5(rt, slot); // the tile's CURRENT format and the candidate
+            const Sums5 cur = load5w(rt, g->slot4[prev], g->w), q = load5w(rt, slot, g->w); // the tile's CURRENT format and the candidate
             const double cy = g->sum_y + (q.y - cur.y);     // :259
             const double cy2 = g->sum_y2 + (q.y2 - cur.y2); // :260
             const double cxy = g->sum_xy + (q.xy - cur.xy); // :261
             const double cab = g->sum_abs + (q.ab - cur.ab); // :262
-            accept = is_good(pcc_hoisted(N, g->mean_x, g->am2, cy, cy2, cxy, cab), MTQ_METRIC_PCC, thr);
+            accept = is_good(pcc_hoisted(N, g->mean_x, g->am2, cy, cy2, cxy, cab, &g->degenerate), MTQ_METRIC_PCC, thr);
             if (accept) { g->sum_y = cy; g->sum_y2 = cy2; g->sum_xy = cxy; g->sum_abs = cab; g->cur_valid = false; }
         } else if (g->metric == MTQ_METRIC_MAE) {
             if (prev == fmt) { // :280-284
@@ -580,10 +594,15 @@ extern "C" int mtq_greedy_run(const double *stats, int64_t tiles, uint32_t fmt_m
         rng_shuffle(&rng, n, cand.data());                                                    // order = rng.permutation(candidates), :231
         rc = mtq_greedy_pass(g, formats[f], cand.data(), n);
     }
+    if (rc == MTQ_OK && g->w == 3 && g->degenerate)
+        rc = fail(MTQ_ERR_UNSUPPORTED, "zero-variance tensor: the decision needs the full records (Σ|x−y|), not the slim ones");
     if (rc == MTQ_OK) {
         std::memcpy(map, g->assign.data(), (size_t)tiles);
         if (counts) for (int f = 0; f < MTQ_NUM_TILE_FORMATS; ++f) counts[f] = g->counts[f];
-        if (out) rc = mtq_columns_from_stats(stats, tiles, fmt_mask, map, elem_count, out);
+        if (out) {
+            if (g->w == 3) for (int k = 0; k < 9; ++k) out[k] = std::nan(""); // columns of slim scans come from mtq_column_sums_device
+            else rc = mtq_columns_from_stats(stats, tiles, fmt_mask, map, elem_count, out);
+        }
     }
     mtq_greedy_destroy(g);
     return rc;
@@ -646,7 +665,7 @@ extern "C" int mtq_greedy_run_batch(const double *stats, int64_t count, int64_t 
 {
     if (!stats || !formats || !seeds || !maps) return fail(MTQ_ERR_INVALID, "null argument");
     if (count <= 0 || tiles <= 0) return fail(MTQ_ERR_INVALID, "count and tiles must be positive");
-    const int rec = 2 + 5 * popcount4(fmt_mask);
+    const int rec = 2 + ((fmt_mask & MTQ_MASK_SLIM) ? 3 : 5) * popcount4(fmt_mask);
     const int nt = (int)std::max<int64_t>(1, std::min<int64_t>(n_threads, count));
     auto st = std::make_shared<BatchState>();
     auto work = [=]() {

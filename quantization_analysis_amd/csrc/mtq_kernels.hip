@@ -326,7 +326,35 @@ static int finish_counter_launch(unsigned *work, hipStream_t s)
     return rc;
 }
 
-extern "C" size_t mtq_stats_record_doubles(uint32_t fmt_mask) { return 2 + 5 * (size_t)__builtin_popcount(fmt_mask & MTQ_MASK_ALL); }
+extern "C" size_t mtq_stats_record_doubles(uint32_t fmt_mask)
+{
+    return 2 + ((fmt_mask & MTQ_MASK_SLIM) ? 3 : 5) * (size_t)__builtin_popcount(fmt_mask & MTQ_MASK_ALL);
+}
+
+// out[t] = [Σx, Σx², {Σy, Σy², Σxy} per format] of the full record t: one thread per output double.
+__global__ __launch_bounds__(256) void pack_slim_records(const double *__restrict__ stats, int64_t tiles, int rec_in, int rec_out,
+                                                         double *__restrict__ out)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= tiles * rec_out) return;
+    const int64_t t = i / rec_out;
+    const int k = (int)(i - t * rec_out);
+    const int src = k < 2 ? k : 2 + 5 * ((k - 2) / 3) + (k - 2) % 3;
+    out[i] = stats[t * rec_in + src];
+}
+
+extern "C" int mtq_pack_slim_records(const double *stats, int64_t tiles, uint32_t fmt_mask, double *out, void *stream)
+{
+    if (!stats || !out) return fail(MTQ_ERR_INVALID, "null argument");
+    if (tiles <= 0 || tiles > ((int64_t)1 << 34)) return fail(MTQ_ERR_INVALID, "tiles out of range");
+    if ((fmt_mask & ~MTQ_MASK_ALL) != 0 || (fmt_mask & MTQ_MASK_ALL) == 0) return fail(MTQ_ERR_INVALID, "fmt_mask must name stored formats only");
+    if (int rc = require_device()) return rc;
+    const int nf = __builtin_popcount(fmt_mask & MTQ_MASK_ALL), rec_in = 2 + 5 * nf, rec_out = 2 + 3 * nf;
+    const int64_t n = tiles * rec_out;
+    hipLaunchKernelGGL(pack_slim_records, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), stats, tiles, rec_in,
+                       rec_out, out);
+    return check_launch("mtq_pack_slim_records");
+}
 
 extern "C" int mtq_tile_stats_batched(const void *x, int in_dtype, int64_t count, int64_t stride_elems, int64_t rows,
                                       int64_t cols, int64_t ld, uint32_t fmt_mask, double *stats, void *stream)

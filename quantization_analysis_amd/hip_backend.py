@@ -25,7 +25,7 @@ TILE = 32
 # every symbol include/mtq.h declares (tests check the library exports exactly these)
 EXPORTS = [
     "mtq_version", "mtq_last_error", "mtq_device_count", "mtq_stats_record_doubles",
-    "mtq_tile_stats", "mtq_tile_stats_batched", "mtq_quantize", "mtq_apply_assignment", "mtq_dequant_fp8_block",
+    "mtq_tile_stats", "mtq_tile_stats_batched", "mtq_quantize", "mtq_apply_assignment", "mtq_dequant_fp8_block", "mtq_pack_slim_records",
     "mtq_greedy_create", "mtq_greedy_pass", "mtq_greedy_assignment", "mtq_greedy_fixed",
     "mtq_greedy_counts", "mtq_greedy_value", "mtq_greedy_destroy",
     "mtq_tile_scores", "mtq_threshold_assign", "mtq_columns_from_stats", "mtq_columns_from_sums", "mtq_tile_scores_device",
@@ -89,6 +89,7 @@ def lib() -> ctypes.CDLL:
     L.mtq_threshold_assign.argtypes = [vp, i64, u32, vp, ci, ci, dbl, dbl, vp, vp, i64, ctypes.POINTER(i64)]
     L.mtq_columns_from_stats.argtypes = [vp, i64, u32, vp, dbl, vp]
     L.mtq_columns_from_sums.argtypes = [vp, dbl, vp]
+    L.mtq_pack_slim_records.argtypes = [vp, i64, u32, vp, vp]
     L.mtq_tile_scores_device.argtypes = [vp, i64, u32, ci, vp, vp]
     L.mtq_threshold_assign_device.argtypes = [vp, i64, u32, vp, ci, ci, dbl, dbl, vp, vp, vp]
     L.mtq_columns_scratch_doubles.argtypes = []
@@ -125,6 +126,7 @@ def mask_formats(mask: int) -> list[str]:
 
 
 MASK_BF16_IDENTITY = 0x10  # include/mtq.h MTQ_MASK_BF16_IDENTITY (host functions only)
+MASK_SLIM = 0x20           # include/mtq.h MTQ_MASK_SLIM (pcc greedy scan on 3-double slots)
 
 
 def parse_cpulist(text: str) -> set:
@@ -162,7 +164,19 @@ def bind_to_gpu_numa_node(device_index: int) -> str:
 
 
 def record_doubles(mask: int) -> int:
-    return 2 + 5 * bin(mask & 0xF).count("1")
+    return 2 + (3 if mask & MASK_SLIM else 5) * bin(mask & 0xF).count("1")
+
+
+def pack_slim_records(stats_dev, mask: int, out=None):
+    """Device copy of K1's records [..., tiles, 2+5F] without Σ|d| and max: [..., tiles, 2+3F] (mtq_pack_slim_records)."""
+    torch = _torch()
+    require_gpu()
+    lead = tuple(stats_dev.shape[:-1])
+    T = int(np.prod(lead))
+    if out is None:
+        out = torch.empty(lead + (record_doubles(mask | MASK_SLIM),), dtype=torch.float64, device=stats_dev.device)
+    check(lib().mtq_pack_slim_records(stats_dev.data_ptr(), T, mask & 0xF, out.data_ptr(), _stream_ptr()))
+    return out
 
 
 def tiles_hw(rows: int, cols: int) -> tuple[int, int]:

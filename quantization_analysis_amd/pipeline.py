@@ -59,6 +59,19 @@ def _scan_chunk(first, stats, mask, tiles_hw, numel, tile_formats, metric, thres
     return res
 
 
+def columns_from_sums_batch(sums: np.ndarray, n: float) -> np.ndarray:
+    """mtq_columns_from_sums for many tensors at once: sums [count, 7] (Σx, Σx², Σy, Σy², Σxy, Σ|d|, max|d|) → [count, 3]
+    pcc, mae, atol — the same double operations in the same order (metrics.py:6-16 as moments), element-wise in NumPy."""
+    sx, sx2, sy, sy2, sxy, sab, mx = (sums[:, i] for i in range(7))
+    mean_x, mean_y = sx / n, sy / n
+    am2 = np.maximum(sx2 - n * mean_x * mean_x, 0.0)
+    bm2 = np.maximum(sy2 - n * mean_y * mean_y, 0.0)
+    denom = np.sqrt(am2 * bm2)
+    with np.errstate(all="ignore"):
+        pcc = np.where(denom == 0.0, np.where(sab == 0.0, 1.0, 0.0), (sxy - n * mean_x * mean_y) / denom)
+    return np.stack([pcc, sab / n if n != 0.0 else np.zeros_like(sab), mx], axis=1)
+
+
 class GreedyPipeline:
     """mixed-tile-greedy over a (count, rows, cols) device tensor of equally shaped bf16/fp32 matrices."""
 
@@ -78,20 +91,35 @@ class GreedyPipeline:
         self.pool = cf.ThreadPoolExecutor(max_workers=3)  # chunk-level tasks; the fan-out over tensors happens inside the C call (shared scan pool)
         self.stream = torch.cuda.Stream()        # K1 launches
         self.copy_stream = torch.cuda.Stream()   # records D2H, overlapped with the next chunk's K1
+        self.col_stream = torch.cuda.Stream()    # maps up / column sums / sums down of a finished batch (must not queue behind the next batch's copies)
         self.timing = KernelTiming()
         self._bufs = {}
         self._open = []        # enqueued, not yet finished (oldest first)
         self._next_slot = 0
 
-    def _buffers(self, slot: int, count: int, tiles: int, rec: int, device):
-        """Records of a whole batch: device buffer + pinned host mirror (scans read the pinned memory in place).  Two slots
-        alternate so that a batch can be on the GPU / the PCIe link while the previous one is still being scanned."""
-        key = (count, tiles, rec, str(device))
+    def _layout(self, x3d):
+        """→ (K1 mask, host mask, slim?) for a batch.  bf16 storage: the bf16 candidate is the identity, its record slot would be
+        [Σx, Σx², Σx², 0, 0]; K1 then writes the BFP slots only and the host scan synthesises format 0
+        (MTQ_MASK_BF16_IDENTITY).  pcc metric: Σ|d| and max feed no decision (bar the zero-variance case), so a slim copy of the
+        records (3 doubles per format, MTQ_MASK_SLIM) crosses PCIe and the result's mae / atol come from the device."""
+        torch = self.torch
+        identity = x3d.dtype == torch.bfloat16 and (self.mask & 1) and (self.mask & 0xE) and os.environ.get("MTQ_IDENTITY_RECORDS", "1") != "0"
+        k1_mask = self.mask & 0xE if identity else self.mask
+        host_mask = k1_mask | hb.MASK_BF16_IDENTITY if identity else self.mask
+        slim = self.metric == "pcc" and os.environ.get("MTQ_SLIM_RECORDS", "1") != "0"
+        return k1_mask, host_mask | (hb.MASK_SLIM if slim else 0), slim
+
+    def _buffers(self, slot: int, count: int, tiles: int, rec: int, rec_host: int, device):
+        """Records of a whole batch: device buffer (full records, what K1 writes), device staging buffer of what crosses PCIe
+        (the same buffer unless the records are slimmed) and its pinned host mirror (scans read the pinned memory in place).
+        Two slots alternate so that a batch can be on the GPU / the PCIe link while the previous one is still being scanned."""
+        key = (count, tiles, rec, rec_host, str(device))
         if self._bufs.get(slot, (None,))[0] != key:
             torch = self.torch
             dev = torch.empty((count, tiles, rec), dtype=torch.float64, device=device)
-            host = torch.empty((count, tiles, rec), dtype=torch.float64, pin_memory=True)
-            self._bufs[slot] = (key, dev, host, host.numpy())
+            stage = dev if rec_host == rec else torch.empty((count, tiles, rec_host), dtype=torch.float64, device=device)
+            host = torch.empty((count, tiles, rec_host), dtype=torch.float64, pin_memory=True)
+            self._bufs[slot] = (key, dev, stage, host, host.numpy())
         return self._bufs[slot][1:]
 
     def reserve(self, x3d) -> None:
@@ -100,33 +128,29 @@ class GreedyPipeline:
         torch = self.torch
         count, rows, cols = x3d.shape
         th, tw = hb.tiles_hw(rows, cols)
-        identity = x3d.dtype == torch.bfloat16 and (self.mask & 1) and (self.mask & 0xE) and os.environ.get("MTQ_IDENTITY_RECORDS", "1") != "0"
-        rec = hb.record_doubles(self.mask & 0xE if identity else self.mask)
+        k1_mask, host_mask, _slim = self._layout(x3d)
         for slot in (0, 1):
-            dev, host, _np = self._buffers(slot, count, th * tw, rec, x3d.device)
+            dev, stage, host, _np = self._buffers(slot, count, th * tw, hb.record_doubles(k1_mask), hb.record_doubles(host_mask), x3d.device)
             dev.zero_()
-            host.copy_(dev, non_blocking=True)   # first DMA into the pinned pages (mappings are set up lazily)
+            stage.zero_()
+            host.copy_(stage, non_blocking=True)   # first DMA into the pinned pages (mappings are set up lazily)
         torch.cuda.synchronize()
         hb.greedy_run_batch(np.zeros((self.workers, 1, hb.record_doubles(0xF))), 0xF, ["bf16"], self.metric, self.threshold, 1024.0,
                             [1] * self.workers, self.workers)
 
     def enqueue(self, x3d, seeds=None) -> dict:
-        """GPU half of a batch, non-blocking: per chunk K1 on the launch stream and the records' D2H on the copy stream.
-        At most two batches may be enqueued and not yet finished (two record slots)."""
+        """GPU half of a batch, non-blocking: per chunk K1 on the launch stream (plus the slim copy of its records) and the
+        records' D2H on the copy stream.  At most two batches may be enqueued and not yet finished (two record slots)."""
         torch = self.torch
         if len(self._open) >= 2:
             raise RuntimeError("finish() an enqueued batch before enqueuing a third one")
         count, rows, cols = x3d.shape
         th, tw = hb.tiles_hw(rows, cols)
-        # bf16 storage: the bf16 candidate is the identity, its record slot would be [Σx, Σx², Σx², 0, 0]; K1 then writes
-        # the BFP slots only and the host scan synthesises format 0 (MTQ_MASK_BF16_IDENTITY): 23 % fewer bytes over PCIe
-        identity = x3d.dtype == torch.bfloat16 and (self.mask & 1) and (self.mask & 0xE) and os.environ.get("MTQ_IDENTITY_RECORDS", "1") != "0"
-        k1_mask = self.mask & 0xE if identity else self.mask
-        host_mask = k1_mask | hb.MASK_BF16_IDENTITY if identity else self.mask
-        tiles, rec = th * tw, hb.record_doubles(k1_mask)
+        k1_mask, host_mask, slim = self._layout(x3d)
+        tiles = th * tw
         slot = self._next_slot
         self._next_slot ^= 1
-        dev, host, host_np = self._buffers(slot, count, tiles, rec, x3d.device)
+        dev, stage, host, host_np = self._buffers(slot, count, tiles, hb.record_doubles(k1_mask), hb.record_doubles(host_mask), x3d.device)
         pending = []  # (event, first_index, n)
         self.stream.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(self.stream):
@@ -138,33 +162,70 @@ class GreedyPipeline:
                 hb.tile_stats_batched(x3d[first:first + n], k1_mask, out=dev[first:first + n])
                 e1.record(self.stream)
                 self.timing.events.append((e0, e1, n * tiles))
-                self.copy_stream.wait_event(e1)
+                ready = e1
+                if slim:
+                    hb.pack_slim_records(dev[first:first + n], k1_mask, out=stage[first:first + n])
+                    ready = torch.cuda.Event()
+                    ready.record(self.stream)
+                self.copy_stream.wait_event(ready)
                 with torch.cuda.stream(self.copy_stream):
-                    host[first:first + n].copy_(dev[first:first + n], non_blocking=True)
+                    host[first:first + n].copy_(stage[first:first + n], non_blocking=True)
                     done = torch.cuda.Event(blocking=True)   # the driver thread sleeps while it waits: spinning would burn a core of the scan budget
                     done.record(self.copy_stream)
                 pending.append((done, first, n))
         enq = {"pending": pending, "host_np": host_np, "host_mask": host_mask, "tiles_hw": (th, tw), "numel": rows * cols,
-               "seeds": seeds, "x": x3d}
+               "seeds": seeds, "x": x3d, "dev": dev, "k1_mask": k1_mask, "slim": slim}
         self._open.append(enq)
         return enq
+
+    def _scan_args(self, enq: dict, first: int, n: int, stats, mask):
+        seeds = enq["seeds"]
+        sd = [self.seed] * n if seeds is None else [int(v) for v in seeds[first:first + n]]
+        return (first, stats, mask, enq["tiles_hw"], enq["numel"], self.tile_formats, self.metric, self.threshold, sd, self.workers)
 
     def finish(self, enq: dict) -> list[TensorResult]:
         """Host half: as each chunk's records land, its scans go to the scan pool; returns when all of them are done.
         The GPU meanwhile works on whatever was enqueued after this batch."""
+        torch = self.torch
         if not self._open or self._open[0] is not enq:
             raise RuntimeError("batches finish in the order they were enqueued")
         futures = []
         for evt, first, n in enq["pending"]:
             evt.synchronize()
-            seeds = enq["seeds"]
-            sd = [self.seed] * n if seeds is None else [int(v) for v in seeds[first:first + n]]
-            futures.append(self.pool.submit(_scan_chunk, first, enq["host_np"][first:first + n], enq["host_mask"], enq["tiles_hw"],
-                                            enq["numel"], self.tile_formats, self.metric, self.threshold, sd, self.workers))
-        results = [r for f in futures for r in f.result()]
+            futures.append((first, n, self.pool.submit(_scan_chunk, *self._scan_args(enq, first, n, enq["host_np"][first:first + n], enq["host_mask"]))))
+        results: list[TensorResult] = []
+        for first, n, fut in futures:
+            try:
+                results.extend(fut.result())
+            except hb.MtqError:
+                if not enq["slim"]:
+                    raise
+                # a zero-variance tensor in this chunk: its decision needs Σ|x−y|, which the slim records do not carry
+                full = enq["dev"][first:first + n].cpu().numpy()
+                results.extend(_scan_chunk(*self._scan_args(enq, first, n, full, enq["host_mask"] & ~hb.MASK_SLIM)))
+        if enq["slim"]:
+            self._columns_from_device(enq, results)
         self._open.pop(0)
-        enq["x"] = None
+        enq["x"] = enq["dev"] = None
         return results
+
+    def _columns_from_device(self, enq: dict, results: list) -> None:
+        """pcc / mae / atol of every tensor of the batch from the full records on the device under the maps the scans
+        produced: maps up (1 B/tile), one batched reduction, seven doubles per tensor back."""
+        torch = self.torch
+        dev = enq["dev"]
+        count, tiles = dev.shape[0], dev.shape[1]
+        maps = np.stack([r.assignment.reshape(-1) for r in results])
+        with torch.cuda.stream(self.col_stream):
+            dmaps = torch.from_numpy(maps).to(dev.device, non_blocking=False)
+            scratch = torch.empty((count, int(hb.lib().mtq_columns_scratch_doubles())), dtype=torch.float64, device=dev.device)
+            hb.check(hb.lib().mtq_column_sums_device_batched(dev.data_ptr(), count, tiles, enq["host_mask"] & ~hb.MASK_SLIM, dmaps.data_ptr(),
+                                                             scratch.data_ptr(), self.col_stream.cuda_stream))
+            sums = scratch[:, :7].cpu().numpy()
+        cols = columns_from_sums_batch(sums, float(enq["numel"]))
+        k = {"pcc": 0, "mae": 1, "atol": 2}[self.metric]
+        for r, c in zip(results, cols):
+            r.pcc, r.mae, r.atol, r.metric_value = float(c[0]), float(c[1]), float(c[2]), float(c[k])
 
     def run(self, x3d, seeds=None) -> list[TensorResult]:
         """One batch, start to end (enqueue + finish)."""

@@ -197,6 +197,32 @@ def test_identity_bf16_mask_equals_full_records():
         hb.greedy_run(slim, 0xE, ALL, "pcc", 0.999, 1024.0, 5)
 
 
+def test_slim_records_equal_full_records_for_pcc():
+    """MTQ_MASK_SLIM: 3 doubles per format (Σy, Σy², Σxy) are all the pcc scan reads, except in the zero-variance case."""
+    for kind, shape, thr in (("normal_bf16", (256, 256), 0.999), ("heavy_f32", (160, 224), 0.99)):
+        x = gen(kind, 4, shape)
+        full = orc.tile_stats(x, ALL)
+        keep = [0, 1] + [2 + 5 * s + k for s in range(4) for k in range(3)]
+        slim = np.ascontiguousarray(full[:, keep])
+        assert slim.shape[1] == hb.record_doubles(0xF | hb.MASK_SLIM) == 14
+        for fmts in (ALL, ["bfp8", "bfp4"]):
+            a1, c1, _o1 = hb.greedy_run(full, 0xF, fmts, "pcc", thr, float(x.size), 31)
+            a2, c2, o2 = hb.greedy_run(slim, 0xF | hb.MASK_SLIM, fmts, "pcc", thr, float(x.size), 31)
+            assert np.array_equal(a1, a2) and c1 == c2 and np.isnan(o2["pcc"])
+    # identity + slim together (what the streamed driver sends for bf16 storage): 2 + 3*3 doubles
+    x = gen("normal_bf16", 5, (128, 256))
+    full = orc.tile_stats(x, ALL)
+    both = np.ascontiguousarray(full[:, [0, 1] + [2 + 5 * s + k for s in (1, 2, 3) for k in range(3)]])
+    a1, c1, _ = hb.greedy_run(full, 0xF, ALL, "pcc", 0.999, float(x.size), 9)
+    a2, c2, _ = hb.greedy_run(both, 0xE | hb.MASK_BF16_IDENTITY | hb.MASK_SLIM, ALL, "pcc", 0.999, float(x.size), 9)
+    assert np.array_equal(a1, a2) and c1 == c2 and both.shape[1] == 11
+    const = orc.tile_stats(np.full((64, 64), 0.5, dtype=np.float32), ALL)
+    with pytest.raises(hb.MtqError, match="zero-variance"):
+        hb.greedy_run(np.ascontiguousarray(const[:, keep]), 0xF | hb.MASK_SLIM, ALL, "pcc", 0.999, 4096.0, 3)
+    with pytest.raises(hb.MtqError):
+        hb.greedy_run(slim, 0xF | hb.MASK_SLIM, ALL, "mae", 1e-3, float(x.size), 3)
+
+
 def test_greedy_run_batch_equals_single_runs():
     xs = [gen("normal_bf16", s, (256, 256)) for s in range(5)]
     st = np.stack([orc.tile_stats(x, ALL) for x in xs])
