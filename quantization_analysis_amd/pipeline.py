@@ -94,6 +94,8 @@ class GreedyPipeline:
         self.col_stream = torch.cuda.Stream()    # maps up / column sums / sums down of a finished batch (must not queue behind the next batch's copies)
         self.timing = KernelTiming()
         self._bufs = {}
+        self._colbufs = {}
+        self._unresolved = []  # batches whose device-side columns are in flight (oldest first)
         self._open = []        # enqueued, not yet finished (oldest first)
         self._next_slot = 0
 
@@ -148,6 +150,8 @@ class GreedyPipeline:
         th, tw = hb.tiles_hw(rows, cols)
         k1_mask, host_mask, slim = self._layout(x3d)
         tiles = th * tw
+        while len(self._unresolved) > 1:                 # the batch two back owned the record slot this one takes
+            self.resolve(self._unresolved.pop(0))
         slot = self._next_slot
         self._next_slot ^= 1
         dev, stage, host, host_np = self._buffers(slot, count, tiles, hb.record_doubles(k1_mask), hb.record_doubles(host_mask), x3d.device)
@@ -183,9 +187,11 @@ class GreedyPipeline:
         sd = [self.seed] * n if seeds is None else [int(v) for v in seeds[first:first + n]]
         return (first, stats, mask, enq["tiles_hw"], enq["numel"], self.tile_formats, self.metric, self.threshold, sd, self.workers)
 
-    def finish(self, enq: dict) -> list[TensorResult]:
+    def finish(self, enq: dict, defer_columns: bool = False) -> list[TensorResult]:
         """Host half: as each chunk's records land, its scans go to the scan pool; returns when all of them are done.
-        The GPU meanwhile works on whatever was enqueued after this batch."""
+        The GPU meanwhile works on whatever was enqueued after this batch.  With defer_columns the device-side columns of a
+        slim batch are only LAUNCHED here (maps up, batched sums, seven doubles per tensor down, all asynchronous on their
+        own stream, all from this thread); resolve(enq) waits for them and fills pcc / mae / atol in."""
         torch = self.torch
         if not self._open or self._open[0] is not enq:
             raise RuntimeError("batches finish in the order they were enqueued")
@@ -203,29 +209,56 @@ class GreedyPipeline:
                 # a zero-variance tensor in this chunk: its decision needs Σ|x−y|, which the slim records do not carry
                 full = enq["dev"][first:first + n].cpu().numpy()
                 results.extend(_scan_chunk(*self._scan_args(enq, first, n, full, enq["host_mask"] & ~hb.MASK_SLIM)))
-        if enq["slim"]:
-            self._columns_from_device(enq, results)
         self._open.pop(0)
-        enq["x"] = enq["dev"] = None
+        enq["x"] = None
+        if enq["slim"]:
+            self._launch_columns(enq, results)
+            if not defer_columns:
+                self.resolve(enq)
         return results
 
-    def _columns_from_device(self, enq: dict, results: list) -> None:
+    def _launch_columns(self, enq: dict, results: list) -> None:
         """pcc / mae / atol of every tensor of the batch from the full records on the device under the maps the scans
-        produced: maps up (1 B/tile), one batched reduction, seven doubles per tensor back."""
+        produced: maps up (1 B/tile), one batched reduction, seven doubles per tensor back — launched, not waited for."""
         torch = self.torch
         dev = enq["dev"]
         count, tiles = dev.shape[0], dev.shape[1]
-        maps = np.stack([r.assignment.reshape(-1) for r in results])
+        key = (count, tiles, str(dev.device))
+        if self._colbufs.get("key") != key:
+            n_scratch = int(hb.lib().mtq_columns_scratch_doubles())
+            self._colbufs = {"key": key, "ring": [
+                {"maps_host": torch.empty((count, tiles), dtype=torch.int8, pin_memory=True),
+                 "maps_dev": torch.empty((count, tiles), dtype=torch.int8, device=dev.device),
+                 "scratch": torch.empty((count, n_scratch), dtype=torch.float64, device=dev.device),
+                 "sums_host": torch.empty((count, 7), dtype=torch.float64, pin_memory=True)} for _ in range(2)], "next": 0}
+        cb = self._colbufs["ring"][self._colbufs["next"]]
+        self._colbufs["next"] ^= 1
+        mh = cb["maps_host"].numpy()
+        for i, r in enumerate(results):
+            mh[i] = r.assignment.reshape(-1)
+        # no stream dependency is needed (and none wanted: the copy stream already holds the NEXT batch's copies): this batch's
+        # records were complete before its D2H events fired, and those were waited for above
         with torch.cuda.stream(self.col_stream):
-            dmaps = torch.from_numpy(maps).to(dev.device, non_blocking=False)
-            scratch = torch.empty((count, int(hb.lib().mtq_columns_scratch_doubles())), dtype=torch.float64, device=dev.device)
-            hb.check(hb.lib().mtq_column_sums_device_batched(dev.data_ptr(), count, tiles, enq["host_mask"] & ~hb.MASK_SLIM, dmaps.data_ptr(),
-                                                             scratch.data_ptr(), self.col_stream.cuda_stream))
-            sums = scratch[:, :7].cpu().numpy()
-        cols = columns_from_sums_batch(sums, float(enq["numel"]))
+            cb["maps_dev"].copy_(cb["maps_host"], non_blocking=True)
+            hb.check(hb.lib().mtq_column_sums_device_batched(dev.data_ptr(), count, tiles, enq["host_mask"] & ~hb.MASK_SLIM, cb["maps_dev"].data_ptr(),
+                                                             cb["scratch"].data_ptr(), self.col_stream.cuda_stream))
+            cb["sums_host"].copy_(cb["scratch"][:, :7], non_blocking=True)
+            done = torch.cuda.Event(blocking=True)
+            done.record(self.col_stream)
+        enq["col_pending"] = (done, cb["sums_host"], results)
+
+    def resolve(self, enq: dict) -> None:
+        """Wait for the columns launched by finish(..., defer_columns=True) and fill them into the batch's results."""
+        pend = enq.pop("col_pending", None)
+        if pend is None:
+            return
+        done, sums_host, results = pend
+        done.synchronize()
+        cols = columns_from_sums_batch(sums_host.numpy(), float(enq["numel"]))
         k = {"pcc": 0, "mae": 1, "atol": 2}[self.metric]
         for r, c in zip(results, cols):
             r.pcc, r.mae, r.atol, r.metric_value = float(c[0]), float(c[1]), float(c[2]), float(c[k])
+        enq["dev"] = None
 
     def run(self, x3d, seeds=None) -> list[TensorResult]:
         """One batch, start to end (enqueue + finish)."""
@@ -244,10 +277,13 @@ class GreedyPipeline:
         for x3d in batches:
             cur = self.enqueue(x3d)
             if prev is not None:
-                results = self.finish(prev)
+                results = self.finish(prev, defer_columns=True)   # columns launched; collected while the next batch is scanned
+                self._unresolved.append(prev)
             prev = cur
         if prev is not None:
             results = self.finish(prev)
+        while self._unresolved:
+            self.resolve(self._unresolved.pop(0))
         torch.cuda.current_stream().wait_stream(self.stream)
         torch.cuda.current_stream().wait_stream(self.copy_stream)
         return results
