@@ -88,7 +88,7 @@ class GreedyPipeline:
             raise ValueError("seed 0 means 'draw a random seed' in the reference; pass a non-zero seed")
         self.chunk = int(chunk)
         self.workers = int(workers)
-        self.pool = cf.ThreadPoolExecutor(max_workers=3)  # chunk-level tasks; the fan-out over tensors happens inside the C call (shared scan pool)
+        self.pool = cf.ThreadPoolExecutor(max_workers=int(os.environ.get("MTQ_CHUNK_TASKS", "8")))  # chunk-level tasks; the fan-out over tensors happens inside the C call (shared scan pool)
         self.stream = torch.cuda.Stream()        # K1 launches
         self.copy_stream = torch.cuda.Stream()   # records D2H, overlapped with the next chunk's K1
         self.col_stream = torch.cuda.Stream()    # maps up / column sums / sums down of a finished batch (must not queue behind the next batch's copies)
