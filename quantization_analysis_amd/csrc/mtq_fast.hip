@@ -136,7 +136,7 @@ __device__ __forceinline__ void fast_group(const uint32_t w[8], GroupOut &G, Rel
     FmtAcc A8 = {0, 0u, 0u, 0u, 0, 0x80008000u, 0x80008000u}, A4 = A8, A2 = A8; // biased extremes start at δ = 0: a phantom zero never changes max |δ|
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-        const uint32_t e = (ab[i] >> 7) & 0x00FF00FFu;
+        const uint32_t e = pk_lshr(ab[i], 0x00070007u);          // per-half exponent field (the sign bits are already cleared)
         const uint32_t d = as_u32(__builtin_elementwise_min(as_us2(Ep - e), as_us2(0x000F000Fu))); // min(E−e, 15) per half
         dor |= d + 0x00010001u;                                 // bit 4 of a half set ⇔ that element is in the tail class
         const uint32_t m = (ab[i] & 0x007F007Fu) | 0x00800080u;
