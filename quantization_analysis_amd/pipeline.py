@@ -372,11 +372,11 @@ class ThresholdPipeline:
             scratch = torch.empty((n, scratch_n), dtype=torch.float64, device=x3d.device)
             dmaps = dmaps.contiguous()
             hb.check(hb.lib().mtq_column_sums_device_batched(recs.data_ptr(), n, tiles, dec_mask, dmaps.data_ptr(), scratch.data_ptr(), hb._stream_ptr()))
-            sums = scratch[:, :7].cpu().numpy()
+            cols = columns_from_sums_batch(scratch[:, :7].cpu().numpy(), float(numel))
+            k = {"pcc": 0, "mae": 1, "atol": 2}[self.metric]
             for j in range(n):
-                cols_j = hb.columns_from_sums(sums[j], float(numel))
                 bc = np.bincount(maps[j], minlength=len(MIXED_TILE_FORMATS))
                 counts = {f: int(bc[i]) for i, f in enumerate(MIXED_TILE_FORMATS)}
-                results.append(TensorResult(first + j, maps[j].reshape(th, tw), counts, mixed_tile_total_bytes(counts), cols_j["pcc"], cols_j["mae"],
-                                            cols_j["atol"], cols_j[self.metric]))
+                results.append(TensorResult(first + j, maps[j].reshape(th, tw), counts, mixed_tile_total_bytes(counts), float(cols[j, 0]),
+                                            float(cols[j, 1]), float(cols[j, 2]), float(cols[j, k])))
         return results
