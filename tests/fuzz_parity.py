@@ -1,0 +1,83 @@
+"""Randomised GPU-vs-oracle parity sweep (not collected by pytest; run by hand on an MI355X box):
+    python tests/fuzz_parity.py [cases] [seed]
+Random shapes (ragged and aligned), storage types, value distributions (wide exponent spreads, zeros, sparse groups,
+huge / tiny scales), format subsets: K1 records, K2 / K3 outputs and greedy / threshold maps against the CPU oracle, bit for bit."""
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, __file__.rsplit("/tests/", 1)[0])
+import torch  # noqa: E402
+
+from oracle import mtq_oracle as orc  # noqa: E402
+from quantization_analysis_amd import hip_backend as hb  # noqa: E402
+
+ALL = ["bf16", "bfp8", "bfp4", "bfp2"]
+
+
+def make(rng, shape, bf16):
+    kind = rng.integers(0, 6)
+    x = rng.standard_normal(shape)
+    if kind == 1:
+        x *= np.exp(rng.standard_normal(shape) * 2.0)
+    elif kind == 2:
+        x *= np.exp2(rng.integers(-30, 30, size=shape))
+    elif kind == 3:
+        x *= rng.random(shape) < 0.3
+    elif kind == 4:
+        x *= np.repeat(rng.random((shape[0], -(-shape[1] // 16))) < 0.5, 16, axis=1)[:, : shape[1]]
+    elif kind == 5:
+        x *= np.exp2(float(rng.integers(-60, 60)))
+    x = (x * 0.02).astype(np.float32)
+    if bf16:
+        x = torch.from_numpy(x).to(torch.bfloat16).float().numpy()
+    return x
+
+
+def eq(a, b):
+    both = np.isnan(a) & np.isnan(b)
+    return np.array_equal(np.where(both, 0, a.view(np.uint64 if a.dtype == np.float64 else np.uint32)),
+                          np.where(both, 0, b.view(np.uint64 if b.dtype == np.float64 else np.uint32)))
+
+
+def main():
+    cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+    rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+    hb.require_gpu()
+    t0 = time.time()
+    bad = 0
+    for c in range(cases):
+        aligned = rng.random() < 0.4
+        rows = int(rng.integers(1, 6)) * 32 if aligned else int(rng.integers(1, 200))
+        cols = int(rng.integers(1, 5)) * 128 if aligned else int(rng.integers(1, 300))
+        bf16 = bool(rng.random() < 0.5)
+        x = make(rng, (rows, cols), bf16)
+        mask = int(rng.integers(1, 16))
+        fm = [f for i, f in enumerate(ALL) if mask >> i & 1]
+        xd = torch.from_numpy(x).to(torch.bfloat16).cuda() if bf16 else torch.from_numpy(x).cuda()
+        with np.errstate(all="ignore"):
+            want = orc.tile_stats(x, fm)
+            got = hb.tile_stats(xd, mask).cpu().numpy()
+            ok = eq(got, want)
+            fmt = ALL[int(rng.integers(0, 4))]
+            ok_q = eq(hb.quantize(xd, fmt).cpu().numpy(), orc.quantize_weight_values(x, fmt))
+            th, tw = -(-rows // 32), -(-cols // 32)
+            amap = rng.integers(0, 4, size=(th, tw)).astype(np.int8)
+            ok_a = eq(hb.apply_assignment(xd, amap).cpu().numpy(), orc.apply_assignment(x, amap))
+            ok_g = ok_t = True
+            if c % 4 == 0 and np.isfinite(x).all() and np.abs(x).max() > 0:
+                thr = float(rng.choice([0.99, 0.999, 0.9]))
+                a, _counts, _st = orc.greedy(x, ALL, "pcc", thr, 7)
+                full = hb.tile_stats(xd, 0xF).cpu().numpy()
+                g, _c2, _o = hb.greedy_run(full, 0xF, ALL, "pcc", thr, float(x.size), 7)
+                ok_g = np.array_equal(g.reshape(a.shape), a)
+        if not (ok and ok_q and ok_a and ok_g and ok_t):
+            bad += 1
+            print(f"MISMATCH case {c}: shape {(rows, cols)} bf16 {bf16} mask {mask:#x} fmt {fmt}: stats {ok} quantize {ok_q} apply {ok_a} greedy {ok_g}", flush=True)
+    print(f"{cases} cases, {bad} mismatches, {time.time() - t0:.1f} s")
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    raise SystemExit(main())
