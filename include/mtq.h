@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define MTQ_VERSION 120 /* 0.1.2: + mtq_rng_integers, identity-bf16 mask, device-side decisions */
+#define MTQ_VERSION 121 /* 0.1.2: + mtq_rng_integers, identity-bf16 mask, device-side decisions */
 
 typedef enum {
     MTQ_OK = 0,
@@ -197,12 +197,14 @@ int mtq_tile_scores(const double *stats, int64_t tiles, uint32_t fmt_mask, int m
  * K4 threshold_assign — mixed_tile_threshold.py:111-123 / scripts/sweep_mixed_tile_threshold.py:145-155:
  * per tile the lowest-bytes format among `formats` whose score passes, else the highest-bytes one.
  * The reference compares float32 scores with a float32-rounded threshold (NumPy ≥ 2, NEP 50);
- * tiles whose float64 score lies within `band` of float32(threshold) are listed in knife_ids
- * (capacity knife_cap) so the caller can re-score exactly those with the literal float32 expression.
+ * tiles with a looked-at format whose float64 score lies within `band` of float32(threshold) are listed in knife_ids
+ * (capacity knife_cap), with the bit mask of those format codes in knife_near (nullable, same capacity), so the caller
+ * can decide exactly those formats of those tiles with the literal float32 expression.  Formats behind the chosen one
+ * were not looked at.
  */
 int mtq_threshold_assign(const double *stats, int64_t tiles, uint32_t fmt_mask,
                          const int *formats, int n_formats, int metric, double threshold, double band,
-                         int8_t *map, int64_t *knife_ids, int64_t knife_cap, int64_t *n_knife);
+                         int8_t *map, int64_t *knife_ids, uint8_t *knife_near, int64_t knife_cap, int64_t *n_knife);
 
 /*
  * Tensor-level columns (pcc, mae, atol) of the reconstruction a map implies, from the raw sums in
@@ -228,8 +230,9 @@ int mtq_columns_from_sums(const double sums[7], double elem_count, double out[9]
 /* mtq_tile_scores on the device: scores[formats][tiles] (device), rows as documented for mtq_tile_scores. */
 int mtq_tile_scores_device(const double *stats, int64_t tiles, uint32_t fmt_mask, int metric, double *scores, void *stream);
 
-/* K4: mtq_threshold_assign on the device.  map: int8[tiles]; knife: uint8[tiles], 1 where a looked-at format's score is
- * within `band` of float32(threshold) (the caller re-scores those tiles with the literal float32 expression). */
+/* K4: mtq_threshold_assign on the device.  map: int8[tiles]; knife: uint8[tiles], bit c set where looked-at format code c
+ * scores within `band` of float32(threshold) (0 for most tiles; the caller decides those formats of those tiles with the
+ * literal float32 expression). */
 int mtq_threshold_assign_device(const double *stats, int64_t tiles, uint32_t fmt_mask, const int *formats, int n_formats,
                                 int metric, double threshold, double band, int8_t *map, uint8_t *knife, void *stream);
 

@@ -29,31 +29,61 @@ def threshold_assign(ts: TileStats, tile_formats: list[str], metric: str, thresh
     from .. import hip_backend as hb
 
     if ts.on_device and ts.host_stats is None:  # K4 on the device: the records stay where K1 wrote them
-        amap, knife = hb.threshold_assign_device(ts.stats_dev, ts.mask, tile_formats, metric, threshold, band)
+        amap, knife, near = hb.threshold_assign_device(ts.stats_dev, ts.mask, tile_formats, metric, threshold, band, with_near=True)
     else:
-        amap, knife = hb.threshold_assign(ts.stats, ts.mask, tile_formats, metric, threshold, band)
-    rescore_knife_tiles(ts, amap, knife, tile_formats, metric, threshold, quantizer)
+        amap, knife, near = hb.threshold_assign(ts.stats, ts.mask, tile_formats, metric, threshold, band, with_near=True)
+    rescore_knife_tiles(ts, amap, knife, tile_formats, metric, threshold, quantizer, near)
     return amap.reshape(ts.tiles_h, ts.tiles_w), int(knife.size)
 
 
-def rescore_knife_tiles(ts: TileStats, amap: np.ndarray, knife: np.ndarray, tile_formats: list[str], metric: str, threshold: float,
-                        quantizer: Quantizer) -> None:
-    """Decide the tiles in `knife` again with the literal float32 per-tile score of the reference (tile_utils.py:46-57 on y
-    tiles quantized through the selected backend) and patch the flat int8 map `amap` in place."""
-    if not knife.size:
-        return
+def decide_knife_tiles(chosen: np.ndarray, near: np.ndarray, tile_formats: list[str], metric: str, threshold: float, literal_scores) -> np.ndarray:
+    """The reference's rule (:111-123) for the knife-edge tiles, evaluating the literal float32 score only where it can
+    change the outcome.  `chosen[k]` is K4's format code for knife tile k and `near[k]` the mask of format codes whose float64
+    score fell inside the noise band.  K4 walked the formats in ascending bytes up to the chosen one: a looked-at format
+    outside the band keeps its float64 decision (failed before the chosen one, passed at it — the same trust every
+    non-knife tile gets); a format inside the band, and any format behind the chosen one once that is overturned, is
+    decided by `literal_scores(fmt, sel)` → np.float32 scores of knife tiles `sel` (tile_utils.py:46-57 on y quantized
+    through the selected backend).  → int8 codes."""
     by_prec = sorted(tile_formats, key=lambda f: MIXED_TILE_BYTES_PER_ELEM.get(f, 0.0))  # :112-114
     best = max(by_prec, key=lambda f: MIXED_TILE_BYTES_PER_ELEM.get(f, 0.0))             # :115
+    codes = [MIXED_TILE_FORMATS.index(f) for f in by_prec]
+    rank = np.full(len(MIXED_TILE_FORMATS), len(by_prec), dtype=np.int64)
+    for i, c in enumerate(codes):
+        rank[c] = i
+    seen_upto = rank[np.asarray(chosen, dtype=np.int64)]     # index (ascending bytes) of the last format K4 looked at
+    out = np.full(len(chosen), MIXED_TILE_FORMATS.index(best), dtype=np.int8)
+    open_ = np.ones(len(chosen), dtype=bool)
+    for i, (f, c) in enumerate(zip(by_prec, codes)):
+        if not open_.any():
+            break
+        literal = open_ & ((((near >> c) & 1) != 0) | (i > seen_upto))
+        passed = open_ & ~literal & (i == seen_upto)
+        sel = np.flatnonzero(literal)
+        if sel.size:
+            scores = literal_scores(f, sel)
+            ok = np.fromiter((metric_is_good(scores[k], metric, threshold) for k in range(sel.size)), dtype=bool, count=sel.size)
+            passed[sel[ok]] = True                                 # np.float32 vs Python float, as the reference
+        out[passed] = c
+        open_ &= ~passed
+    return out
+
+
+def rescore_knife_tiles(ts: TileStats, amap: np.ndarray, knife: np.ndarray, tile_formats: list[str], metric: str, threshold: float,
+                        quantizer: Quantizer, near: np.ndarray | None = None) -> None:
+    """Decide the tiles in `knife` again with the literal float32 per-tile score of the reference (tile_utils.py:46-57 on y
+    tiles quantized through the selected backend) and patch the flat int8 map `amap` in place.  Without `near` every format
+    of every knife tile is treated as inside the band."""
+    if not knife.size:
+        return
     x_tiles = gather_tiles(ts, knife)
-    scores = {f: tile_metrics(x_tiles, np.asarray(_quantize_tiles(x_tiles, f, quantizer), dtype=np.float32), metric)
-              for f in by_prec}
-    for k, t in enumerate(knife):
-        chosen = best
-        for f in by_prec:
-            if metric_is_good(scores[f][k], metric, threshold):  # np.float32 vs Python float, as the reference
-                chosen = f
-                break
-        amap[t] = MIXED_TILE_FORMATS.index(chosen)
+    if near is None:
+        near = np.full(knife.size, 0xF, dtype=np.uint8)
+
+    def literal_scores(fmt: str, sel: np.ndarray) -> np.ndarray:
+        xs = x_tiles[sel]
+        return tile_metrics(xs, np.asarray(_quantize_tiles(xs, fmt, quantizer), dtype=np.float32), metric)
+
+    amap[knife] = decide_knife_tiles(amap[knife], np.asarray(near, dtype=np.uint8), tile_formats, metric, threshold, literal_scores)
 
 
 def _quantize_tiles(x_tiles: np.ndarray, fmt: str, quantizer: Quantizer) -> np.ndarray:

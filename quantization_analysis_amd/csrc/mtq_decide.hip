@@ -36,9 +36,9 @@ __global__ __launch_bounds__(256) void threshold_assign_dev(const double *__rest
 {
     const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (t >= tiles) return;
-    bool k;
-    map[t] = (int8_t)threshold_decide(stats + t * rec, plan, metric, thr32, band, k);
-    knife[t] = k ? 1u : 0u;
+    unsigned near;
+    map[t] = (int8_t)threshold_decide(stats + t * rec, plan, metric, thr32, band, near);
+    knife[t] = (uint8_t)near;
 }
 
 constexpr int kColBlocks = 256, kColVals = 7;   // Σx, Σx², Σy, Σy², Σxy, Σ|d|, max|d|

@@ -331,7 +331,7 @@ extern "C" int mtq_tile_scores(const double *stats, int64_t tiles, uint32_t fmt_
 
 extern "C" int mtq_threshold_assign(const double *stats, int64_t tiles, uint32_t fmt_mask, const int *formats, int n_formats,
                                     int metric, double threshold, double band, int8_t *map, int64_t *knife_ids,
-                                    int64_t knife_cap, int64_t *n_knife)
+                                    uint8_t *knife_near, int64_t knife_cap, int64_t *n_knife)
 {
     if (!stats || !formats || !map) return fail(MTQ_ERR_INVALID, "null argument");
     if (n_formats <= 0 || n_formats > MTQ_NUM_TILE_FORMATS) return fail(MTQ_ERR_INVALID, "n_formats must be 1..4");
@@ -342,10 +342,13 @@ extern "C" int mtq_threshold_assign(const double *stats, int64_t tiles, uint32_t
     const double thr32 = (double)(float)threshold; // NumPy >= 2 compares np.float32 score with float32(threshold) (metrics.py:30-33, NEP 50)
     int64_t nk = 0;
     for (int64_t t = 0; t < tiles; ++t) {
-        bool knife;
-        map[t] = (int8_t)threshold_decide(stats + t * rec, plan, metric, thr32, band, knife);
-        if (knife) {
-            if (knife_ids && nk < knife_cap) knife_ids[nk] = t;
+        unsigned near;
+        map[t] = (int8_t)threshold_decide(stats + t * rec, plan, metric, thr32, band, near);
+        if (near) {
+            if (nk < knife_cap) {
+                if (knife_ids) knife_ids[nk] = t;
+                if (knife_near) knife_near[nk] = (uint8_t)near;
+            }
             ++nk;
         }
     }

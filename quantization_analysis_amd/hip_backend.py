@@ -86,7 +86,7 @@ def lib() -> ctypes.CDLL:
     L.mtq_greedy_destroy.argtypes = [vp]
     L.mtq_greedy_destroy.restype = None
     L.mtq_tile_scores.argtypes = [vp, i64, u32, ci, vp]
-    L.mtq_threshold_assign.argtypes = [vp, i64, u32, vp, ci, ci, dbl, dbl, vp, vp, i64, ctypes.POINTER(i64)]
+    L.mtq_threshold_assign.argtypes = [vp, i64, u32, vp, ci, ci, dbl, dbl, vp, vp, vp, i64, ctypes.POINTER(i64)]
     L.mtq_columns_from_stats.argtypes = [vp, i64, u32, vp, dbl, vp]
     L.mtq_columns_from_sums.argtypes = [vp, dbl, vp]
     L.mtq_pack_slim_records.argtypes = [vp, i64, u32, vp, vp]
@@ -103,7 +103,7 @@ def lib() -> ctypes.CDLL:
     L.mtq_rng_destroy.restype = None
     L.mtq_greedy_run.argtypes = [vp, i64, u32, vp, ci, ci, dbl, dbl, ctypes.c_uint64, vp, vp, vp]
     L.mtq_greedy_run_batch.argtypes = [vp, i64, i64, u32, vp, ci, ci, dbl, dbl, vp, vp, vp, vp, ci]
-    if L.mtq_version() < 120:
+    if L.mtq_version() < 121:
         raise MtqError("libmtq_hip.so is older than this package")
     _lib = L
     return L
@@ -442,17 +442,19 @@ def tile_scores(stats: np.ndarray, mask: int, metric: str) -> np.ndarray:
     return out
 
 
-def threshold_assign(stats: np.ndarray, mask: int, formats, metric: str, threshold: float, band: float = 2e-6):
-    """K4 on host stats → (int8[T] map, knife-edge tile ids)."""
+def threshold_assign(stats: np.ndarray, mask: int, formats, metric: str, threshold: float, band: float = 2e-6, with_near: bool = False):
+    """K4 on host stats → (int8[T] map, knife-edge tile ids[, uint8 masks of the format codes inside the band per id])."""
     stats = np.ascontiguousarray(stats, dtype=np.float64)
     T = stats.shape[0]
     fm = (ctypes.c_int * len(formats))(*[MIXED_TILE_FORMATS.index(f) for f in formats])
     amap = np.empty(T, dtype=np.int8)
     knife = np.empty(T, dtype=np.int64)
+    near = np.empty(T, dtype=np.uint8)
     nk = ctypes.c_int64(0)
     check(lib().mtq_threshold_assign(stats.ctypes.data, T, mask, fm, len(formats), METRIC_CODE[metric], float(threshold), float(band),
-                                     amap.ctypes.data, knife.ctypes.data, T, ctypes.byref(nk)))
-    return amap, knife[: min(nk.value, T)].copy()
+                                     amap.ctypes.data, knife.ctypes.data, near.ctypes.data, T, ctypes.byref(nk)))
+    k = min(nk.value, T)
+    return (amap, knife[:k].copy(), near[:k].copy()) if with_near else (amap, knife[:k].copy())
 
 
 def _score_rows(mask: int) -> int:
@@ -471,7 +473,8 @@ def tile_scores_device(stats_dev, mask: int, metric: str):
 
 def threshold_assign_device_raw(stats_dev, mask: int, formats, metric: str, threshold: float, band: float = 2e-6):
     """K4 on device-resident records [T, rec] (any number of tensors' tiles back to back) → device int8 [2, T]: row 0 the
-    map, row 1 the knife-edge flags; asynchronous on the current stream."""
+    map, row 1 the knife-edge masks (bit c: format code c scored inside the band; 0 for most tiles); asynchronous on the
+    current stream."""
     torch = _torch()
     require_gpu()
     T = stats_dev.shape[0]
@@ -482,10 +485,12 @@ def threshold_assign_device_raw(stats_dev, mask: int, formats, metric: str, thre
     return both
 
 
-def threshold_assign_device(stats_dev, mask: int, formats, metric: str, threshold: float, band: float = 2e-6):
-    """K4 on device-resident records → (int8[T] map on the host, knife-edge tile ids): only T + T bytes cross PCIe."""
+def threshold_assign_device(stats_dev, mask: int, formats, metric: str, threshold: float, band: float = 2e-6, with_near: bool = False):
+    """K4 on device-resident records → (int8[T] map on the host, knife-edge tile ids[, their near masks]): only T + T bytes
+    cross PCIe."""
     host = threshold_assign_device_raw(stats_dev, mask, formats, metric, threshold, band).cpu().numpy()
-    return host[0].copy(), np.nonzero(host[1])[0].astype(np.int64)
+    ids = np.flatnonzero(host[1]).astype(np.int64)
+    return (host[0].copy(), ids, host[1][ids].astype(np.uint8)) if with_near else (host[0].copy(), ids)
 
 
 def columns_from_sums(sums7: np.ndarray, elem_count: float) -> dict:

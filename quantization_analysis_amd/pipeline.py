@@ -313,11 +313,12 @@ class ThresholdPipeline:
         self.quantizer = Quantizer("hip")
         self.knife_tiles = 0
 
-    def _rescore_chunk(self, xc, maps: np.ndarray, jj: np.ndarray, tt: np.ndarray, tiles_w: int) -> None:
-        """The knife-edge tiles of a whole chunk at once: one indexed gather on the device, one K2 call per format, the
-        reference's literal float32 tile score (tile_utils.py:46-57), maps patched in place (reference :117-123)."""
-        from .compression_algorithms.metrics import metric_is_good
-        from .compression_algorithms.tile_utils import MIXED_TILE_BYTES_PER_ELEM, tile_metrics
+    def _rescore_chunk(self, xc, maps: np.ndarray, near: np.ndarray, jj: np.ndarray, tt: np.ndarray, tiles_w: int) -> None:
+        """The knife-edge tiles of a whole chunk at once: one indexed gather on the device, then per format K2 and the
+        reference's literal float32 tile score (tile_utils.py:46-57) for exactly the (tile, format) pairs inside the band
+        (mixed_tile_threshold.decide_knife_tiles); maps patched in place (reference :117-123)."""
+        from .compression_algorithms.mixed_tile_threshold import decide_knife_tiles
+        from .compression_algorithms.tile_utils import tile_metrics
 
         torch = self.torch
         n, h, w = xc.shape
@@ -331,17 +332,13 @@ class ThresholdPipeline:
         inside = (rows < h)[:, :, None] & (cols < w)[:, None, :]
         x_dev = torch.where(inside, vals, torch.zeros((), dtype=torch.float32, device=dev)).contiguous()   # (k, 32, 32), pads zero
         x_tiles = x_dev.cpu().numpy()
-        k = x_tiles.shape[0]
-        by_prec = sorted(self.tile_formats, key=lambda f: MIXED_TILE_BYTES_PER_ELEM.get(f, 0.0))
-        best = max(by_prec, key=lambda f: MIXED_TILE_BYTES_PER_ELEM.get(f, 0.0))
-        scores = {f: tile_metrics(x_tiles, hb.quantize(x_dev.view(k * 32, 32), f).cpu().numpy().reshape(k, 32, 32), self.metric) for f in by_prec}
-        for i in range(k):
-            chosen = best
-            for f in by_prec:
-                if metric_is_good(scores[f][i], self.metric, self.threshold):
-                    chosen = f
-                    break
-            maps[jj[i], tt[i]] = MIXED_TILE_FORMATS.index(chosen)
+
+        def literal_scores(fmt: str, sel: np.ndarray) -> np.ndarray:
+            xs = x_dev if sel.size == x_dev.shape[0] else x_dev[torch.from_numpy(sel).to(dev)]
+            y = hb.quantize(xs.reshape(sel.size * 32, 32), fmt).cpu().numpy().reshape(sel.size, 32, 32)
+            return tile_metrics(x_tiles[sel], y, self.metric)
+
+        maps[jj, tt] = decide_knife_tiles(maps[jj, tt], near[jj, tt].astype(np.uint8), self.tile_formats, self.metric, self.threshold, literal_scores)
 
     def run(self, x3d) -> list[TensorResult]:
         torch = self.torch
@@ -362,11 +359,11 @@ class ThresholdPipeline:
         torch.cuda.current_stream().synchronize()
         for first, n, recs, both, host in launched:
             maps = host[0].numpy().reshape(n, tiles).copy()
-            flags = host[1].numpy().reshape(n, tiles)
-            jj, tt = np.nonzero(flags)                                                         # knife-edge (tensor, tile) pairs of the chunk (few)
+            near = host[1].numpy().reshape(n, tiles)                                           # per tile: mask of format codes inside the band
+            jj, tt = np.divmod(np.flatnonzero(near.view(np.bool_)), tiles)                     # knife-edge (tensor, tile) pairs of the chunk (few)
             dirty = jj.size > 0
             if dirty:
-                self._rescore_chunk(x3d[first:first + n], maps, jj, tt, tw)
+                self._rescore_chunk(x3d[first:first + n], maps, near, jj, tt, tw)
                 self.knife_tiles += int(jj.size)
             dmaps = torch.from_numpy(maps).to(x3d.device) if dirty else both[0].view(n, tiles)
             scratch = torch.empty((n, scratch_n), dtype=torch.float64, device=x3d.device)

@@ -25,7 +25,7 @@ def test_header_symbols_exported():
     L = hb.lib()
     for name in declared:
         assert hasattr(L, name), name
-    assert L.mtq_version() == 120
+    assert L.mtq_version() == 121
     assert L.mtq_stats_record_doubles(0xF) == 22 and L.mtq_stats_record_doubles(0b0110) == 12
 
 
@@ -106,6 +106,40 @@ def test_host_threshold_assign_matches_golden_maps(golden_dir):
         for i, f in enumerate(fm):
             assert np.max(np.abs(sc[i] - d[f"{name}_score_{f}"].astype(np.float64))) <= 1e-6, (name, f)
     assert total_knife > 0  # the knife-edge fixtures must exercise the band
+
+
+def test_knife_tiles_are_decided_lazily_and_like_the_reference(golden_dir):
+    """decide_knife_tiles evaluates the literal float32 score only for the (tile, format) pairs inside the band — with a very
+    wide band (many knife tiles, partial masks) the patched map must still be the reference's map, and fewer literal
+    evaluations than tiles x formats must have been needed."""
+    from quantization_analysis_amd.compression_algorithms.mixed_tile_threshold import decide_knife_tiles
+    from quantization_analysis_amd.compression_algorithms.tile_utils import reshape_to_2d_with_padding, tile_metrics, to_tiles
+
+    d = np.load(golden_dir / "f5_threshold.npz")
+    meta = json.loads((golden_dir / "golden_meta.json").read_text())["f5"]
+    evaluated = possible = 0
+    for name, m in meta.items():
+        x = d[f"{name}_x"]
+        x2d, _ = orc.flatten_2d(x)
+        fm = [f for f in ALL if f in m["formats"]]
+        mask = hb.fmt_mask(fm)
+        stats = orc.tile_stats(x2d, fm)
+        band = 5e-3 if m["metric"] == "pcc" else 0.2 * float(m["threshold"])
+        amap, knife, near = hb.threshold_assign(stats, mask, m["formats"], m["metric"], m["threshold"], band=band, with_near=True)
+        assert np.all(near != 0) and knife.size == near.size
+        x_tiles = to_tiles(reshape_to_2d_with_padding(x)[0])
+        y_tiles = {f: to_tiles(reshape_to_2d_with_padding(orc.quantize_weight_values(x, f))[0]) for f in m["formats"]}
+        calls = []
+
+        def literal(fmt, sel):
+            calls.append(sel.size)
+            return tile_metrics(x_tiles[knife[sel]], y_tiles[fmt][knife[sel]], m["metric"])
+
+        amap[knife] = decide_knife_tiles(amap[knife], near, m["formats"], m["metric"], m["threshold"], literal)
+        assert np.array_equal(amap, d[f"{name}_assign"].reshape(-1)), name
+        evaluated += sum(calls)
+        possible += knife.size * len(m["formats"])
+    assert 0 < evaluated < possible
 
 
 def test_threshold_best_precision_and_order():
