@@ -357,6 +357,8 @@ class ThresholdPipeline:
             both = hb.threshold_assign_device_raw(recs.view(n * tiles, -1), dec_mask, self.tile_formats, self.metric, self.threshold, self.band)
             launched.append((first, n, recs, both, both.to("cpu", non_blocking=True)))
         torch.cuda.current_stream().synchronize()
+        codes = torch.arange(len(MIXED_TILE_FORMATS), dtype=torch.int8, device=x3d.device)
+        summed = []  # (first, n, host maps, column sums and per-format tile counts on the device)
         for first, n, recs, both, host in launched:
             maps = host[0].numpy().reshape(n, tiles).copy()
             near = host[1].numpy().reshape(n, tiles)                                           # per tile: mask of format codes inside the band
@@ -365,15 +367,16 @@ class ThresholdPipeline:
             if dirty:
                 self._rescore_chunk(x3d[first:first + n], maps, near, jj, tt, tw)
                 self.knife_tiles += int(jj.size)
-            dmaps = torch.from_numpy(maps).to(x3d.device) if dirty else both[0].view(n, tiles)
+            dmaps = (torch.from_numpy(maps).to(x3d.device) if dirty else both[0].view(n, tiles)).contiguous()
             scratch = torch.empty((n, scratch_n), dtype=torch.float64, device=x3d.device)
-            dmaps = dmaps.contiguous()
             hb.check(hb.lib().mtq_column_sums_device_batched(recs.data_ptr(), n, tiles, dec_mask, dmaps.data_ptr(), scratch.data_ptr(), hb._stream_ptr()))
+            summed.append((first, n, maps, scratch, (dmaps.unsqueeze(-1) == codes).sum(dim=1)))   # counts ≡ np.bincount per tensor
+        k = {"pcc": 0, "mae": 1, "atol": 2}[self.metric]
+        for first, n, maps, scratch, counts_dev in summed:                                      # one wait for all chunks' sums
             cols = columns_from_sums_batch(scratch[:, :7].cpu().numpy(), float(numel))
-            k = {"pcc": 0, "mae": 1, "atol": 2}[self.metric]
+            bc = counts_dev.cpu().numpy()
             for j in range(n):
-                bc = np.bincount(maps[j], minlength=len(MIXED_TILE_FORMATS))
-                counts = {f: int(bc[i]) for i, f in enumerate(MIXED_TILE_FORMATS)}
+                counts = {f: int(bc[j, i]) for i, f in enumerate(MIXED_TILE_FORMATS)}
                 results.append(TensorResult(first + j, maps[j].reshape(th, tw), counts, mixed_tile_total_bytes(counts), float(cols[j, 0]),
                                             float(cols[j, 1]), float(cols[j, 2]), float(cols[j, k])))
         return results
