@@ -1,7 +1,7 @@
 """Randomised GPU-vs-oracle parity sweep (not collected by pytest; run by hand on an MI355X box):
     python tests/fuzz_parity.py [cases] [seed]
 Random shapes (ragged and aligned), storage types, value distributions (wide exponent spreads, zeros, sparse groups,
-huge / tiny scales), format subsets: K1 records, K2 / K3 outputs and greedy / threshold maps against the CPU oracle, bit for bit."""
+huge / tiny scales, ±Inf / NaN / denormals — two NaNs compare equal whatever their payload), format subsets: K1 records, K2 / K3 outputs and greedy / threshold maps against the CPU oracle, bit for bit."""
 import sys
 import time
 
@@ -17,7 +17,7 @@ ALL = ["bf16", "bfp8", "bfp4", "bfp2"]
 
 
 def make(rng, shape, bf16):
-    kind = rng.integers(0, 6)
+    kind = rng.integers(0, 8)
     x = rng.standard_normal(shape)
     if kind == 1:
         x *= np.exp(rng.standard_normal(shape) * 2.0)
@@ -30,9 +30,19 @@ def make(rng, shape, bf16):
     elif kind == 5:
         x *= np.exp2(float(rng.integers(-60, 60)))
     x = (x * 0.02).astype(np.float32)
+    if kind == 6:   # specials: ±Inf, NaN, ±0, float32 denormals, the largest finite values
+        pool = np.array([np.inf, -np.inf, np.nan, 0.0, -0.0, 1e-40, -3e-39, 3.4e38, -3.3e38, 1.1754944e-38], dtype=np.float32)
+        hit = rng.random(shape) < 0.02
+        x = np.where(hit, pool[rng.integers(0, pool.size, size=shape)], x).astype(np.float32)
+    elif kind == 7:  # everything tiny or everything huge (exponents outside the exact route's window)
+        x = (x * np.float32(2.0) ** float(rng.choice([-120, -100, 100, 110]))).astype(np.float32)
     if bf16:
         x = torch.from_numpy(x).to(torch.bfloat16).float().numpy()
     return x
+
+
+def kind_ok(x):
+    return bool(np.isfinite(x).all() and np.abs(x).max() > 0 and np.isfinite(np.float64(x).__pow__(2).sum()))
 
 
 def eq(a, b):
@@ -41,9 +51,9 @@ def eq(a, b):
                           np.where(both, 0, b.view(np.uint64 if b.dtype == np.float64 else np.uint32)))
 
 
-def main():
-    cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
-    rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+def run(cases: int, seed: int) -> int:
+    """→ number of mismatching cases (each one is printed)."""
+    rng = np.random.default_rng(seed)
     hb.require_gpu()
     t0 = time.time()
     bad = 0
@@ -66,7 +76,7 @@ def main():
             amap = rng.integers(0, 4, size=(th, tw)).astype(np.int8)
             ok_a = eq(hb.apply_assignment(xd, amap).cpu().numpy(), orc.apply_assignment(x, amap))
             ok_g = ok_t = True
-            if c % 4 == 0 and np.isfinite(x).all() and np.abs(x).max() > 0:
+            if c % 4 == 0 and kind_ok(x):
                 thr = float(rng.choice([0.99, 0.999, 0.9]))
                 a, _counts, _st = orc.greedy(x, ALL, "pcc", thr, 7)
                 full = hb.tile_stats(xd, 0xF).cpu().numpy()
@@ -76,8 +86,8 @@ def main():
             bad += 1
             print(f"MISMATCH case {c}: shape {(rows, cols)} bf16 {bf16} mask {mask:#x} fmt {fmt}: stats {ok} quantize {ok_q} apply {ok_a} greedy {ok_g}", flush=True)
     print(f"{cases} cases, {bad} mismatches, {time.time() - t0:.1f} s")
-    return 1 if bad else 0
+    return bad
 
 
 if __name__ == "__main__":
-    raise SystemExit(main())
+    raise SystemExit(1 if run(int(sys.argv[1]) if len(sys.argv) > 1 else 200, int(sys.argv[2]) if len(sys.argv) > 2 else 1) else 0)
