@@ -24,7 +24,6 @@ from pathlib import Path
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
-import numpy as np
 import torch
 
 ROWS = COLS = 4096

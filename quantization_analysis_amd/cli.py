@@ -164,7 +164,6 @@ def _columns_emulation(xf: np.ndarray, y: np.ndarray):
 def _none_rows_hip(x, formats, quantizer):
     """`none` baseline on the hip backend: pcc/mae/atol of every pure mixed-tile format come from ONE
     K1 pass (sum the per-tile records); fp0 from three device reductions.  y is not materialised or cached."""
-    from . import hip_backend as hb
     from .compression_algorithms.tile_search import columns_from_stats, compute_tile_stats
 
     out = {}

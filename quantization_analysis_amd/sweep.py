@@ -10,10 +10,9 @@ from __future__ import annotations
 
 import numpy as np
 
-from . import hip_backend as hb
 from .compression_algorithms.mixed_tile_threshold import KNIFE_BAND, _quantize_tiles
 from .compression_algorithms.quantizer import Quantizer
-from .compression_algorithms.tile_search import columns_from_stats, compute_tile_stats, gather_tiles, slot_of, tile_scores
+from .compression_algorithms.tile_search import columns_from_stats, compute_tile_stats, gather_tiles, tile_scores
 from .compression_algorithms.tile_utils import MIXED_TILE_BYTES_PER_ELEM, MIXED_TILE_FORMATS, mixed_tile_total_bytes, tile_metrics
 
 
