@@ -5,11 +5,15 @@
 // Build with -ffp-contract=off: the reference evaluates these formulas as separately rounded
 // Python-float (IEEE double) operations (mixed_tile_greedy.py:176-190).
 #include <hip/hip_runtime_api.h>
+#if defined(__x86_64__)
+#include <immintrin.h>
+#endif
 
 #include <cmath>
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <algorithm>
 #include <atomic>
@@ -96,6 +100,27 @@ static inline double pcc_hoisted(double n, double mean_x, double am2, double sy,
     if (denom == 0.0) { *degenerate = true; return sab == 0.0 ? 1.0 : 0.0; } // the one place Σ|d| decides (slim records do not carry it)
     return (sxy - n * mean_x * mean_y) / denom;
 }
+
+#if defined(__x86_64__)
+// pcc_hoisted for eight candidates at once (AVX-512: correctly rounded division and square root per lane, the same
+// operations in the same order as the scalar form — the bits of every lane are the scalar result's).  Returns the mask of
+// lanes with value >= thr; *special gets the lanes whose denominator is zero (the scalar path decides those: Σ|d|).
+__attribute__((target("avx512f"))) static inline unsigned pcc_good8(__m512d cy, __m512d cy2, __m512d cxy, double n, double mean_x, double am2, double thr,
+                                                                     unsigned *special)
+{
+    const __m512d zero = _mm512_setzero_pd(), N = _mm512_set1_pd(n);
+    const __m512d mean_y = _mm512_div_pd(cy, N);
+    __m512d bm2 = _mm512_sub_pd(cy2, _mm512_mul_pd(_mm512_mul_pd(N, mean_y), mean_y));
+    bm2 = _mm512_mask_blend_pd(_mm512_cmp_pd_mask(bm2, zero, _CMP_LT_OQ), bm2, zero);
+    const __m512d denom = _mm512_sqrt_pd(_mm512_mul_pd(_mm512_set1_pd(am2), bm2));
+    *special = _mm512_cmp_pd_mask(denom, zero, _CMP_EQ_OQ);
+    const __m512d num = _mm512_sub_pd(cxy, _mm512_mul_pd(_mm512_mul_pd(N, _mm512_set1_pd(mean_x)), mean_y));
+    return _mm512_cmp_pd_mask(_mm512_div_pd(num, denom), _mm512_set1_pd(thr), _CMP_GE_OQ);
+}
+static const bool g_avx512 = __builtin_cpu_supports("avx512f") && !std::getenv("MTQ_SCAN_SCALAR");
+#else
+static const bool g_avx512 = false;
+#endif
 
 } // namespace mtq
 
@@ -195,11 +220,163 @@ extern "C" int mtq_greedy_create(mtq_greedy **out, const double *stats, int64_t 
     return MTQ_OK;
 }
 
+// One visit of the pcc scan (mixed_tile_greedy.py:237-278), the scalar form: also the fallback of the eight-wide pass below.
+static inline void pcc_visit(mtq_greedy *g, int fmt, int slot, int64_t t)
+{
+    const double thr = g->thr, N = g->n;
+    const int prev = g->assign[(size_t)t];
+    const double *rt = g->stats + t * g->rec;
+    if (prev == fmt) { // :237-241 — current_value is a pure function of the running sums: reuse it until a move is accepted
+        if (!g->cur_valid) {
+            g->cur_value = pcc_hoisted(N, g->mean_x, g->am2, g->sum_y, g->sum_y2, g->sum_xy, g->sum_abs, &g->degenerate);
+            g->cur_valid = true;
+        }
+        if (!is_good(g->cur_value, MTQ_METRIC_PCC, thr)) g->fixed[(size_t)t] = 1;
+        return;
+    }
+    const Sums5 cur = load5w(rt, g->slot4[prev], g->w), q = load5w(rt, slot, g->w); // the tile's CURRENT format and the candidate
+    const double cy = g->sum_y + (q.y - cur.y);     // :259
+    const double cy2 = g->sum_y2 + (q.y2 - cur.y2); // :260
+    const double cxy = g->sum_xy + (q.xy - cur.xy); // :261
+    const double cab = g->sum_abs + (q.ab - cur.ab); // :262
+    if (is_good(pcc_hoisted(N, g->mean_x, g->am2, cy, cy2, cxy, cab, &g->degenerate), MTQ_METRIC_PCC, thr)) { // :264-276
+        g->sum_y = cy; g->sum_y2 = cy2; g->sum_xy = cxy; g->sum_abs = cab; g->cur_valid = false;
+        g->counts[prev]--;
+        g->counts[fmt]++;
+        g->assign[(size_t)t] = (int8_t)fmt;
+    } else {
+        g->fixed[(size_t)t] = 1; // :277-278
+    }
+}
+
+#if defined(__x86_64__)
+// The pcc pass, eight candidates per step.  Two divisions and a square root per visit keep the divider busy for ~15 cycles
+// and make up most of a scalar visit; eight lanes share them here.  The visits stay sequential in effect by speculating on
+// the outcome of the batch and keeping only the prefix the speculation was right for:
+//   accept mode — lane i assumes lanes < i were accepted: its sums are the running sums plus the deltas of lanes 0..i, added
+//                 one after the other exactly as the sequential scan adds them; everything up to the first rejected lane
+//                 (that lane's rejection included) is what the sequential scan does;
+//   reject mode — every lane assumes the running sums are unchanged; everything up to the first accepted lane (included) is
+//                 what the sequential scan does.
+// The mode follows the last outcome (long runs of either kind are the rule: the scan accepts until the metric reaches the
+// threshold and mostly rejects afterwards).  Batches with an out-of-range id, a tile already in this format or a zero
+// denominator, and the tail of the order, go through pcc_visit one by one.
+template <bool kSlim>
+__attribute__((target("avx512f"))) static int greedy_pass_pcc8(mtq_greedy *g, int fmt, int slot, const int64_t *order, int64_t n)
+{
+    const double thr = g->thr, N = g->n;
+    const int w = g->w, rec = g->rec;
+    // where Σy, Σy², Σxy of every format sit in a slim record (the identity bf16 reads Σx, Σx², Σx²): branch-free deltas
+    int oy[MTQ_NUM_TILE_FORMATS], oy2[MTQ_NUM_TILE_FORMATS], oxy[MTQ_NUM_TILE_FORMATS];
+    for (int f = 0; f < MTQ_NUM_TILE_FORMATS; ++f) {
+        const int ps = g->slot4[f];
+        oy[f] = ps >= 0 ? 2 + w * ps : 0;
+        oy2[f] = ps >= 0 ? 3 + w * ps : 1;
+        oxy[f] = ps >= 0 ? 4 + w * ps : 1;
+    }
+    const int so = oy[fmt];
+    bool accept_mode = true;
+    alignas(64) double cy[8], cy2[8], cxy[8], cab[8];
+    int64_t moved[MTQ_NUM_TILE_FORMATS] = {0, 0, 0, 0};   // accepted moves by previous format (counts are adjusted once, at the end)
+    int64_t k = 0;
+    int rc = MTQ_OK;
+    while (k < n) {
+        int64_t tt[8];
+        int prev[8];
+        bool plain = n - k >= 8;
+        for (int i = 0; plain && i < 8; ++i) {
+            const int64_t t = order[k + i];
+            if ((uint64_t)t >= (uint64_t)g->T) { plain = false; break; }
+            const int p = g->assign[(size_t)t];
+            if (p == fmt) { plain = false; break; }
+            tt[i] = t;
+            prev[i] = p;
+        }
+        if (k + 24 <= n) { // the records of the batch after next (random visiting order, 2 cache lines each)
+            for (int i = 16; i < 24; ++i) {
+                const int64_t ta = order[k + i];
+                if ((uint64_t)ta >= (uint64_t)g->T) continue;
+                const double *ra = g->stats + ta * rec;
+                __builtin_prefetch(ra + so);
+                __builtin_prefetch(ra + oy[g->assign[(size_t)ta]]);
+                if (!kSlim) __builtin_prefetch(ra + so + 4);
+            }
+        }
+        if (!plain) {
+            const int64_t t = order[k];
+            if ((uint64_t)t >= (uint64_t)g->T) { rc = fail(MTQ_ERR_INVALID, "order contains a tile id out of range"); break; }
+            pcc_visit(g, fmt, slot, t);
+            ++k;
+            continue;
+        }
+        // deltas of the eight candidates, kept in registers (a 64-byte load of eight fresh scalar stores would not be forwarded)
+        double dy[8], dy2[8], dxy[8], dab[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const double *rt = g->stats + tt[i] * rec;
+            if (kSlim) {
+                const int p = prev[i];
+                dy[i] = rt[so] - rt[oy[p]]; dy2[i] = rt[so + 1] - rt[oy2[p]]; dxy[i] = rt[oxy[fmt]] - rt[oxy[p]];
+            } else {
+                const Sums5 cur = load5w(rt, g->slot4[prev[i]], w), q = load5w(rt, slot, w);
+                dy[i] = q.y - cur.y; dy2[i] = q.y2 - cur.y2; dxy[i] = q.xy - cur.xy; dab[i] = q.ab - cur.ab;
+            }
+        }
+        __m512d vy, vy2, vxy;
+        if (accept_mode) { // lane i: the running sums after lanes 0..i, added one after the other as the sequential scan adds them
+            double a[8], b[8], c[8], sab = g->sum_abs;
+            a[0] = g->sum_y + dy[0]; b[0] = g->sum_y2 + dy2[0]; c[0] = g->sum_xy + dxy[0];
+#pragma unroll
+            for (int i = 1; i < 8; ++i) { a[i] = a[i - 1] + dy[i]; b[i] = b[i - 1] + dy2[i]; c[i] = c[i - 1] + dxy[i]; }
+            vy = _mm512_set_pd(a[7], a[6], a[5], a[4], a[3], a[2], a[1], a[0]);
+            vy2 = _mm512_set_pd(b[7], b[6], b[5], b[4], b[3], b[2], b[1], b[0]);
+            vxy = _mm512_set_pd(c[7], c[6], c[5], c[4], c[3], c[2], c[1], c[0]);
+            if (!kSlim) for (int i = 0; i < 8; ++i) { sab = sab + dab[i]; cab[i] = sab; }
+        } else {           // lane i: the running sums plus its own delta
+            vy = _mm512_add_pd(_mm512_set1_pd(g->sum_y), _mm512_set_pd(dy[7], dy[6], dy[5], dy[4], dy[3], dy[2], dy[1], dy[0]));
+            vy2 = _mm512_add_pd(_mm512_set1_pd(g->sum_y2), _mm512_set_pd(dy2[7], dy2[6], dy2[5], dy2[4], dy2[3], dy2[2], dy2[1], dy2[0]));
+            vxy = _mm512_add_pd(_mm512_set1_pd(g->sum_xy), _mm512_set_pd(dxy[7], dxy[6], dxy[5], dxy[4], dxy[3], dxy[2], dxy[1], dxy[0]));
+            if (!kSlim) for (int i = 0; i < 8; ++i) cab[i] = g->sum_abs + dab[i];
+        }
+        _mm512_store_pd(cy, vy); _mm512_store_pd(cy2, vy2); _mm512_store_pd(cxy, vxy);   // for the lane that ends up as the running sums
+        unsigned special = 0;
+        const unsigned ok = pcc_good8(vy, vy2, vxy, N, g->mean_x, g->am2, thr, &special) & 0xFFu;
+        if (special) { // a zero denominator in the batch: Σ|d| decides (and slim records flag the tensor) — one by one
+            for (int i = 0; i < 8; ++i) pcc_visit(g, fmt, slot, tt[i]);
+            k += 8;
+            continue;
+        }
+        auto take = [&](int i) { // lane i's candidate is accepted last: its sums become the running sums
+            g->sum_y = cy[i]; g->sum_y2 = cy2[i]; g->sum_xy = cxy[i]; g->cur_valid = false;
+            if (!kSlim) g->sum_abs = cab[i];
+        };
+        auto move = [&](int i) { moved[prev[i]]++; g->assign[(size_t)tt[i]] = (int8_t)fmt; };
+        if (accept_mode) {
+            const int j = __builtin_ctz((~ok & 0xFFu) | 0x100u);   // first rejected lane, 8 when none
+            for (int i = 0; i < j; ++i) move(i);
+            if (j > 0) take(j - 1);
+            if (j < 8) { g->fixed[(size_t)tt[j]] = 1; k += j + 1; if (j == 0) accept_mode = false; }
+            else k += 8;
+        } else {
+            const int j = __builtin_ctz(ok | 0x100u);              // first accepted lane, 8 when none
+            for (int i = 0; i < j; ++i) g->fixed[(size_t)tt[i]] = 1;
+            if (j < 8) { move(j); take(j); k += j + 1; if (j == 0) accept_mode = true; }
+            else k += 8;
+        }
+    }
+    for (int f = 0; f < MTQ_NUM_TILE_FORMATS; ++f) { g->counts[f] -= moved[f]; g->counts[fmt] += moved[f]; }
+    return rc;
+}
+#endif
+
 extern "C" int mtq_greedy_pass(mtq_greedy *g, int fmt, const int64_t *order, int64_t n)
 {
     if (!g || (!order && n > 0)) return fail(MTQ_ERR_INVALID, "null argument");
     const int slot = slot_of(g->mask, fmt);
     if (!slot_ok(slot)) return fail(MTQ_ERR_INVALID, "format is not in the handle's fmt_mask");
+#if defined(__x86_64__)
+    if (g->metric == MTQ_METRIC_PCC && g_avx512 && g->n != 0.0) return g->w == 3 ? greedy_pass_pcc8<true>(g, fmt, slot, order, n) : greedy_pass_pcc8<false>(g, fmt, slot, order, n);
+#endif
     const double thr = g->thr, N = g->n;
     constexpr int64_t kAhead = 12; // the visiting order is random and a record is 2–3 cache lines: fetch ahead of the dependent arithmetic
     for (int64_t k = 0; k < n; ++k) {
@@ -220,21 +397,8 @@ extern "C" int mtq_greedy_pass(mtq_greedy *g, int fmt, const int64_t *order, int
         const double *rt = g->stats + t * g->rec;
         bool accept;
         if (g->metric == MTQ_METRIC_PCC) {
-            if (prev == fmt) { // :237-241 — current_value is a pure function of the running sums: reuse it until a move is accepted
-                if (!g->cur_valid) {
-                    g->cur_value = pcc_hoisted(N, g->mean_x, g->am2, g->sum_y, g->sum_y2, g->sum_xy, g->sum_abs, &g->degenerate);
-                    g->cur_valid = true;
-                }
-                if (!is_good(g->cur_value, MTQ_METRIC_PCC, thr)) g->fixed[(size_t)t] = 1;
-                continue;
-            }
-            const Sums5 cur = load5w(rt, g->slot4[prev], g->w), q = load5w(rt, slot, g->w); // the tile's CURRENT format and the candidate
-            const double cy = g->sum_y + (q.y - cur.y);     // :259
-            const double cy2 = g->sum_y2 + (q.y2 - cur.y2); // :260
-            const double cxy = g->sum_xy + (q.xy - cur.xy); // :261
-            const double cab = g->sum_abs + (q.ab - cur.ab); // :262
-            accept = is_good(pcc_hoisted(N, g->mean_x, g->am2, cy, cy2, cxy, cab, &g->degenerate), MTQ_METRIC_PCC, thr);
-            if (accept) { g->sum_y = cy; g->sum_y2 = cy2; g->sum_xy = cxy; g->sum_abs = cab; g->cur_valid = false; }
+            pcc_visit(g, fmt, slot, t);
+            continue;
         } else if (g->metric == MTQ_METRIC_MAE) {
             if (prev == fmt) { // :280-284
                 if (!is_good(N != 0.0 ? g->sum_abs / N : 0.0, MTQ_METRIC_MAE, thr)) g->fixed[(size_t)t] = 1;
