@@ -101,7 +101,7 @@ def main() -> None:
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--tensors", type=int, default=128, help="4096x4096 bf16 tensors per step per GPU (128 = 4 GiB, SURVEY §8(d) M1 stream)")
-    ap.add_argument("--chunk", type=int, default=16, help="tensors per K1 launch")
+    ap.add_argument("--chunk", type=int, default=32, help="tensors per K1 launch")
     ap.add_argument("--workers", type=int, default=default_workers(), help="host scan threads per rank (default: this rank's share of the cgroup CPU quota / affinity mask, at most 32)")
     ap.add_argument("--cpu-sample", type=int, default=24, help="tensors timed on the CPU port, ~0.5 s each (0 = skip)")
     args = ap.parse_args()

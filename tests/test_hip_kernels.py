@@ -514,6 +514,45 @@ def test_streamed_pipeline_matches_oracle():
         assert np.array_equal(r.assignment, a) and r.counts == counts, i
 
 
+def test_chain_records_and_initial_sums_on_the_device(monkeypatch):
+    """mtq_pack_chain_records / mtq_chain_initial_sums against NumPy on the same records (bit for bit: one subtraction per value,
+    one sequential addition chain per sum), for the identity-bf16 layout and a stored-bf16 layout, tile counts that are not a
+    multiple of 64; and the pipeline with chain records switched off gives the maps it gives with them."""
+    from quantization_analysis_amd.pipeline import GreedyPipeline
+
+    for kind, shape, bf16, mask, fm in (("heavy_bf16", (96, 224), True, 0xE | hb.MASK_BF16_IDENTITY, ALL), ("heavy_f32", (160, 96), False, 0xF, ALL),
+                                        ("normal_bf16", (64, 128), True, 0xE | hb.MASK_BF16_IDENTITY, ["bfp8", "bfp2"]),
+                                        ("heavy_f32", (2080, 32), False, 0xF, ["bfp4", "bf16", "bfp8"])):
+        xs = np.stack([gen(kind, 40 + i, shape) for i in range(3)])
+        recs = hb.tile_stats_batched(dev(xs, bf16=bf16), mask & 0xF)
+        chain, base, init = hb.pack_chain_records(recs, mask, fm)
+        st = recs.cpu().numpy()
+        slots = {f: bin(mask & ((1 << ALL.index(f)) - 1) & 0xF).count("1") for f in ALL if mask >> ALL.index(f) & 1}
+
+        def sums(f):
+            if f in slots:
+                return st[:, :, 2 + 5 * slots[f]: 5 + 5 * slots[f]]
+            return np.stack([st[:, :, 0], st[:, :, 1], st[:, :, 1]], axis=2)      # the identity bf16
+
+        want_chain = np.concatenate([sums(fm[p]) - sums(fm[p - 1]) for p in range(1, len(fm))], axis=2)
+        want_base = np.concatenate([st[:, :, :2], sums(fm[0])], axis=2)
+        want_init = np.add.accumulate(want_base, axis=1)[:, -1, :]
+        assert np.array_equal(chain.cpu().numpy().view(np.uint64), want_chain.view(np.uint64)), (kind, fm)
+        assert np.array_equal(base.cpu().numpy().view(np.uint64), want_base.view(np.uint64)), (kind, fm)
+        assert np.array_equal(init.cpu().numpy().view(np.uint64), np.ascontiguousarray(want_init).view(np.uint64)), (kind, fm)
+    xs = dev(np.stack([gen("heavy_bf16", 60 + i, (128, 256)) for i in range(5)]), bf16=True)
+    got = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("MTQ_CHAIN_RECORDS", flag)
+        pipe = GreedyPipeline(ALL, "pcc", 0.995, 123, chunk=2, workers=2)
+        try:
+            got[flag] = pipe.run(xs, seeds=[3, 4, 5, 6, 7])
+        finally:
+            pipe.close()
+    for a, b in zip(got["1"], got["0"]):
+        assert np.array_equal(a.assignment, b.assignment) and a.counts == b.counts and (a.pcc, a.mae, a.atol) == (b.pcc, b.mae, b.atol)
+
+
 def test_fast_kernel_strided_view_and_batch_stride():
     """The exact-integer kernel on a column window of a wider matrix (ld > cols) and on a batch whose tensors are
     padded apart (stride > rows*cols): same records as the oracle on the dense copies."""
