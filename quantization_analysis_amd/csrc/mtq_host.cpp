@@ -588,13 +588,18 @@ const unsigned __int128 kPcgMult = ((unsigned __int128)0x2360ED051FC65DA4ull << 
 
 inline void pcg_step(mtq_rng *r) { r->state = r->state * kPcgMult + r->inc; }
 
+inline uint64_t pcg_output(unsigned __int128 state)   // XSL-RR of a state
+{
+    const uint64_t hi = (uint64_t)(state >> 64), lo = (uint64_t)state;
+    const uint64_t x = hi ^ lo;
+    const unsigned rot = (unsigned)(state >> 122);
+    return (x >> rot) | (x << ((64u - rot) & 63u));
+}
+
 inline uint64_t pcg_next64(mtq_rng *r)
 {
     pcg_step(r);
-    const uint64_t hi = (uint64_t)(r->state >> 64), lo = (uint64_t)r->state;
-    const uint64_t x = hi ^ lo;
-    const unsigned rot = (unsigned)(r->state >> 122);
-    return (x >> rot) | (x << ((64u - rot) & 63u));
+    return pcg_output(r->state);
 }
 
 inline uint32_t pcg_next32(mtq_rng *r)

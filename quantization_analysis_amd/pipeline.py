@@ -4,7 +4,7 @@ A model's matched tensors are independent (reference wq:655 loop), so a rank str
   K1 (batched launch over a chunk of equally shaped tensors, HIP stream A)
     → stats D2H into pinned host memory (stream B, event)
     → per-tensor sequential greedy scan on host worker threads (C++ scan pool in libmtq_hip.so, GIL released)
-while the next chunk's K1 is already running; `run_steps` also overlaps consecutive batches (two record slots).  y is not materialised here (assignment maps + pcc/mae/atol
+while the next chunk's K1 is already running; `run_steps` also overlaps consecutive batches (three record slots).  y is not materialised here (assignment maps + pcc/mae/atol
 are the outputs the north star names); use compression_algorithms.* for the drop-in run() that returns y.
 """
 from __future__ import annotations
@@ -86,6 +86,8 @@ def columns_from_sums_batch(sums: np.ndarray, n: float) -> np.ndarray:
 class GreedyPipeline:
     """mixed-tile-greedy over a (count, rows, cols) device tensor of equally shaped bf16/fp32 matrices."""
 
+    SLOTS = 3   # record slots = batches in flight: one on the GPU, one queued behind it, one being scanned (see run_steps)
+
     def __init__(self, tile_formats=None, metric: str = "pcc", threshold: float = 0.999, seed: int = 123,
                  chunk: int = 8, workers: int = 8):
         import torch
@@ -111,6 +113,7 @@ class GreedyPipeline:
         self._unresolved = []  # batches whose device-side columns are in flight (oldest first)
         self._open = []        # enqueued, not yet finished (oldest first)
         self._next_slot = 0
+        self._slot_owner = {}
 
     def _layout(self, x3d):
         """→ (K1 mask, host mask, slim?) for a batch.  bf16 storage: the bf16 candidate is the identity, its record slot would be
@@ -133,7 +136,8 @@ class GreedyPipeline:
     def _buffers(self, slot: int, count: int, tiles: int, rec: int, rec_host: int, device):
         """Records of a whole batch: device buffer (full records, what K1 writes), device staging buffer of what crosses PCIe
         (the same buffer unless the records are slimmed) and its pinned host mirror (scans read the pinned memory in place).
-        Two slots alternate so that a batch can be on the GPU / the PCIe link while the previous one is still being scanned."""
+        SLOTS of them rotate so that a batch can be queued and another on the GPU / the PCIe link while an earlier one is still
+        being scanned."""
         key = (count, tiles, rec, rec_host, str(device))
         if self._bufs.get(slot, (None,))[0] != key:
             torch = self.torch
@@ -163,7 +167,7 @@ class GreedyPipeline:
         k1_mask, host_mask, slim = self._layout(x3d)
         chain = self._chain(slim)
         rec_host = 3 * (len(self.tile_formats) - 1) if chain else hb.record_doubles(host_mask)
-        for slot in (0, 1):
+        for slot in range(self.SLOTS):
             dev, stage, host, _np = self._buffers(slot, count, th * tw, hb.record_doubles(k1_mask), rec_host, x3d.device)
             dev.zero_()
             stage.zero_()
@@ -178,18 +182,20 @@ class GreedyPipeline:
 
     def enqueue(self, x3d, seeds=None) -> dict:
         """GPU half of a batch, non-blocking: per chunk K1 on the launch stream (plus the slim copy of its records) and the
-        records' D2H on the copy stream.  At most two batches may be enqueued and not yet finished (two record slots)."""
+        records' D2H on the copy stream.  At most SLOTS batches may be enqueued and not yet finished."""
         torch = self.torch
-        if len(self._open) >= 2:
-            raise RuntimeError("finish() an enqueued batch before enqueuing a third one")
+        if len(self._open) >= self.SLOTS:
+            raise RuntimeError("finish() an enqueued batch before enqueuing another one: every record slot is in use")
         count, rows, cols = x3d.shape
         th, tw = hb.tiles_hw(rows, cols)
         k1_mask, host_mask, slim = self._layout(x3d)
         tiles = th * tw
-        while len(self._unresolved) > 1:                 # the batch two back owned the record slot this one takes
-            self.resolve(self._unresolved.pop(0))
         slot = self._next_slot
-        self._next_slot ^= 1
+        self._next_slot = (slot + 1) % self.SLOTS
+        owner = self._slot_owner.get(slot)               # the batch SLOTS back: its device-side columns read the records K1 is about to overwrite
+        if owner is not None and "col_pending" in owner:
+            self.resolve(owner)
+            self._unresolved = [e for e in self._unresolved if e is not owner]
         chain = self._chain(slim)
         rec_host = 3 * (len(self.tile_formats) - 1) if chain else hb.record_doubles(host_mask)
         dev, stage, host, host_np = self._buffers(slot, count, tiles, hb.record_doubles(k1_mask), rec_host, x3d.device)
@@ -233,6 +239,7 @@ class GreedyPipeline:
                "seeds": seeds, "x": x3d, "dev": dev, "k1_mask": k1_mask, "slim": slim, "chain": chain,
                "init_np": init_np if chain else None}
         self._open.append(enq)
+        self._slot_owner[slot] = enq
         return enq
 
     def _scan_args(self, enq: dict, first: int, n: int, stats, mask):
@@ -290,9 +297,9 @@ class GreedyPipeline:
                 {"maps_host": torch.empty((count, tiles), dtype=torch.int8, pin_memory=True),
                  "maps_dev": torch.empty((count, tiles), dtype=torch.int8, device=dev.device),
                  "scratch": torch.empty((count, n_scratch), dtype=torch.float64, device=dev.device),
-                 "sums_host": torch.empty((count, 7), dtype=torch.float64, pin_memory=True)} for _ in range(2)], "next": 0}
+                 "sums_host": torch.empty((count, 7), dtype=torch.float64, pin_memory=True)} for _ in range(self.SLOTS)], "next": 0}
         cb = self._colbufs["ring"][self._colbufs["next"]]
-        self._colbufs["next"] ^= 1
+        self._colbufs["next"] = (self._colbufs["next"] + 1) % self.SLOTS
         mh = cb["maps_host"].numpy()
         for i, r in enumerate(results):
             mh[i] = r.assignment.reshape(-1)
@@ -329,19 +336,23 @@ class GreedyPipeline:
         return results
 
     def run_steps(self, batches) -> list[TensorResult]:
-        """A sequence of batches with the next batch's GPU work enqueued before the current batch's scans are collected
-        (the first chunk's latency and the last chunk's scan tail of every batch hide behind its neighbours).  Returns the
-        LAST batch's results; every batch is fully processed."""
+        """A sequence of batches, SLOTS of them in flight: a batch's GPU work is enqueued two batches before its scans are
+        collected, so the K1 stream always holds the next batch's launches while the driver thread waits for the scans of an
+        earlier one (with one batch of look-ahead the stream ran dry for ≈ 1 ms per step: the last chunk's copy and scans of
+        batch i−1 end about when K1 of batch i does).  Returns the LAST batch's results; every batch is fully processed."""
         torch = self.torch
-        results, prev = [], None
+        results, open_ = [], []
         for x3d in batches:
-            cur = self.enqueue(x3d)
-            if prev is not None:
-                results = self.finish(prev, defer_columns=True)   # columns launched; collected while the next batch is scanned
-                self._unresolved.append(prev)
-            prev = cur
-        if prev is not None:
-            results = self.finish(prev)
+            open_.append(self.enqueue(x3d))
+            if len(open_) == self.SLOTS:
+                done = open_.pop(0)
+                results = self.finish(done, defer_columns=True)   # columns launched; collected while later batches are scanned
+                self._unresolved.append(done)
+        while open_:
+            done = open_.pop(0)
+            results = self.finish(done, defer_columns=bool(open_))
+            if open_:
+                self._unresolved.append(done)
         while self._unresolved:
             self.resolve(self._unresolved.pop(0))
         torch.cuda.current_stream().wait_stream(self.stream)

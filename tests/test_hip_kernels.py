@@ -497,16 +497,17 @@ def test_streamed_pipeline_matches_oracle():
     for i, r in zip((0, 2), res):
         a, counts, _st = orc.greedy(xs[i], ALL, "mae", 3e-4, 123)
         assert np.array_equal(r.assignment, a) and r.counts == counts, i
-    # overlapped batches (two record slots): the last batch's results, each batch its own tensors
+    # overlapped batches (three record slots): the last batch's results, each batch its own tensors
     b1 = dev(np.stack([gen("normal_bf16", 70 + i, (128, 256)) for i in range(4)]), bf16=True)
     b2x = np.stack([gen("heavy_bf16", 80 + i, (128, 256)) for i in range(4)])
     pipe = GreedyPipeline(ALL, "pcc", 0.998, 123, chunk=3, workers=2)
     try:
         last = pipe.run_steps([b1, dev(b2x, bf16=True), b1, dev(b2x, bf16=True)])
         with pytest.raises(RuntimeError):
-            e1, e2 = pipe.enqueue(b1), pipe.enqueue(b1)
+            open_ = [pipe.enqueue(b1) for _ in range(pipe.SLOTS)]
             pipe.enqueue(b1)
-        pipe.finish(e1), pipe.finish(e2)
+        for e in open_:
+            pipe.finish(e)
     finally:
         pipe.close()
     for i, r in enumerate(last):
