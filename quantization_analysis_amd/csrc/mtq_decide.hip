@@ -100,17 +100,19 @@ __global__ __launch_bounds__(256) void columns_final_dev(const double *__restric
 
 // Chain records for the pcc greedy scan over distinct formats f0, f1, … (include/mtq.h): per tile the differences of
 // consecutive formats' (Σy, Σy², Σxy) — the subtraction the scan performs at every visit (mixed_tile_greedy.py:259-261) — and,
-// for the initial sums, [Σx, Σx², Σy, Σy², Σxy](f0) in a compact side array.  One thread per tile.
-struct ChainPlan { int slot[MTQ_NUM_TILE_FORMATS], n; };
+// for the initial sums the host accumulates in tile order, a compact side array: [Σx, Σx²] when f0 is the identity bf16 (its
+// Σy, Σy², Σxy are Σx, Σx², Σx²), else [Σx, Σx², Σy, Σy², Σxy](f0).  One thread per tile.
+struct ChainPlan { int slot[MTQ_NUM_TILE_FORMATS], n, base_doubles; };
 __global__ __launch_bounds__(256) void pack_chain_records_dev(const double *__restrict__ stats, int64_t tiles, int rec, ChainPlan plan,
-                                                              double *__restrict__ chain, double *__restrict__ base5)
+                                                              double *__restrict__ chain, double *__restrict__ base)
 {
     const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (t >= tiles) return;
     const double *r = stats + t * rec;
     Sums5 prev = load5(r, plan.slot[0]);
-    double *b = base5 + t * 5;
-    b[0] = r[0]; b[1] = r[1]; b[2] = prev.y; b[3] = prev.y2; b[4] = prev.xy;
+    double *b = base + t * plan.base_doubles;
+    b[0] = r[0]; b[1] = r[1];
+    if (plan.base_doubles == 5) { b[2] = prev.y; b[3] = prev.y2; b[4] = prev.xy; }
     double *c = chain + t * 3 * (plan.n - 1);
     for (int p = 1; p < plan.n; ++p) {
         const Sums5 q = load5(r, plan.slot[p]);
@@ -118,33 +120,6 @@ __global__ __launch_bounds__(256) void pack_chain_records_dev(const double *__re
         c += 3;
         prev = q;
     }
-}
-
-// The five running sums of the all-f0 assignment, accumulated in tile order as the reference accumulates them
-// (mixed_tile_greedy.py:147-174): a dependent chain of `tiles` float64 additions per sum — one wave per tensor, lane c owns
-// sum c, batches of 64 tiles staged through LDS (double-buffered) so that the chain never waits for memory.
-__global__ __launch_bounds__(64) void chain_initial_sums_dev(const double *__restrict__ base5, int64_t tiles, double *__restrict__ init5)
-{
-    __shared__ double buf[2][320];
-    const int lane = threadIdx.x;
-    base5 += (int64_t)blockIdx.x * tiles * 5;
-    const int64_t total = tiles * 5, batches = (tiles + 63) / 64;
-    double v[5];
-    auto fetch = [&](int64_t b) {
-        for (int k = 0; k < 5; ++k) { const int64_t i = b * 320 + k * 64 + lane; v[k] = i < total ? base5[i] : 0.0; }
-    };
-    fetch(0);
-    double s = 0.0;
-    for (int64_t b = 0; b < batches; ++b) {
-        double *cur = buf[b & 1];
-        for (int k = 0; k < 5; ++k) cur[k * 64 + lane] = v[k];
-        __syncthreads();
-        if (b + 1 < batches) fetch(b + 1);                      // in flight while the chain below runs
-        const int cnt = (int)(tiles - b * 64 < 64 ? tiles - b * 64 : 64);
-        if (lane < 5)
-            for (int j = 0; j < cnt; ++j) s = s + cur[j * 5 + lane];
-    }
-    if (lane < 5) init5[(int64_t)blockIdx.x * 5 + lane] = s;
 }
 
 static SlotTable slot_table(uint32_t fmt_mask)
@@ -210,32 +185,26 @@ extern "C" int mtq_column_sums_device(const double *stats, int64_t tiles, uint32
 }
 
 extern "C" int mtq_pack_chain_records(const double *stats, int64_t tiles, uint32_t fmt_mask, const int *formats, int n_formats, double *chain,
-                                      double *base5, void *stream)
+                                      double *base, int base_doubles, void *stream)
 {
-    if (!stats || !formats || !chain || !base5) return fail(MTQ_ERR_INVALID, "null argument");
+    if (!stats || !formats || !chain || !base) return fail(MTQ_ERR_INVALID, "null argument");
     if (tiles <= 0 || tiles > ((int64_t)1 << 34)) return fail(MTQ_ERR_INVALID, "tiles out of range");
     if (n_formats < 2 || n_formats > MTQ_NUM_TILE_FORMATS) return fail(MTQ_ERR_INVALID, "a chain needs 2..4 formats");
     if (fmt_mask & MTQ_MASK_SLIM) return fail(MTQ_ERR_INVALID, "chain records are packed from full records");
     ChainPlan plan;
     plan.n = n_formats;
+    plan.base_doubles = base_doubles;
     for (int p = 0; p < MTQ_NUM_TILE_FORMATS; ++p) plan.slot[p] = -1;
     for (int p = 0; p < n_formats; ++p) {
         plan.slot[p] = slot_of(fmt_mask, formats[p]);
         if (!slot_ok(plan.slot[p])) return fail(MTQ_ERR_INVALID, "a requested format is not in fmt_mask");
         for (int q = 0; q < p; ++q) if (formats[q] == formats[p]) return fail(MTQ_ERR_INVALID, "chain records need distinct formats");
     }
+    if (base_doubles != 5 && !(base_doubles == 2 && plan.slot[0] == kVirtualSlot))
+        return fail(MTQ_ERR_INVALID, "base_doubles is 5, or 2 when the first format is the identity bf16");
     if (int rc = require_device()) return rc;
     const int rec = 2 + 5 * popcount4(fmt_mask);
     hipLaunchKernelGGL(pack_chain_records_dev, dim3((unsigned)((tiles + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), stats, tiles,
-                       rec, plan, chain, base5);
+                       rec, plan, chain, base);
     return check_launch("mtq_pack_chain_records");
-}
-
-extern "C" int mtq_chain_initial_sums(const double *base5, int64_t count, int64_t tiles, double *init5, void *stream)
-{
-    if (!base5 || !init5) return fail(MTQ_ERR_INVALID, "null argument");
-    if (count <= 0 || count > 65535 || tiles <= 0 || tiles > ((int64_t)1 << 34)) return fail(MTQ_ERR_INVALID, "count / tiles out of range");
-    if (int rc = require_device()) return rc;
-    hipLaunchKernelGGL(chain_initial_sums_dev, dim3((unsigned)count), dim3(64), 0, static_cast<hipStream_t>(stream), base5, tiles, init5);
-    return check_launch("mtq_chain_initial_sums");
 }

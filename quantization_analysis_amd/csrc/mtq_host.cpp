@@ -802,12 +802,13 @@ extern "C" int mtq_greedy_run(const double *stats, int64_t tiles, uint32_t fmt_m
 // The search of one tensor on CHAIN records (include/mtq.h): pcc metric, distinct formats f0, f1, …  Every visit of pass
 // p >= 1 moves a tile from f(p−1) to f(p) — a tile that is still a candidate accepted every earlier pass, a rejected one is
 // fixed — so all the scan reads of a tile is the difference of the two formats' sums, formed on the device by the subtraction
-// the record-based scan performs (:259-261), and the running sums start from the all-f0 sums in tile order (:147-174), also
-// accumulated on the device.  Same operations in the same order as mtq_greedy_run: same maps, same counts.
-extern "C" int mtq_greedy_run_chain(const double *chain, const double *init5, int64_t tiles, const int *formats, int n_formats,
+// the record-based scan performs (:259-261); the running sums start from the all-f0 sums, accumulated here in tile order
+// (:147-174) from a compact side array.  Same operations in the same order as mtq_greedy_run: same maps, same counts.
+extern "C" int mtq_greedy_run_chain(const double *chain, const double *base, int base_doubles, int64_t tiles, const int *formats, int n_formats,
                                     double threshold, double elem_count, uint64_t seed, int8_t *map, int64_t counts[4])
 {
-    if (!chain || !init5 || !formats || !map) return fail(MTQ_ERR_INVALID, "null argument");
+    if (!chain || !base || !formats || !map) return fail(MTQ_ERR_INVALID, "null argument");
+    if (base_doubles != 2 && base_doubles != 5) return fail(MTQ_ERR_INVALID, "base_doubles is 2 (identity bf16 first) or 5");
     if (tiles <= 0) return fail(MTQ_ERR_INVALID, "tiles must be positive");
     if (n_formats < 2 || n_formats > MTQ_NUM_TILE_FORMATS) return fail(MTQ_ERR_INVALID, "a chain needs 2..4 formats");
     if (seed == 0) return fail(MTQ_ERR_INVALID, "seed 0 means 'draw a random seed' in the reference; resolve it before calling");
@@ -818,6 +819,16 @@ extern "C" int mtq_greedy_run_chain(const double *chain, const double *init5, in
     mtq_greedy g;
     g.T = tiles; g.mask = 0; g.rec = 3 * (n_formats - 1); g.metric = MTQ_METRIC_PCC; g.thr = threshold; g.n = elem_count;
     g.stats = chain; g.w = 3; g.degenerate = false;
+    // running globals of the all-f0 assignment, accumulated in tile order (:147-174); for the identity bf16 Σy, Σy², Σxy are the
+    // same additions of the same values as Σx, Σx², Σx²
+    double init5[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+    for (int64_t t = 0; t < tiles; ++t) {
+        const double *b = base + t * base_doubles;
+        init5[0] += b[0];
+        init5[1] += b[1];
+        if (base_doubles == 5) { init5[2] += b[2]; init5[3] += b[3]; init5[4] += b[4]; }
+    }
+    if (base_doubles == 2) { init5[2] = init5[0]; init5[3] = init5[1]; init5[4] = init5[1]; }
     g.sum_x = init5[0]; g.sum_x2 = init5[1]; g.sum_y = init5[2]; g.sum_y2 = init5[3]; g.sum_xy = init5[4]; g.sum_abs = 0.0;
     g.cur_valid = false; g.cur_value = 0.0; g.max_abs = 0.0; g.max_count = 0;
     g.mean_x = elem_count != 0.0 ? g.sum_x / elem_count : 0.0;
@@ -963,17 +974,18 @@ extern "C" int mtq_greedy_run_batch(const double *stats, int64_t count, int64_t 
     });
 }
 
-// mtq_greedy_run_chain over `count` tensors: chain [count][tiles][3(F−1)], init5 [count][5].
-extern "C" int mtq_greedy_run_chain_batch(const double *chain, const double *init5, int64_t count, int64_t tiles, const int *formats,
-                                          int n_formats, double threshold, double elem_count, const uint64_t *seeds, int8_t *maps,
-                                          int64_t *counts, int n_threads)
+// mtq_greedy_run_chain over `count` tensors: chain [count][tiles][3(F−1)], base [count][tiles][base_doubles].
+extern "C" int mtq_greedy_run_chain_batch(const double *chain, const double *base, int base_doubles, int64_t count, int64_t tiles,
+                                          const int *formats, int n_formats, double threshold, double elem_count, const uint64_t *seeds,
+                                          int8_t *maps, int64_t *counts, int n_threads)
 {
-    if (!chain || !init5 || !formats || !seeds || !maps) return fail(MTQ_ERR_INVALID, "null argument");
+    if (!chain || !base || !formats || !seeds || !maps) return fail(MTQ_ERR_INVALID, "null argument");
     if (count <= 0 || tiles <= 0) return fail(MTQ_ERR_INVALID, "count and tiles must be positive");
     if (n_formats < 2 || n_formats > MTQ_NUM_TILE_FORMATS) return fail(MTQ_ERR_INVALID, "a chain needs 2..4 formats");
+    if (base_doubles != 2 && base_doubles != 5) return fail(MTQ_ERR_INVALID, "base_doubles is 2 (identity bf16 first) or 5");
     const int rec = 3 * (n_formats - 1);
     return run_batch(count, n_threads, "mtq_greedy_run_chain_batch failed", [=](int64_t i) {
-        return mtq_greedy_run_chain(chain + i * tiles * rec, init5 + 5 * i, tiles, formats, n_formats, threshold, elem_count, seeds[i],
-                                    maps + i * tiles, counts ? counts + 4 * i : nullptr);
+        return mtq_greedy_run_chain(chain + i * tiles * rec, base + i * tiles * base_doubles, base_doubles, tiles, formats, n_formats, threshold,
+                                    elem_count, seeds[i], maps + i * tiles, counts ? counts + 4 * i : nullptr);
     });
 }

@@ -59,9 +59,9 @@ def _scan_chunk(first, stats, mask, tiles_hw, numel, tile_formats, metric, thres
     return res
 
 
-def _scan_chunk_chain(first, chain, init5, tiles_hw, numel, tile_formats, threshold, seeds, n_threads) -> list[TensorResult]:
+def _scan_chunk_chain(first, chain, base, tiles_hw, numel, tile_formats, threshold, seeds, n_threads) -> list[TensorResult]:
     """_scan_chunk on chain records (pcc, distinct formats): maps and counts; pcc / mae / atol are filled in from the device."""
-    maps, counts = hb.greedy_run_chain_batch(chain, init5, tile_formats, threshold, float(numel), seeds, n_threads)
+    maps, counts = hb.greedy_run_chain_batch(chain, base, tile_formats, threshold, float(numel), seeds, n_threads)
     nan = float("nan")
     res = []
     for j in range(maps.shape[0]):
@@ -105,7 +105,6 @@ class GreedyPipeline:
         self.stream = torch.cuda.Stream()        # K1 launches
         self.copy_stream = torch.cuda.Stream()   # records D2H, overlapped with the next chunk's K1
         self.col_stream = torch.cuda.Stream()    # maps up / column sums / sums down of a finished batch (must not queue behind the next batch's copies)
-        self.init_stream = torch.cuda.Stream()   # chain records: the sequential initial sums of a chunk (16 waves) beside the next chunk's K1
         self.timing = KernelTiming()
         self._bufs = {}
         self._chainbufs = {}
@@ -128,8 +127,10 @@ class GreedyPipeline:
         return k1_mask, host_mask | (hb.MASK_SLIM if slim else 0), slim
 
     def _chain(self, slim: bool) -> bool:
-        """Chain records (differences of consecutive formats' sums, 3 doubles per step of the format chain: 72 instead of 88
-        B/tile for four formats) serve the pcc search over distinct formats; they are packed from K1's records on the device."""
+        """Chain records (differences of consecutive formats' sums, 3 doubles per step of the format chain, plus Σx, Σx² — or the
+        first format's five sums — in a side array) serve the pcc search over distinct formats: the same bytes over PCIe, one
+        24-byte read per visit instead of two record slots and a short sequential pass for the initial sums.  Measured
+        equal or slower than the slim records on the GPU boxes, hence opt-in: MTQ_CHAIN_RECORDS=1."""
         f = self.tile_formats
         return slim and len(f) >= 2 and len(set(f)) == len(f) and os.environ.get("MTQ_CHAIN_RECORDS", "0") == "1"
 
@@ -147,15 +148,13 @@ class GreedyPipeline:
             self._bufs[slot] = (key, dev, stage, host, host.numpy())
         return self._bufs[slot][1:]
 
-    def _chain_buffers(self, slot: int, count: int, tiles: int, device):
-        """Side buffers of the chain path: [Σx, Σx², Σy, Σy², Σxy](f0) per tile (device only) and the per-tensor initial sums
-        (device + pinned host)."""
-        key = (count, tiles, str(device))
+    def _chain_buffers(self, slot: int, count: int, tiles: int, bd: int, device):
+        """The chain path's side array ([Σx, Σx²] or the first format's five sums per tile): device + pinned host."""
+        key = (count, tiles, bd, str(device))
         if self._chainbufs.get(slot, (None,))[0] != key:
             torch = self.torch
-            init_host = torch.empty((count, 5), dtype=torch.float64, pin_memory=True)
-            self._chainbufs[slot] = (key, torch.empty((count, tiles, 5), dtype=torch.float64, device=device),
-                                     torch.empty((count, 5), dtype=torch.float64, device=device), init_host, init_host.numpy())
+            host = torch.empty((count, tiles, bd), dtype=torch.float64, pin_memory=True)
+            self._chainbufs[slot] = (key, torch.empty((count, tiles, bd), dtype=torch.float64, device=device), host, host.numpy())
         return self._chainbufs[slot][1:]
 
     def reserve(self, x3d) -> None:
@@ -173,9 +172,9 @@ class GreedyPipeline:
             stage.zero_()
             host.copy_(stage, non_blocking=True)   # first DMA into the pinned pages (mappings are set up lazily)
             if chain:
-                _base, init_dev, init_host, _inp = self._chain_buffers(slot, count, th * tw, x3d.device)
-                init_dev.zero_()
-                init_host.copy_(init_dev, non_blocking=True)
+                base_dev, base_host, _bnp = self._chain_buffers(slot, count, th * tw, hb.chain_base_doubles(host_mask, self.tile_formats), x3d.device)
+                base_dev.zero_()
+                base_host.copy_(base_dev, non_blocking=True)
         torch.cuda.synchronize()
         hb.greedy_run_batch(np.zeros((self.workers, 1, hb.record_doubles(0xF))), 0xF, ["bf16"], self.metric, self.threshold, 1024.0,
                             [1] * self.workers, self.workers)
@@ -200,7 +199,7 @@ class GreedyPipeline:
         rec_host = 3 * (len(self.tile_formats) - 1) if chain else hb.record_doubles(host_mask)
         dev, stage, host, host_np = self._buffers(slot, count, tiles, hb.record_doubles(k1_mask), rec_host, x3d.device)
         if chain:
-            base5, init_dev, init_host, init_np = self._chain_buffers(slot, count, tiles, x3d.device)
+            base_dev, base_host, base_np = self._chain_buffers(slot, count, tiles, hb.chain_base_doubles(host_mask, self.tile_formats), x3d.device)
         dec_mask = host_mask & ~hb.MASK_SLIM             # what the full records on the device hold (identity bf16 included)
         pending = []  # (event, first_index, n)
         self.stream.wait_stream(torch.cuda.current_stream())
@@ -213,17 +212,13 @@ class GreedyPipeline:
                 hb.tile_stats_batched(x3d[first:first + n], k1_mask, out=dev[first:first + n])
                 e1.record(self.stream)
                 self.timing.events.append((e0, e1, n * tiles))
-                ready, sums_ready = e1, None
+                ready = e1
                 # Packing stays on the K1 stream: K1 is a persistent grid over every CU, so a kernel on another stream only gets
                 # waves once K1 drains — packing there delayed each chunk's copy by a whole K1 launch (measured: 450–517 M tiles/s
                 # against 582–603 M).
-                if chain:   # differences of consecutive formats here; the sequential initial sums on their own stream
+                if chain:
                     hb.pack_chain_records(dev[first:first + n], dec_mask, self.tile_formats, chain_out=stage[first:first + n],
-                                          base_out=base5[first:first + n], init_out=init_dev[first:first + n], init_stream=self.init_stream)
-                    with torch.cuda.stream(self.init_stream):   # 40 B per tensor: the copy stream must not wait for them
-                        init_host[first:first + n].copy_(init_dev[first:first + n], non_blocking=True)
-                        sums_ready = torch.cuda.Event(blocking=True)
-                        sums_ready.record(self.init_stream)
+                                          base_out=base_dev[first:first + n])
                 elif slim:
                     hb.pack_slim_records(dev[first:first + n], k1_mask, out=stage[first:first + n])
                 if chain or slim:
@@ -232,12 +227,14 @@ class GreedyPipeline:
                 self.copy_stream.wait_event(ready)
                 with torch.cuda.stream(self.copy_stream):
                     host[first:first + n].copy_(stage[first:first + n], non_blocking=True)
+                    if chain:
+                        base_host[first:first + n].copy_(base_dev[first:first + n], non_blocking=True)
                     done = torch.cuda.Event(blocking=True)   # the driver thread sleeps while it waits: spinning would burn a core of the scan budget
                     done.record(self.copy_stream)
-                pending.append((done, first, n, sums_ready))
+                pending.append((done, first, n))
         enq = {"pending": pending, "host_np": host_np, "host_mask": host_mask, "tiles_hw": (th, tw), "numel": rows * cols,
                "seeds": seeds, "x": x3d, "dev": dev, "k1_mask": k1_mask, "slim": slim, "chain": chain,
-               "init_np": init_np if chain else None}
+               "base_np": base_np if chain else None}
         self._open.append(enq)
         self._slot_owner[slot] = enq
         return enq
@@ -256,13 +253,11 @@ class GreedyPipeline:
         if not self._open or self._open[0] is not enq:
             raise RuntimeError("batches finish in the order they were enqueued")
         futures = []
-        for evt, first, n, sums_ready in enq["pending"]:
+        for evt, first, n in enq["pending"]:
             evt.synchronize()
-            if sums_ready is not None:
-                sums_ready.synchronize()
             if enq["chain"]:
                 a = self._scan_args(enq, first, n, None, 0)
-                futures.append((first, n, self.pool.submit(_scan_chunk_chain, first, enq["host_np"][first:first + n], enq["init_np"][first:first + n],
+                futures.append((first, n, self.pool.submit(_scan_chunk_chain, first, enq["host_np"][first:first + n], enq["base_np"][first:first + n],
                                                            a[3], a[4], self.tile_formats, self.threshold, a[8], self.workers)))
             else:
                 futures.append((first, n, self.pool.submit(_scan_chunk, *self._scan_args(enq, first, n, enq["host_np"][first:first + n], enq["host_mask"]))))

@@ -8,7 +8,7 @@ hb.require_gpu()
 x = bench.make_batch(16, 0, torch.device('cuda', 0))
 recs = hb.tile_stats_batched(x, 0xE)
 mask = 0xE | hb.MASK_BF16_IDENTITY
-chain, base, init = hb.pack_chain_records(recs, mask, bench.FORMATS)
+chain, base = hb.pack_chain_records(recs, mask, bench.FORMATS)
 torch.cuda.synchronize()
 import ctypes
 fm = (ctypes.c_int * 4)(0, 1, 2, 3)
@@ -19,6 +19,5 @@ def timed(fn, reps=10):
         e0.record(); fn(); e1.record(); e1.synchronize(); ts.append(e0.elapsed_time(e1))
     return sorted(ts)[len(ts) // 2]
 T = recs.shape[1]
-print("pack_chain_records (16 tensors): %.3f ms" % timed(lambda: hb.check(hb.lib().mtq_pack_chain_records(recs.data_ptr(), 16 * T, mask, fm, 4, chain.data_ptr(), base.data_ptr(), hb._stream_ptr()))))
-print("chain_initial_sums (16 tensors): %.3f ms" % timed(lambda: hb.check(hb.lib().mtq_chain_initial_sums(base.data_ptr(), 16, T, init.data_ptr(), hb._stream_ptr()))))
+print("pack_chain_records (16 tensors): %.3f ms" % timed(lambda: hb.check(hb.lib().mtq_pack_chain_records(recs.data_ptr(), 16 * T, mask, fm, 4, chain.data_ptr(), base.data_ptr(), 2, hb._stream_ptr()))))
 print("pack_slim_records (16 tensors): %.3f ms" % timed(lambda: hb.pack_slim_records(recs, 0xE)))
