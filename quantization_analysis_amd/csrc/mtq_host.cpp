@@ -276,8 +276,8 @@ static inline void pcc_visit(mtq_greedy *g, int fmt, int slot, int64_t t)
 // threshold and mostly rejects afterwards).  Batches with an out-of-range id, a tile already in this format or a zero
 // denominator, and the tail of the order, go through pcc_visit one by one.
 enum { kScanFull = 0, kScanSlim = 1, kScanChain = 2 };
-template <int kMode>
-__attribute__((target("avx512f"))) static int greedy_pass_pcc8(mtq_greedy *g, int fmt, int slot, const int64_t *order, int64_t n)
+template <int kMode, typename Idx>
+__attribute__((target("avx512f"))) static int greedy_pass_pcc8(mtq_greedy *g, int fmt, int slot, const Idx *order, int64_t n)
 {
     constexpr bool kSlim = kMode != kScanFull, kChain = kMode == kScanChain;   // chain records carry no Σ|d| either
     const double thr = g->thr, N = g->n;
@@ -387,14 +387,17 @@ __attribute__((target("avx512f"))) static int greedy_pass_pcc8(mtq_greedy *g, in
 }
 #endif
 
-extern "C" int mtq_greedy_pass(mtq_greedy *g, int fmt, const int64_t *order, int64_t n)
+// mtq_greedy_pass for a visiting order of 64-bit ids (the C ABI) or 32-bit ids (mtq_greedy_run: half the footprint of the
+// shuffled array)
+template <typename Idx>
+static int greedy_pass_any(mtq_greedy *g, int fmt, const Idx *order, int64_t n)
 {
     if (!g || (!order && n > 0)) return fail(MTQ_ERR_INVALID, "null argument");
     const int slot = slot_of(g->mask, fmt);
     if (!slot_ok(slot)) return fail(MTQ_ERR_INVALID, "format is not in the handle's fmt_mask");
 #if defined(__x86_64__)
-    if (g->metric == MTQ_METRIC_PCC && g_avx512 && g->n != 0.0) return g->chain_off >= 0 ? greedy_pass_pcc8<kScanChain>(g, fmt, slot, order, n)
-               : g->w == 3 ? greedy_pass_pcc8<kScanSlim>(g, fmt, slot, order, n) : greedy_pass_pcc8<kScanFull>(g, fmt, slot, order, n);
+    if (g->metric == MTQ_METRIC_PCC && g_avx512 && g->n != 0.0) return g->chain_off >= 0 ? greedy_pass_pcc8<kScanChain, Idx>(g, fmt, slot, order, n)
+               : g->w == 3 ? greedy_pass_pcc8<kScanSlim, Idx>(g, fmt, slot, order, n) : greedy_pass_pcc8<kScanFull, Idx>(g, fmt, slot, order, n);
 #endif
     const double thr = g->thr, N = g->n;
     constexpr int64_t kAhead = 12; // the visiting order is random and a record is 2–3 cache lines: fetch ahead of the dependent arithmetic
@@ -464,6 +467,8 @@ extern "C" int mtq_greedy_pass(mtq_greedy *g, int fmt, const int64_t *order, int
     }
     return MTQ_OK;
 }
+
+extern "C" int mtq_greedy_pass(mtq_greedy *g, int fmt, const int64_t *order, int64_t n) { return greedy_pass_any<int64_t>(g, fmt, order, n); }
 
 extern "C" int mtq_greedy_assignment(const mtq_greedy *g, int8_t *assign)
 {
@@ -646,8 +651,8 @@ void rng_seed(mtq_rng *r, uint64_t seed)
 // draw by draw (an unpredictable rejection branch per element), so the draws of a block are generated first and then
 // consumed without branches: a rejected draw swaps an element with itself and leaves i where it is.  Draws generated
 // beyond the last one consumed are handed back by replaying the generator from the block's start.
-template <bool kSwap>
-void rng_shuffle_impl(mtq_rng *r, int64_t n, int64_t *arr)
+template <bool kSwap, typename Idx>
+void rng_shuffle_impl(mtq_rng *r, int64_t n, Idx *arr)
 {
     if (n < 2) return;
     int64_t i = n - 1;
@@ -658,7 +663,7 @@ void rng_shuffle_impl(mtq_rng *r, int64_t n, int64_t *arr)
             uint64_t v;
             if ((uint64_t)i <= 0xFFFFFFFFull) { while ((v = (pcg_next32(r) & mask)) > (uint64_t)i) {} }
             else { while ((v = (pcg_next64(r) & mask)) > (uint64_t)i) {} }
-            if (kSwap) { const int64_t t = arr[i]; arr[i] = arr[(int64_t)v]; arr[(int64_t)v] = t; }
+            if (kSwap) { const Idx t = arr[i]; arr[i] = arr[(int64_t)v]; arr[(int64_t)v] = t; }
         }
         return;
     }
@@ -673,15 +678,20 @@ void rng_shuffle_impl(mtq_rng *r, int64_t n, int64_t *arr)
         for (int k = 0; k < kBlock; ++k) { const uint64_t o = pcg_next64(r); buf[cnt++] = (uint32_t)o; buf[cnt++] = (uint32_t)(o >> 32); }
         int p = 0;
         while (p < cnt && ii >= 1u) {
-            const uint32_t v = buf[p++] & m32;
-            const bool ok = v <= ii;
-            if (kSwap) {
-                const uint32_t j = ok ? v : ii;       // rejected: swap with itself
-                const int64_t a = arr[ii], b = arr[j];
-                arr[ii] = b; arr[j] = a;
+            // the mask (smallest 2^k − 1 >= ii) only changes when ii crosses a power of two: inside a level the loop-carried
+            // chain is the compare and the conditional decrement alone
+            while ((m32 >> 1) >= ii) m32 >>= 1;
+            const uint32_t lo = m32 >> 1;                 // ii in (lo, m32] keeps this mask; lo == 0 at the last level (ii == 1)
+            while (p < cnt && ii > lo) {
+                const uint32_t v = buf[p++] & m32;
+                const bool ok = v <= ii;
+                if (kSwap) {
+                    const uint32_t j = ok ? v : ii;   // rejected: swap with itself
+                    const Idx a = arr[ii], b = arr[j];
+                    arr[ii] = b; arr[j] = a;
+                }
+                ii -= ok ? 1u : 0u;
             }
-            ii -= ok ? 1u : 0u;
-            m32 = ((m32 >> 1) >= ii) ? (m32 >> 1) : m32; // smallest 2^k − 1 >= ii: one step at most per decrement (harmless at ii == 0)
         }
         if (p == cnt) { r->has32 = false; continue; } // the whole block was consumed, its last high half included
         // finished inside the block: hand the unused draws back by replaying from the block's start
@@ -696,9 +706,10 @@ void rng_shuffle_impl(mtq_rng *r, int64_t n, int64_t *arr)
     }
 }
 
-void rng_shuffle(mtq_rng *r, int64_t n, int64_t *arr) { rng_shuffle_impl<true>(r, n, arr); }
+void rng_shuffle(mtq_rng *r, int64_t n, int64_t *arr) { rng_shuffle_impl<true, int64_t>(r, n, arr); }
+void rng_shuffle(mtq_rng *r, int64_t n, int32_t *arr) { rng_shuffle_impl<true, int32_t>(r, n, arr); }
 // The same draws without the array: advances the generator exactly as a shuffle of n elements would.
-void rng_skip_shuffle(mtq_rng *r, int64_t n) { rng_shuffle_impl<false>(r, n, nullptr); }
+void rng_skip_shuffle(mtq_rng *r, int64_t n) { rng_shuffle_impl<false, int64_t>(r, n, nullptr); }
 
 void rng_permutation(mtq_rng *r, int64_t n, int64_t *out)
 {
@@ -767,23 +778,24 @@ extern "C" int mtq_greedy_run(const double *stats, int64_t tiles, uint32_t fmt_m
     if (int rc = mtq_greedy_create(&g, stats, tiles, fmt_mask, metric, threshold, elem_count, formats[0])) return rc;
     mtq_rng rng;
     rng_seed(&rng, seed);
-    std::vector<int64_t> cand((size_t)tiles);
+    if (tiles > INT32_MAX) { mtq_greedy_destroy(g); return fail(MTQ_ERR_INVALID, "more than 2^31 tiles in one tensor"); }
+    std::vector<int32_t> cand((size_t)tiles);   // 32-bit tile ids: the shuffled array of a 4096² tensor is 64 KB instead of 128
     int rc = MTQ_OK;
     for (int f = 0; f < n_formats && rc == MTQ_OK; ++f) {
         int64_t n = 0;
-        for (int64_t t = 0; t < tiles; ++t) if (!g->fixed[(size_t)t]) cand[(size_t)n++] = t; // np.where(~fixed)[0], :228
+        for (int64_t t = 0; t < tiles; ++t) if (!g->fixed[(size_t)t]) cand[(size_t)n++] = (int32_t)t; // np.where(~fixed)[0], :228
         if (n == 0) break;                                                                     // :229-230
         if (f == 0 && n == tiles) {
             // The pass of the base format: every tile already has it, so each visit only asks whether the current value passes
             // (:237-241) — the same answer for all of them, whatever the order.  The generator still advances as the
             // permutation would have (the later passes' orders depend on it).
             rng_skip_shuffle(&rng, n);
-            rc = mtq_greedy_pass(g, formats[0], cand.data(), 1);              // evaluates the current value once, on tile 0
+            rc = greedy_pass_any<int32_t>(g, formats[0], cand.data(), 1);     // evaluates the current value once, on tile 0
             if (rc == MTQ_OK && g->fixed[0]) std::fill(g->fixed.begin(), g->fixed.end(), (uint8_t)1);
             continue;
         }
         rng_shuffle(&rng, n, cand.data());                                                    // order = rng.permutation(candidates), :231
-        rc = mtq_greedy_pass(g, formats[f], cand.data(), n);
+        rc = greedy_pass_any<int32_t>(g, formats[f], cand.data(), n);
     }
     if (rc == MTQ_OK && g->w == 3 && g->degenerate)
         rc = fail(MTQ_ERR_UNSUPPORTED, "zero-variance tensor: the decision needs the full records (Σ|x−y|), not the slim ones");
@@ -845,15 +857,16 @@ extern "C" int mtq_greedy_run_chain(const double *chain, const double *base, int
     rng_skip_shuffle(&rng, tiles);
     if (!is_good(pcc_hoisted(g.n, g.mean_x, g.am2, g.sum_y, g.sum_y2, g.sum_xy, g.sum_abs, &g.degenerate), MTQ_METRIC_PCC, threshold))
         std::fill(g.fixed.begin(), g.fixed.end(), (uint8_t)1);
-    std::vector<int64_t> cand((size_t)tiles);
+    if (tiles > INT32_MAX) return fail(MTQ_ERR_INVALID, "more than 2^31 tiles in one tensor");
+    std::vector<int32_t> cand((size_t)tiles);
     for (int p = 1; p < n_formats && rc == MTQ_OK; ++p) {
         int64_t n = 0;
-        for (int64_t t = 0; t < tiles; ++t) if (!g.fixed[(size_t)t]) cand[(size_t)n++] = t;
+        for (int64_t t = 0; t < tiles; ++t) if (!g.fixed[(size_t)t]) cand[(size_t)n++] = (int32_t)t;
         if (n == 0) break;
         rng_shuffle(&rng, n, cand.data());
         g.chain_off = 3 * (p - 1);
 #if defined(__x86_64__)
-        if (g_avx512 && g.n != 0.0) { rc = greedy_pass_pcc8<kScanChain>(&g, formats[p], 0, cand.data(), n); continue; }
+        if (g_avx512 && g.n != 0.0) { rc = greedy_pass_pcc8<kScanChain, int32_t>(&g, formats[p], 0, cand.data(), n); continue; }
 #endif
         for (int64_t k = 0; k < n; ++k) pcc_visit(&g, formats[p], 0, cand[(size_t)k]);
     }

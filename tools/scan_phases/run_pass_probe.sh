@@ -16,3 +16,5 @@ g++ -O2 -o /tmp/mtq_pass_probe pass_probe.cpp -L../../quantization_analysis_amd 
 echo "eight-wide:"; /tmp/mtq_pass_probe
 echo "scalar:"; MTQ_SCAN_SCALAR=1 /tmp/mtq_pass_probe
 grep -m1 "model name" /proc/cpuinfo
+g++ -O2 -o /tmp/mtq_rng_probe rng_probe.cpp -L../../quantization_analysis_amd -lmtq_hip -Wl,-rpath,$(cd ../../quantization_analysis_amd && pwd) -Wl,-rpath,/opt/rocm/lib
+echo "NumPy-compatible permutation:"; /tmp/mtq_rng_probe
