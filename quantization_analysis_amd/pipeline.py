@@ -70,6 +70,12 @@ def _scan_chunk_chain(first, chain, base, tiles_hw, numel, tile_formats, thresho
     return res
 
 
+def _when_landed(event, fn, *args):
+    """Chunk task of the streamed driver: sleep until the chunk's records are on the host (a blocking HIP event), then scan."""
+    event.synchronize()
+    return fn(*args)
+
+
 def columns_from_sums_batch(sums: np.ndarray, n: float) -> np.ndarray:
     """mtq_columns_from_sums for many tensors at once: sums [count, 7] (Σx, Σx², Σy, Σy², Σxy, Σ|d|, max|d|) → [count, 3]
     pcc, mae, atol — the same double operations in the same order (metrics.py:6-16 as moments), element-wise in NumPy."""
@@ -112,7 +118,6 @@ class GreedyPipeline:
         self._unresolved = []  # batches whose device-side columns are in flight (oldest first)
         self._open = []        # enqueued, not yet finished (oldest first)
         self._next_slot = 0
-        self._slot_owner = {}
 
     def _layout(self, x3d):
         """→ (K1 mask, host mask, slim?) for a batch.  bf16 storage: the bf16 candidate is the identity, its record slot would be
@@ -191,10 +196,8 @@ class GreedyPipeline:
         tiles = th * tw
         slot = self._next_slot
         self._next_slot = (slot + 1) % self.SLOTS
-        owner = self._slot_owner.get(slot)               # the batch SLOTS back: its device-side columns read the records K1 is about to overwrite
-        if owner is not None and "col_pending" in owner:
-            self.resolve(owner)
-            self._unresolved = [e for e in self._unresolved if e is not owner]
+        # the batch SLOTS back read this slot's records in its device-side column sums: those run on the K1 stream (see
+        # _launch_columns), ahead of the K1 launches below in stream order — no host-side wait is needed here
         chain = self._chain(slim)
         rec_host = 3 * (len(self.tile_formats) - 1) if chain else hb.record_doubles(host_mask)
         dev, stage, host, host_np = self._buffers(slot, count, tiles, hb.record_doubles(k1_mask), rec_host, x3d.device)
@@ -232,11 +235,22 @@ class GreedyPipeline:
                     done = torch.cuda.Event(blocking=True)   # the driver thread sleeps while it waits: spinning would burn a core of the scan budget
                     done.record(self.copy_stream)
                 pending.append((done, first, n))
-        enq = {"pending": pending, "host_np": host_np, "host_mask": host_mask, "tiles_hw": (th, tw), "numel": rows * cols,
+        enq = {"host_np": host_np, "host_mask": host_mask, "tiles_hw": (th, tw), "numel": rows * cols,
                "seeds": seeds, "x": x3d, "dev": dev, "k1_mask": k1_mask, "slim": slim, "chain": chain,
                "base_np": base_np if chain else None}
+        # The scans are handed to the chunk-task pool HERE, each behind its records' event: they start the moment the records land,
+        # whatever the driver thread is doing (with the submission in finish() the scans of a batch only started once the driver
+        # got there — all four chunks at once, 3.3 ms of scans with the GPU idle behind them).
+        futures = []
+        for done, first, n in pending:
+            if chain:
+                a = self._scan_args(enq, first, n, None, 0)
+                futures.append((first, n, self.pool.submit(_when_landed, done, _scan_chunk_chain, first, host_np[first:first + n], base_np[first:first + n],
+                                                           a[3], a[4], self.tile_formats, self.threshold, a[8], self.workers)))
+            else:
+                futures.append((first, n, self.pool.submit(_when_landed, done, _scan_chunk, *self._scan_args(enq, first, n, host_np[first:first + n], host_mask))))
+        enq["futures"] = futures
         self._open.append(enq)
-        self._slot_owner[slot] = enq
         return enq
 
     def _scan_args(self, enq: dict, first: int, n: int, stats, mask):
@@ -245,22 +259,14 @@ class GreedyPipeline:
         return (first, stats, mask, enq["tiles_hw"], enq["numel"], self.tile_formats, self.metric, self.threshold, sd, self.workers)
 
     def finish(self, enq: dict, defer_columns: bool = False) -> list[TensorResult]:
-        """Host half: as each chunk's records land, its scans go to the scan pool; returns when all of them are done.
+        """Host half: collects the chunk scans that enqueue() queued behind the records' events; returns when all of them are done.
         The GPU meanwhile works on whatever was enqueued after this batch.  With defer_columns the device-side columns of a
         slim batch are only LAUNCHED here (maps up, batched sums, seven doubles per tensor down, all asynchronous on their
         own stream, all from this thread); resolve(enq) waits for them and fills pcc / mae / atol in."""
         torch = self.torch
         if not self._open or self._open[0] is not enq:
             raise RuntimeError("batches finish in the order they were enqueued")
-        futures = []
-        for evt, first, n in enq["pending"]:
-            evt.synchronize()
-            if enq["chain"]:
-                a = self._scan_args(enq, first, n, None, 0)
-                futures.append((first, n, self.pool.submit(_scan_chunk_chain, first, enq["host_np"][first:first + n], enq["base_np"][first:first + n],
-                                                           a[3], a[4], self.tile_formats, self.threshold, a[8], self.workers)))
-            else:
-                futures.append((first, n, self.pool.submit(_scan_chunk, *self._scan_args(enq, first, n, enq["host_np"][first:first + n], enq["host_mask"]))))
+        futures = enq.pop("futures")
         results: list[TensorResult] = []
         for first, n, fut in futures:
             try:
@@ -295,15 +301,29 @@ class GreedyPipeline:
                  "sums_host": torch.empty((count, 7), dtype=torch.float64, pin_memory=True)} for _ in range(self.SLOTS)], "next": 0}
         cb = self._colbufs["ring"][self._colbufs["next"]]
         self._colbufs["next"] = (self._colbufs["next"] + 1) % self.SLOTS
+        user = cb.get("user")                            # the batch SLOTS back read its sums out of this ring entry
+        if user is not None and "col_pending" in user:
+            self.resolve(user)
+            self._unresolved = [e for e in self._unresolved if e is not user]
+        cb["user"] = enq
         mh = cb["maps_host"].numpy()
         for i, r in enumerate(results):
             mh[i] = r.assignment.reshape(-1)
-        # no stream dependency is needed (and none wanted: the copy stream already holds the NEXT batch's copies): this batch's
-        # records were complete before its D2H events fired, and those were waited for above
+        # The reduction runs on the K1 STREAM, between K1 launches: K1 is a persistent grid over every CU, and on a stream of its
+        # own this kernel only got waves in the gaps of the K1 stream — once the scans stopped leaving such gaps, the driver
+        # thread waited 3 ms per step for it.  Stream order also makes it read the records before a later batch's K1 overwrites
+        # them.  Only the two copies stay on the side stream.
         with torch.cuda.stream(self.col_stream):
             cb["maps_dev"].copy_(cb["maps_host"], non_blocking=True)
-            hb.check(hb.lib().mtq_column_sums_device_batched(dev.data_ptr(), count, tiles, enq["host_mask"] & ~hb.MASK_SLIM, cb["maps_dev"].data_ptr(),
-                                                             cb["scratch"].data_ptr(), self.col_stream.cuda_stream))
+            maps_up = torch.cuda.Event()
+            maps_up.record(self.col_stream)
+        self.stream.wait_event(maps_up)
+        hb.check(hb.lib().mtq_column_sums_device_batched(dev.data_ptr(), count, tiles, enq["host_mask"] & ~hb.MASK_SLIM, cb["maps_dev"].data_ptr(),
+                                                         cb["scratch"].data_ptr(), self.stream.cuda_stream))
+        summed = torch.cuda.Event()
+        summed.record(self.stream)
+        with torch.cuda.stream(self.col_stream):
+            self.col_stream.wait_event(summed)
             cb["sums_host"].copy_(cb["scratch"][:, :7], non_blocking=True)
             done = torch.cuda.Event(blocking=True)
             done.record(self.col_stream)

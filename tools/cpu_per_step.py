@@ -5,11 +5,15 @@ import torch
 from quantization_analysis_amd import hip_backend as hb, pipeline as pl
 import bench
 workers = int(sys.argv[1]) if len(sys.argv) > 1 else 16
-steps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+steps = int(sys.argv[2]) if len(sys.argv) > 2 else 100
+chunk = int(sys.argv[3]) if len(sys.argv) > 3 else 32
 hb.require_gpu()
+hb.bind_to_gpu_numa_node(0)
 batch = bench.make_batch(128, 0, torch.device('cuda', 0))
-pipe = pl.GreedyPipeline(bench.FORMATS, bench.METRIC, bench.THRESHOLD, bench.SEED, chunk=16, workers=workers)
-pipe.run_steps(batch for _ in range(2)); torch.cuda.synchronize()
+pipe = pl.GreedyPipeline(bench.FORMATS, bench.METRIC, bench.THRESHOLD, bench.SEED, chunk=chunk, workers=workers)
+pipe.reserve(batch)
+pipe.run_steps(batch for _ in range(5)); torch.cuda.synchronize()
+import gc; gc.collect(); gc.freeze()
 def thr():
     s = open('/sys/fs/cgroup/cpu.stat').read().split()
     d = dict(zip(s[0::2], s[1::2])); return int(d.get('nr_throttled', 0)), int(d.get('throttled_usec', 0)), int(d.get('usage_usec', 0))
