@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define MTQ_VERSION 123 /* 0.1.2: + mtq_rng_integers, identity-bf16 mask, device-side decisions */
+#define MTQ_VERSION 123 /* 0.1.2.3: + mtq_rng_integers, identity-bf16 / slim masks, device-side decisions, knife-edge format masks, chain records */
 
 typedef enum {
     MTQ_OK = 0,
