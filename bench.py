@@ -10,6 +10,7 @@ cpu_baseline = the C oracle (oracle/, a port of the reference's CPU path) on ran
         on a bounded sample of the same tensors.
 
   python bench.py --gpus 1 --steps 5 --warmup 1
+  python bench.py --gpus N ...            (N > 1, not under a launcher: starts its own N ranks before any GPU call)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 """
 from __future__ import annotations
@@ -95,6 +96,44 @@ def default_workers() -> int:
     return max(4, min(32, cpu_budget() // max(local, 1)))
 
 
+def self_launch(n: int, argv: list[str]) -> int:
+    """`python bench.py --gpus N` outside a launcher, N > 1: start N ranks (one process per GPU) as children of
+    `python -m torch.distributed.run` and return its exit code.  Runs BEFORE this process has made any GPU call, and the
+    parent never makes one: a process that has touched the GPU is never re-exec'ed (the ranks are fresh children).
+    Rank 0 of the child job prints the one JSON line; stdout/stderr pass through."""
+    import socket
+    import subprocess
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(Path(__file__).resolve())] + argv
+    return subprocess.run(cmd, env=env).returncode
+
+
+def dry_run(args) -> None:
+    """--dry-run: the rank plumbing of this file with no GPU and no measurement (CPU test of the launcher branch and of the
+    job's only collective): gloo instead of RCCL, made-up summary rows, `value` null."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    dist = None
+    if "RANK" in os.environ:
+        import torch.distributed as dist
+
+        dist.init_process_group("gloo")
+    rows = torch.full((2, 11), float(rank), dtype=torch.float64)
+    all_rows, dt = gather_summary(rows, 1.0 + rank, dist, rank, world)
+    if rank == 0:
+        print(json.dumps({"dry_run": True, "value": None, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ranks_seen": sorted({int(v) for v in all_rows[:, 1]}), "max_seconds": dt,
+                          "config": {"sharding": f"tensors x{world}, RCCL gather of summary rows"}}), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -104,8 +143,13 @@ def main() -> None:
     ap.add_argument("--chunk", type=int, default=32, help="tensors per K1 launch")
     ap.add_argument("--workers", type=int, default=default_workers(), help="host scan threads per rank (default: this rank's share of the cgroup CPU quota / affinity mask, at most 32)")
     ap.add_argument("--cpu-sample", type=int, default=24, help="tensors timed on the CPU port, ~0.5 s each (0 = skip)")
+    ap.add_argument("--dry-run", action="store_true", help="rank plumbing only, on the CPU over gloo (tests); prints no measurement")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args.gpus, sys.argv[1:]))   # nothing above this line touches the GPU
+    if args.dry_run:
+        return dry_run(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -189,6 +233,7 @@ def main() -> None:
                        "k1_chunk": args.chunk, "scan_workers": args.workers, "numa_bind": numa, "sharding": f"tensors x{world}, RCCL gather of summary rows"},
             "roofline": {"bound": "hbm", "kernel": "tile_stats (K1)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_source": "profiles/k1_traffic.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, B/tile x this run's tiles per launch)" if traffic is not None else None,
                          "launch_ms": k_ms, "tiles_per_launch": tiles_per_launch, "launches": kt.launches,
                          "kernel_tiles_per_s": tiles_per_launch / (k_ms * 1e-3)},
             "summary": {"tensors": int(all_rows.shape[0]), "mean_pcc": float(all_rows[:, 2].mean()),

@@ -189,6 +189,24 @@ def test_bench_gather_two_ranks_gloo(tmp_path):
     assert lone.shape == (2, 11) and dt == 0.5
 
 
+def test_bench_self_launches_its_ranks(tmp_path):
+    """`python bench.py --gpus 2` outside a launcher starts two ranks itself (before any GPU call) and rank 0 prints one JSON
+    line; --dry-run keeps the job on the CPU (gloo, made-up rows, no measurement)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE")}
+    env.update(PYTHONPATH=str(ROOT), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--dry-run"],
+                       cwd=tmp_path, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    out = lines[0]
+    assert out["n_gpus"] == 2 and out["ranks_seen"] == [0, 1] and out["max_seconds"] == 2.0 and "x2" in out["config"]["sharding"]
+    assert out["dry_run"] is True and out["value"] is None and out["steps"] == 3
+    # N = 1 never goes through the launcher
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--dry-run"], cwd=tmp_path, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and json.loads(r.stdout.strip().splitlines()[-1])["n_gpus"] == 1, r.stderr[-2000:]
+
+
 @pytest.mark.gpu
 def test_wq_hip_backend(tmp_path, monkeypatch):
     monkeypatch.chdir(tmp_path)
