@@ -267,6 +267,12 @@ int mtq_column_sums_device(const double *stats, int64_t tiles, uint32_t fmt_mask
 int mtq_column_sums_device_batched(const double *stats, int64_t count, int64_t tiles, uint32_t fmt_mask, const int8_t *maps,
                                    double *scratch, void *stream);
 
+/* Diagnostics (no reference counterpart).  K1's persistent waves claim their units from device counters that come from a
+ * per-device ring of slots (csrc/mtq_slot_ring.hpp): a slot is handed out again only behind the event recorded after its
+ * previous launch's reset, so any number of launches may be pending on any streams.  This runs that bookkeeping against
+ * mock event operations on the host (no GPU): 0 = every property holds, else the number of the first failed check. */
+int mtq_selftest_slot_ring(void);
+
 #ifdef __cplusplus
 }
 #endif

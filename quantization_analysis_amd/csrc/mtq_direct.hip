@@ -291,7 +291,7 @@ using namespace mtq;
 // Launcher used by mtq_tile_stats_batched for every input the bf16 LDS-staged kernel does not take (mtq_kernels.hip
 // decides and follows up with tile_stats_redo_flagged).  fmt_mask != 0, count * tiles < 2^31.
 extern "C" int mtq_launch_tile_stats_direct(const void *x, int in_dtype, int64_t count, int64_t stride_elems, int64_t rows, int64_t cols,
-                                            int64_t ld, uint32_t fmt_mask, double *stats, int vec_ok, void *stream, unsigned **work_out, unsigned launch_id)
+                                            int64_t ld, uint32_t fmt_mask, double *stats, int vec_ok, void *stream, mtq::WorkSlot *work_out, unsigned launch_id)
 {
     const int64_t th = (rows + kTile - 1) / kTile, tw = (cols + kTile - 1) / kTile, tiles = th * tw, total = count * tiles;
     if (total >= ((int64_t)1 << 31) || (fmt_mask & MTQ_MASK_ALL) == 0) return fail(MTQ_ERR_INVALID, "direct tile_stats launch out of range");
@@ -306,9 +306,8 @@ extern "C" int mtq_launch_tile_stats_direct(const void *x, int in_dtype, int64_t
     const int64_t max_blocks = (int64_t)cus * MTQ_DIRECT_WAVES_PER_SIMD;   // blocks of 4 waves: one wave of each per SIMD
     const dim3 grid((unsigned)(need < max_blocks ? need : max_blocks));
     hipStream_t st = static_cast<hipStream_t>(stream);
-    unsigned *work = work_counter_slot();
-    if (!work) return fail(MTQ_ERR_HIP, "could not allocate the work counters");
-    *work_out = work;
+    if (int rc = work_counter_acquire(stream, work_out)) return rc;   // `st` now waits for the slot's previous launch to have reset it
+    unsigned *work = work_out->counters;
     if (in_dtype == MTQ_DTYPE_BF16)
         launch_direct<uint16_t>(fmt_mask & MTQ_MASK_ALL, grid, st, static_cast<const uint16_t *>(x), stride_elems, rows, cols, ld, (uint32_t)tw,
                                 (uint32_t)tiles, (uint32_t)total, stats, vec_ok, work, launch_id);

@@ -10,14 +10,19 @@ int failf(int code, const char *fmt, ...);
 int require_device();
 // Zeroed device counters for one K1 launch (persistent waves claim their units from them): kWorkGroups counters,
 // kWorkStride unsigneds apart.  Slots come from a per-device ring of kWorkSlots; the follow-up kernel of the launch
-// (tile_stats_redo_flagged) sets the slot back to zero, so no memset sits on the stream.  nullptr when the ring cannot
-// be allocated.
+// (tile_stats_redo_flagged) sets the slot back to zero, so no memset sits on the stream.  A slot is handed out again only
+// behind the event recorded after that follow-up kernel (mtq_slot_ring.hpp): more than kWorkSlots pending launches queue
+// instead of sharing counters.
 constexpr int kWorkGroups = 64, kWorkStride = 32, kWorkSlots = 128;
 // Word 1 of a slot carries the id of the last launch that marked a tile for the literal fix-up (ids are unique per launch,
 // so the word never needs resetting): the follow-up kernel returns at once unless it finds its own launch's id there.
 constexpr int kWorkStamp = 1;
 unsigned next_launch_id();
-unsigned *work_counter_slot();
+struct WorkSlot { unsigned *counters = nullptr; int index = -1, device = -1; };
+// MTQ_OK and a slot whose previous user `stream` now waits for, or MTQ_ERR_HIP.
+int work_counter_acquire(void *stream, WorkSlot *out);
+// Records the slot's event on `stream` (behind the follow-up kernel) and gives the slot back.
+void work_counter_release(const WorkSlot &slot, void *stream);
 // hipGetLastError() → MTQ_OK / MTQ_ERR_HIP with the kernel name in the message.
 int check_launch(const char *what);
 } // namespace mtq

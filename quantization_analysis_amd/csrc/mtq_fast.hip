@@ -386,7 +386,7 @@ using namespace mtq;
 
 // Launcher used by mtq_tile_stats_batched when the input qualifies (mtq_kernels.hip decides).
 extern "C" int mtq_launch_tile_stats_bf16_fast(const void *x, int64_t count, int64_t stride_elems, int64_t rows, int64_t cols,
-                                               int64_t ld, uint32_t fmt_mask, double *stats, void *stream, unsigned **work_out, unsigned launch_id)
+                                               int64_t ld, uint32_t fmt_mask, double *stats, void *stream, mtq::WorkSlot *work_out, unsigned launch_id)
 {
     const int64_t th = rows / kTile, tw = cols / kTile, tiles = th * tw;
     const int64_t units_w = cols / kUnitCols, upt = th * units_w, total = count * upt;
@@ -406,9 +406,8 @@ extern "C" int mtq_launch_tile_stats_bf16_fast(const void *x, int64_t count, int
     const size_t lds_bytes = kFastWaves * kRolledWaveLds;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const uint16_t *xp = static_cast<const uint16_t *>(x);
-    unsigned *work = work_counter_slot();
-    if (!work) return fail(MTQ_ERR_HIP, "could not allocate the work counters");
-    *work_out = work;
+    if (int rc = work_counter_acquire(stream, work_out)) return rc;   // `st` now waits for the slot's previous launch to have reset it
+    unsigned *work = work_out->counters;
 #define MTQ_LAUNCH_FAST(B) \
     hipLaunchKernelGGL(tile_stats_bf16_rolled<B>, grid, block, lds_bytes, st, xp, stride_elems, ld, (int)tw, tiles, (int)units_w, (int)upt, (int)total, fmt_mask, rec, stats, work, launch_id)
     switch ((fmt_mask >> 1) & 7u) { // one instantiation per requested BFP subset: unrequested formats cost nothing

@@ -11,6 +11,7 @@
 #include "../../include/mtq.h"
 #include "mtq_device.hpp"
 #include "mtq_error.hpp"
+#include "mtq_slot_ring.hpp"
 
 namespace mtq {
 
@@ -275,9 +276,9 @@ static int check_matrix(const void *x, int in_dtype, int64_t rows, int64_t cols,
 using namespace mtq;
 
 extern "C" int mtq_launch_tile_stats_bf16_fast(const void *x, int64_t count, int64_t stride_elems, int64_t rows, int64_t cols,
-                                               int64_t ld, uint32_t fmt_mask, double *stats, void *stream, unsigned **work_out, unsigned launch_id);
+                                               int64_t ld, uint32_t fmt_mask, double *stats, void *stream, mtq::WorkSlot *work_out, unsigned launch_id);
 extern "C" int mtq_launch_tile_stats_direct(const void *x, int in_dtype, int64_t count, int64_t stride_elems, int64_t rows, int64_t cols,
-                                            int64_t ld, uint32_t fmt_mask, double *stats, int vec_ok, void *stream, unsigned **work_out, unsigned launch_id);
+                                            int64_t ld, uint32_t fmt_mask, double *stats, int vec_ok, void *stream, mtq::WorkSlot *work_out, unsigned launch_id);
 
 unsigned mtq::next_launch_id()
 {
@@ -286,27 +287,98 @@ unsigned mtq::next_launch_id()
     return v ? v : id.fetch_add(1u);   // 0 is what a fresh slot holds
 }
 
-// Per-device ring of zeroed unit counters (mtq_error.hpp).  A slot is handed to one K1 launch and set back to zero by
-// that launch's follow-up kernel on the same stream; kWorkSlots launches would have to be pending for a slot to be shared.
-unsigned *mtq::work_counter_slot()
+// Per-device ring of zeroed unit counters (mtq_error.hpp, mtq_slot_ring.hpp).  A slot is handed to one K1 launch and set back
+// to zero by that launch's follow-up kernel on the same stream; the slot's event, recorded behind that kernel, orders its next
+// user after it whatever the stream.
+namespace {
+struct HipEventOps {
+    typedef hipEvent_t event;
+    typedef hipStream_t stream;
+    static bool create(event &e) { return hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess; }
+    static bool record(event &e, stream s) { return hipEventRecord(e, s) == hipSuccess; }
+    static bool wait(stream s, event &e) { return hipStreamWaitEvent(s, e, 0) == hipSuccess; }
+};
+constexpr int kMaxDev = 64;
+constexpr size_t kSlotUnsigned = (size_t)kWorkGroups * kWorkStride;
+struct DeviceRing {
+    std::atomic<unsigned *> base{nullptr};
+    SlotRing<HipEventOps, kWorkSlots> slots;
+};
+DeviceRing g_rings[kMaxDev];
+std::mutex g_ring_mu;
+} // namespace
+
+int mtq::work_counter_acquire(void *stream, WorkSlot *out)
 {
-    constexpr int kMaxDev = 64;
-    constexpr size_t kSlotUnsigned = (size_t)kWorkGroups * kWorkStride;
-    static unsigned *ring[kMaxDev] = {nullptr};
-    static std::atomic<unsigned> next[kMaxDev];
-    static std::mutex mu;
     int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev) return nullptr;
-    if (!ring[dev]) {
-        std::lock_guard<std::mutex> lock(mu);
-        if (!ring[dev]) {
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev) return fail(MTQ_ERR_HIP, "hipGetDevice failed");
+    DeviceRing &r = g_rings[dev];
+    unsigned *base = r.base.load(std::memory_order_acquire);
+    if (!base) {
+        std::lock_guard<std::mutex> lock(g_ring_mu);
+        base = r.base.load(std::memory_order_relaxed);
+        if (!base) {
             unsigned *p = nullptr;
-            if (hipMalloc(reinterpret_cast<void **>(&p), kWorkSlots * kSlotUnsigned * sizeof(unsigned)) != hipSuccess) return nullptr;
-            if (hipMemset(p, 0, kWorkSlots * kSlotUnsigned * sizeof(unsigned)) != hipSuccess || hipDeviceSynchronize() != hipSuccess) { (void)hipFree(p); return nullptr; }
-            ring[dev] = p;
+            if (hipMalloc(reinterpret_cast<void **>(&p), kWorkSlots * kSlotUnsigned * sizeof(unsigned)) != hipSuccess) return fail(MTQ_ERR_HIP, "could not allocate the work counters");
+            if (hipMemset(p, 0, kWorkSlots * kSlotUnsigned * sizeof(unsigned)) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
+                (void)hipFree(p);
+                return fail(MTQ_ERR_HIP, "could not clear the work counters");
+            }
+            r.base.store(p, std::memory_order_release);
+            base = p;
         }
     }
-    return ring[dev] + (next[dev].fetch_add(1u) % kWorkSlots) * kSlotUnsigned;
+    const int i = r.slots.acquire(static_cast<hipStream_t>(stream));
+    if (i < 0) return fail(MTQ_ERR_HIP, "no free work-counter slot (every slot is mid-launch on another thread, or hipStreamWaitEvent failed)");
+    out->counters = base + (size_t)i * kSlotUnsigned;
+    out->index = i;
+    out->device = dev;
+    return MTQ_OK;
+}
+
+void mtq::work_counter_release(const WorkSlot &slot, void *stream)
+{
+    if (slot.index < 0 || slot.device < 0) return;
+    (void)g_rings[slot.device].slots.release(slot.index, static_cast<hipStream_t>(stream));
+}
+
+// The bookkeeping above against mock event operations (no GPU): 0 when every property holds, else the number of the
+// first failed check.  Exported for tests/test_capi_host.py.
+namespace {
+struct MockOps {
+    struct event { int id = -1; int recorded_on = -1; };
+    typedef int stream;
+    static int created, waits, last_wait_event, last_wait_stream;
+    static bool create(event &e) { e.id = created++; return true; }
+    static bool record(event &e, stream s) { e.recorded_on = s; return true; }
+    static bool wait(stream s, event &e) { ++waits; last_wait_event = e.id; last_wait_stream = s; return e.recorded_on >= 0; }
+};
+int MockOps::created = 0, MockOps::waits = 0, MockOps::last_wait_event = -1, MockOps::last_wait_stream = -1;
+} // namespace
+
+extern "C" int mtq_selftest_slot_ring(void)
+{
+    MockOps::created = MockOps::waits = 0;
+    static SlotRing<MockOps, 4> ring;                    // static: the mutexes are not movable; the test runs once per process
+    int a[4];
+    for (int k = 0; k < 4; ++k) a[k] = ring.acquire(10 + k);
+    for (int k = 0; k < 4; ++k) if (a[k] != k) return 1;                 // round robin over fresh slots
+    if (MockOps::waits != 0) return 2;                                    // fresh slots have nothing to wait for
+    if (ring.acquire(20) != -1) return 3;                                 // all four held between acquire and release: refused, not shared
+    if (!ring.release(1, 11)) return 4;
+    const int b = ring.acquire(21);                                       // the only free slot, found wherever the cursor stands
+    if (b != 1) return 5;
+    if (MockOps::waits != 1 || MockOps::last_wait_stream != 21 || MockOps::last_wait_event != 0) return 6;   // its next user waits for its event
+    for (int k = 0; k < 4; ++k) if (!ring.release(k, 30 + k)) return 7;
+    if (MockOps::created != 4) return 8;                                  // one event per slot, created once
+    const int before = MockOps::waits;
+    for (int k = 0; k < 8; ++k) {                                         // 2 × N launches in a row: every reuse waits
+        const int i = ring.acquire(40 + k);
+        if (i < 0) return 9;
+        if (!ring.release(i, 40 + k)) return 10;
+    }
+    if (MockOps::waits != before + 8) return 11;
+    return 0;
 }
 
 // MTQ_FORCE_GENERIC=1 routes every input through tile_stats_generic (A/B checks of the fast kernel).
@@ -319,10 +391,11 @@ static bool force_generic()
 
 // The follow-up kernel zeroes the launch's unit counter; if it could not be launched, do it with a memset so that the
 // slot's next user does not start from a stale count.
-static int finish_counter_launch(unsigned *work, hipStream_t s)
+static int finish_counter_launch(const WorkSlot &work, hipStream_t s)
 {
     const int rc = check_launch("mtq_tile_stats (redo flagged)");
-    if (rc != MTQ_OK) (void)hipMemsetAsync(work, 0, (size_t)kWorkGroups * kWorkStride * sizeof(unsigned), s);
+    if (rc != MTQ_OK) (void)hipMemsetAsync(work.counters, 0, (size_t)kWorkGroups * kWorkStride * sizeof(unsigned), s);
+    work_counter_release(work, s);   // the slot's next user is ordered behind the reset, on whatever stream it launches
     return rc;
 }
 
@@ -371,27 +444,27 @@ extern "C" int mtq_tile_stats_batched(const void *x, int in_dtype, int64_t count
     const int vec_ok = aligned16(x) && (ld * esz) % 16 == 0 && (stride_elems * esz) % 16 == 0;
     // bf16 storage, whole 32x128 units, 16-byte aligned rows, at least one BFP format → exact-integer fast kernel
     if (in_dtype == MTQ_DTYPE_BF16 && vec_ok && rows % kTile == 0 && cols % 128 == 0 && (fmt_mask & 0xEu) != 0 && !force_generic()) {
-        unsigned *work = nullptr;
+        WorkSlot work;
         const unsigned launch_id = next_launch_id();
         if (int rc = mtq_launch_tile_stats_bf16_fast(x, count, stride_elems, rows, cols, ld, fmt_mask, stats, stream, &work, launch_id)) return rc;
         const int64_t waves = (count * tiles + 63) / 64;
         hipLaunchKernelGGL(tile_stats_redo_flagged<uint16_t>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, static_cast<hipStream_t>(stream),
-                           static_cast<const uint16_t *>(x), count, stride_elems, rows, cols, ld, (int)tw, tiles, fmt_mask, rec, stats, vec_ok, work, launch_id);
+                           static_cast<const uint16_t *>(x), count, stride_elems, rows, cols, ld, (int)tw, tiles, fmt_mask, rec, stats, vec_ok, work.counters, launch_id);
         return finish_counter_launch(work, static_cast<hipStream_t>(stream));
     }
     hipStream_t s = static_cast<hipStream_t>(stream);
     // float32 storage, ragged or unaligned bf16: one wave per tile on the reduced-arithmetic route (mtq_direct.hip)
     if ((fmt_mask & MTQ_MASK_ALL) != 0 && count * tiles < ((int64_t)1 << 31) && !force_generic()) {
-        unsigned *work = nullptr;
+        WorkSlot work;
         const unsigned launch_id = next_launch_id();
         if (int rc = mtq_launch_tile_stats_direct(x, in_dtype, count, stride_elems, rows, cols, ld, fmt_mask, stats, vec_ok, stream, &work, launch_id)) return rc;
         const dim3 rgrid((unsigned)(((count * tiles + 63) / 64 + 3) / 4));
         if (in_dtype == MTQ_DTYPE_BF16)
             hipLaunchKernelGGL(tile_stats_redo_flagged<uint16_t>, rgrid, dim3(256), 0, s, static_cast<const uint16_t *>(x), count, stride_elems,
-                               rows, cols, ld, (int)tw, tiles, fmt_mask, rec, stats, vec_ok, work, launch_id);
+                               rows, cols, ld, (int)tw, tiles, fmt_mask, rec, stats, vec_ok, work.counters, launch_id);
         else
             hipLaunchKernelGGL(tile_stats_redo_flagged<float>, rgrid, dim3(256), 0, s, static_cast<const float *>(x), count, stride_elems, rows,
-                               cols, ld, (int)tw, tiles, fmt_mask, rec, stats, vec_ok, work, launch_id);
+                               cols, ld, (int)tw, tiles, fmt_mask, rec, stats, vec_ok, work.counters, launch_id);
         return finish_counter_launch(work, s);
     }
     const int64_t blocks = (count * tiles + 3) / 4;

@@ -31,6 +31,7 @@ EXPORTS = [
     "mtq_greedy_run_chain", "mtq_greedy_run_chain_batch", "mtq_pack_chain_records", "mtq_tile_scores", "mtq_threshold_assign", "mtq_columns_from_stats", "mtq_columns_from_sums", "mtq_tile_scores_device",
     "mtq_threshold_assign_device", "mtq_columns_scratch_doubles", "mtq_column_sums_device", "mtq_column_sums_device_batched",
     "mtq_rng_create", "mtq_rng_permutation", "mtq_rng_integers", "mtq_rng_destroy", "mtq_greedy_run", "mtq_greedy_run_batch",
+    "mtq_selftest_slot_ring",
 ]
 
 

@@ -29,6 +29,12 @@ def test_header_symbols_exported():
     assert L.mtq_stats_record_doubles(0xF) == 22 and L.mtq_stats_record_doubles(0b0110) == 12
 
 
+def test_work_counter_slot_bookkeeping():
+    """K1's work-counter slots (csrc/mtq_slot_ring.hpp) against mock events, on the host: round robin, a slot held between
+    acquire and release is never shared, every reuse waits for the event its previous user recorded."""
+    assert hb.lib().mtq_selftest_slot_ring() == 0
+
+
 def test_argument_errors_are_reported():
     L = hb.lib()
     assert L.mtq_tile_stats(None, 0, 32, 32, 32, 0xF, None, None) == -1
