@@ -20,7 +20,15 @@ from .quantizer import Quantizer
 from .tile_search import TileStats, columns_from_stats, compute_tile_stats, gather_tiles, reconstruct
 from .tile_utils import MIXED_TILE_BYTES_PER_ELEM, MIXED_TILE_FORMATS, mixed_tile_total_bytes, tile_metrics
 
-KNIFE_BAND = 2e-6  # float64-moment score vs float32 two-pass score differ by <= 3.1e-7 (measured)
+# float64-moment score vs float32 two-pass score differ by <= 3.1e-7 for scores of order 1 (measured); the
+# float32 error is relative, so the band is KNIFE_BAND * max(1, |threshold|) (csrc/mtq_decide.hpp, sweep.knife_width):
+# golden F13 holds mae thresholds around 1e3.
+KNIFE_BAND = 2e-6
+
+
+def knife_width(threshold, band: float = KNIFE_BAND):
+    """Half-width of the band around float32(threshold) inside which a float64-moment score is re-decided literally."""
+    return band * np.maximum(1.0, np.abs(np.asarray(threshold, dtype=np.float64)))
 
 
 def threshold_assign(ts: TileStats, tile_formats: list[str], metric: str, threshold: float, quantizer: Quantizer,

@@ -73,16 +73,19 @@ MTQ_HD inline double tile_score(const double *r, int slot, int metric)
 // mixed_tile_threshold.py:111-123 for one tile: formats in ascending bytes (order[], their record slots in slots[]), the
 // first whose score passes, else `best` (the highest-bytes one).  The reference compares float32 scores with a
 // float32-rounded threshold (NumPy >= 2, NEP 50): thr32 = (double)(float)threshold.  `near` gets bit c for every looked-at
-// format code c whose score lies within `band` of thr32 (its decision is inside the float32 noise band: the caller decides
-// exactly those with the literal float32 expression; formats behind the chosen one were not looked at).
+// format code c whose score lies within `band`·max(1, |thr32|) of thr32 (its decision is inside the float32 noise band — the
+// reference's float32 mean / Pearson carry a RELATIVE error, so for mae thresholds far above 1 the band scales with the
+// threshold: the caller decides exactly those with the literal float32 expression; formats behind the chosen one were not
+// looked at).
 struct ThresholdPlan { int order[MTQ_NUM_TILE_FORMATS], slots[MTQ_NUM_TILE_FORMATS], n, best; };
 MTQ_HD inline int threshold_decide(const double *r, const ThresholdPlan &p, int metric, double thr32, double band, unsigned &near)
 {
     int chosen = p.best;
     near = 0u;
+    const double a32 = __builtin_fabs(thr32), width = band * (a32 > 1.0 ? a32 : 1.0);
     for (int i = 0; i < p.n; ++i) {
         const double s = tile_score(r, p.slots[i], metric);
-        if (__builtin_fabs(s - thr32) <= band) near |= 1u << p.order[i];
+        if (__builtin_fabs(s - thr32) <= width) near |= 1u << p.order[i];
         if (is_good((double)(float)s, metric, thr32)) { chosen = p.order[i]; break; }
     }
     return chosen;

@@ -10,7 +10,7 @@ from __future__ import annotations
 
 import numpy as np
 
-from .compression_algorithms.mixed_tile_threshold import KNIFE_BAND, _quantize_tiles
+from .compression_algorithms.mixed_tile_threshold import KNIFE_BAND, _quantize_tiles, knife_width
 from .compression_algorithms.quantizer import Quantizer
 from .compression_algorithms.tile_search import columns_from_stats, compute_tile_stats, gather_tiles, tile_scores
 from .compression_algorithms.tile_utils import MIXED_TILE_BYTES_PER_ELEM, MIXED_TILE_FORMATS, mixed_tile_total_bytes, tile_metrics
@@ -74,7 +74,7 @@ def sweep_tensor(xf, formats: list[str], metric: str, lowest_metric_val: float, 
     # the start of the sweep is itself a float32 tile score of the reference: take the literal one for the extreme tile
     if metric != "atol":
         t_ext = int(np.argmax(s32[hi]) if metric == "pcc" else np.argmin(s32[hi]))
-        cand = np.unique(np.concatenate([[t_ext], np.where(np.abs(s64[hi] - s64[hi][t_ext]) <= KNIFE_BAND)[0]]))
+        cand = np.unique(np.concatenate([[t_ext], np.where(np.abs(s64[hi] - s64[hi][t_ext]) <= knife_width(s64[hi][t_ext]))[0]]))
         if cand.size > MAX_LITERAL_START_TILES:
             # identity-like formats (bf16 of bf16 data): every tile is a candidate and the literal float32 scores are
             # 1 ± 1 ulp; the maximum over a few thousand of them is the maximum over all (each tile rounds up with
@@ -95,7 +95,7 @@ def sweep_tensor(xf, formats: list[str], metric: str, lowest_metric_val: float, 
             pos = np.searchsorted(srt, s64[fi])
             for off in (-1, 0):
                 idx = np.clip(pos + off, 0, srt.size - 1)
-                near |= np.abs(s64[fi] - srt[idx]) <= KNIFE_BAND
+                near |= np.abs(s64[fi] - srt[idx]) <= knife_width(srt[idx])
             ids = np.where(near)[0]
             if ids.size:
                 xt = gather_tiles(ts, ids)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Generate tests/golden/*.npz by IMPORTING the reference (johanna-rock/quantization_analysis).
 
-Run in the build container only:  python tests/golden/make_golden.py
+Run in the build container only:  python tests/golden/make_golden.py [r1|r2|all]   (r1 = the round-1 files, r2 = F3, F7, F11–F13)
 The reference lives at /root/reference and never travels; only the arrays written here are
 committed.  Fixture list follows SURVEY.md §8(c) F1–F8.  Inputs ≤ 64 K elements are stored;
 larger inputs are stored as a (generator, seed, shape) recipe plus a SHA-256 of their bytes.
@@ -87,7 +87,7 @@ def specials_matrix() -> np.ndarray:
     return x
 
 
-def main() -> None:
+def main_r1() -> None:
     meta = {"numpy": np.__version__, "reference": "johanna-rock/quantization_analysis @ /root/reference (2026-03-13 snapshot)"}
     q = Quantizer("emulation")
 
@@ -337,5 +337,185 @@ def main() -> None:
     print("wrote", sorted(p.name for p in OUT.glob("*.npz")))
 
 
+# =====================================================================================================
+# Round 2 additions (VERDICT r1 "what's missing" 1 and 4): separate files, the round-1 files above stay as they are.
+# =====================================================================================================
+def m1_tensor() -> np.ndarray:
+    """SURVEY §8(d) M1 / BASELINE configs[1]: one 4096x4096 bf16 tensor from the CPU generator, as float32 values."""
+    import torch
+
+    g = torch.Generator().manual_seed(0)
+    return (torch.randn(4096, 4096, generator=g) * 0.02).to(torch.bfloat16).float().numpy()
+
+
+def pearson64(a: np.ndarray, b: np.ndarray) -> float:
+    """Two-pass float64 Pearson (the 'true' value the float32 column of metrics.py:6-16 approximates)."""
+    a = a.astype(np.float64).ravel()
+    b = b.astype(np.float64).ravel()
+    am, bm = a - a.mean(), b - b.mean()
+    den = float(np.sqrt(np.dot(am, am) * np.dot(bm, bm)))
+    return 1.0 if den == 0.0 and np.max(np.abs(a - b)) == 0 else (float(np.dot(am, bm)) / den if den else 0.0)
+
+
+def run_algo(name: str, params: dict, xi: np.ndarray, fmts, q, tmp: str) -> dict:
+    """One reference run → the integers and floats a test can pin without storing the arrays (maps and y by SHA-256)."""
+    res = create_algorithm(name, params).run(xi, fmts, q, cache_ctx(tmp))[0]
+    y = np.asarray(res.y, dtype=np.float32)
+    diff = np.abs(xi - y)
+    a = res.meta["assignment"].astype(np.int8)
+    return {"assign": a, "y": y,
+            "summary": {"counts": [int(res.tile_counts[f]) for f in ALL], "tile_bytes": float(res.tile_bytes),
+                        "pcc32": pearson_corr(xi, y), "mae32": float(np.mean(diff)), "atol32": float(np.max(diff)),
+                        "pcc64": pearson64(xi, y), "mae64": float(np.mean(diff.astype(np.float64))),
+                        "assign_shape": list(a.shape), "assign_sha256": sha(a), "y_sha256": sha(y), "x_sha256": sha(xi)}}
+
+
+def main_r2() -> None:
+    import os
+    import time
+
+    q = Quantizer("emulation")
+    meta = {"numpy": np.__version__, "reference": "johanna-rock/quantization_analysis @ /root/reference (2026-03-13 snapshot)"}
+    repo_root = str(OUT.parent.parent)
+    if repo_root not in sys.path:
+        sys.path.append(repo_root)   # AFTER the reference: `compression_algorithms`, `quantization_formats` stay the reference's
+    from quantization_analysis_amd import model_source  # tensor recipes of the synthetic presets (inputs only)
+
+    # ---------------------------------------------------------------- F3: per-tile float64 sums, the reference's own np.sum
+    # (mixed_tile_greedy.py:147-174 for Σx..Σ|d| with np.sum(float32 expr, dtype=float64); :208-214 for the tile maximum)
+    f3 = {}
+    for tag, xi in (("bf16_256", gen("normal_bf16", 81, (256, 256))), ("f32_96x160", gen("heavy_f32", 82, (96, 160)))):
+        padded, _si, pad = reshape_to_2d_with_padding(xi)
+        th_, tw_ = pad[2] // 32, pad[3] // 32
+        tx = padded.reshape(th_, 32, tw_, 32).transpose(0, 2, 1, 3).reshape(-1, 32, 32)
+        rec = np.zeros((th_ * tw_, 2 + 5 * len(ALL)), dtype=np.float64)
+        with np.errstate(all="ignore"):
+            tys = []
+            for fmt in ALL:
+                pq, _, _ = reshape_to_2d_with_padding(q.quantize(xi, fmt))
+                tys.append(pq.reshape(th_, 32, tw_, 32).transpose(0, 2, 1, 3).reshape(-1, 32, 32))
+            for t in range(th_ * tw_):
+                xv = tx[t]
+                rec[t, 0] = float(np.sum(xv, dtype=np.float64))
+                rec[t, 1] = float(np.sum(xv * xv, dtype=np.float64))
+                for k, ty in enumerate(tys):
+                    yv = ty[t]
+                    d = np.abs(xv - yv)
+                    rec[t, 2 + 5 * k: 7 + 5 * k] = [float(np.sum(yv, dtype=np.float64)), float(np.sum(yv * yv, dtype=np.float64)),
+                                                    float(np.sum(xv * yv, dtype=np.float64)), float(np.sum(d, dtype=np.float64)), float(np.max(d))]
+        f3[f"{tag}_x"] = xi
+        f3[f"{tag}_records"] = rec
+    np.savez_compressed(OUT / "f3_tile_sums.npz", **f3)
+
+    # ---------------------------------------------------------------- F7: the reference's `wq` itself → table.txt + used.json
+    # wq is loaded from its file; only the network loader is substituted (build_model_index / load_tensor_fp32 /
+    # resolve_selected_tensors → the `synthetic:tiny` preset of this repo); everything from argparse to the table writer runs.
+    import contextlib
+    import importlib.machinery
+    import importlib.util
+    import io
+    import types
+
+    loader = importlib.machinery.SourceFileLoader("ref_wq", REF + "/wq")
+    spec = importlib.util.spec_from_loader("ref_wq", loader)
+    ref_wq = importlib.util.module_from_spec(spec)
+    sys.modules["ref_wq"] = ref_wq   # dataclasses looks the defining module up by name
+    loader.exec_module(ref_wq)
+    tiny = model_source.build_model_index("synthetic:tiny")
+    names = model_source.resolve_selected_tensors(tiny, None)
+    ref_wq.build_model_index = lambda repo_or_url, revision, cache_dir: types.SimpleNamespace(repo_id="synthetic/tiny", revision=revision)
+    ref_wq.resolve_selected_tensors = lambda index, fq: list(names)
+    ref_wq.load_tensor_fp32 = lambda index, name: tiny.load(name).float().numpy()
+    f7_dir = OUT / "f7_wq"
+    f7_dir.mkdir(exist_ok=True)
+    cfgs = {"greedy": {"algorithm": "mixed-tile-greedy", "quantization_formats": ["bf16", "bfp8", "bfp4", "bfp2", "fp0"], "seed": 123,
+                       "params": {"metric": "pcc", "threshold": 0.999}},
+            "threshold": {"algorithm": "mixed-tile-threshold", "quantization_formats": ["bf16", "bfp8", "bfp4", "bfp2"],
+                          "params": {"metric": "pcc", "threshold": 0.99}}}
+    for tag, cfg in cfgs.items():
+        with tempfile.TemporaryDirectory() as tmp:
+            cwd = os.getcwd()
+            os.chdir(tmp)
+            try:
+                Path("cfg.json").write_text(json.dumps(cfg))
+                ref_wq.fp32_tensor_cache_dir = lambda index: Path(tmp) / "fp32"
+                argv, sys.argv = sys.argv, ["wq", "synthetic/tiny", "--compression-config", "cfg.json", "--summary"]
+                try:
+                    with contextlib.redirect_stdout(io.StringIO()), contextlib.redirect_stderr(io.StringIO()):
+                        rc = ref_wq.run()
+                finally:
+                    sys.argv = argv
+                assert rc == 0
+                run_dirs = sorted(Path("results").glob("*/*/*"))
+                assert len(run_dirs) == 1
+                (f7_dir / f"{tag}_config.json").write_text(json.dumps(cfg, indent=1))
+                (f7_dir / f"{tag}_table.txt").write_text((run_dirs[0] / "table.txt").read_text())
+                (f7_dir / f"{tag}_compression_config.used.json").write_text((run_dirs[0] / "compression_config.used.json").read_text())
+                maps = {n: np.load(p) for n in names for p in run_dirs[0].rglob(f"{ref_wq._slug(n)}/assignment.npy")}
+                np.savez_compressed(f7_dir / f"{tag}_assignments.npz", **maps)
+            finally:
+                os.chdir(cwd)
+
+    # ---------------------------------------------------------------- F11: the headline size (BASELINE configs[1], M1 tensor)
+    f11 = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        x = m1_tensor()
+        t0 = time.perf_counter()
+        f11["greedy_pcc999_seed123"] = run_algo("mixed-tile-greedy", {"metric": "pcc", "threshold": 0.999, "seed": 123, "formats": ALL}, x, ALL, q, tmp)["summary"]
+        f11["greedy_pcc999_seed123"]["reference_seconds"] = round(time.perf_counter() - t0, 1)
+        for thr in (0.94, 0.999):
+            f11[f"threshold_pcc{thr}"] = run_algo("mixed-tile-threshold", {"metric": "pcc", "threshold": thr, "formats": ALL}, x, ALL, q, tmp)["summary"]
+        f11["input"] = "torch.Generator().manual_seed(0); (torch.randn(4096,4096,generator=g)*0.02).to(bfloat16)  (SURVEY 8(d) M1)"
+    meta["f11"] = f11
+
+    # ---------------------------------------------------------------- F12: BASELINE configs[2] / [3] on their own tensor shapes (a subset the
+    # reference finishes in about a minute): DeepSeek-R1 layer-0 self_attn vectors + kv_a_proj_with_mqa, threshold; Llama-3-8B layer-0
+    # k_proj, greedy.  Inputs are this repo's synthetic presets (model_source), results are the reference's.
+    f12 = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        ds = model_source.build_model_index("synthetic:deepseek-r1-layer0")
+        for n in ("model.layers.0.self_attn.q_a_layernorm.weight", "model.layers.0.self_attn.kv_a_layernorm.weight",
+                  "model.layers.0.self_attn.kv_a_proj_with_mqa.weight"):
+            xi = np.asarray(ds.load(n).float().numpy(), dtype=np.float32)
+            for thr in (0.94, 0.999):
+                f12[f"deepseek|{n}|threshold|{thr}"] = run_algo("mixed-tile-threshold", {"metric": "pcc", "threshold": thr, "formats": ALL}, xi, ALL, q, tmp)["summary"]
+        ll = model_source.build_model_index("synthetic:llama3-8b")
+        n = "model.layers.0.self_attn.k_proj.weight"
+        xi = np.asarray(ll.load(n).float().numpy(), dtype=np.float32)
+        f12[f"llama|{n}|greedy|0.999|123"] = run_algo("mixed-tile-greedy", {"metric": "pcc", "threshold": 0.999, "seed": 123, "formats": ALL}, xi, ALL, q, tmp)["summary"]
+    meta["f12"] = f12
+
+    # ---------------------------------------------------------------- F13: large-magnitude mae thresholds (ADVICE r1: the knife-edge band must
+    # scale with the score).  |x| up to ~1e5; thresholds: the median per-tile bfp4 score, exactly one tile's float32 score, that + 1 ulp.
+    f13, f13_meta = {}, {}
+    xi = (gen("heavy_f32", 90, (160, 224)) * np.float32(1e5)).astype(np.float32)
+    padded, _si, pad = reshape_to_2d_with_padding(xi)
+    th_, tw_ = pad[2] // 32, pad[3] // 32
+    tr = padded.reshape(th_, 32, tw_, 32).transpose(0, 2, 1, 3).reshape(-1, 32, 32)
+    pq, _, _ = reshape_to_2d_with_padding(q.quantize(xi, "bfp4"))
+    s4 = np.asarray(tile_metrics(tr, pq.reshape(th_, 32, tw_, 32).transpose(0, 2, 1, 3).reshape(-1, 32, 32), "mae"), dtype=np.float32)
+    one = np.sort(s4)[len(s4) // 3]
+    f13["x"] = xi
+    with tempfile.TemporaryDirectory() as tmp:
+        for tag, thr in (("median", float(np.median(s4))), ("knife_eq", float(one)), ("knife_ulp", float(np.nextafter(one, np.float32(np.inf)))),
+                         ("knife_below", float(np.nextafter(one, np.float32(0))))):
+            r = run_algo("mixed-tile-threshold", {"metric": "mae", "threshold": thr, "formats": ALL}, xi, ALL, q, tmp)
+            f13[f"{tag}_assign"] = r["assign"]
+            f13_meta[tag] = {"threshold": thr, **r["summary"]}
+        for tag, thr, seed in (("greedy_mae", float(np.median(s4)) * 0.5, 41),):
+            r = run_algo("mixed-tile-greedy", {"metric": "mae", "threshold": thr, "seed": seed, "formats": ALL}, xi, ALL, q, tmp)
+            f13[f"{tag}_assign"] = r["assign"]
+            f13_meta[tag] = {"threshold": thr, "algo_seed": seed, **r["summary"]}
+    np.savez_compressed(OUT / "f13_large_magnitude.npz", **f13)
+    meta["f13"] = f13_meta
+
+    (OUT / "golden_meta_r2.json").write_text(json.dumps(meta, indent=1, sort_keys=True))
+    print("wrote f3_tile_sums.npz, f7_wq/, f13_large_magnitude.npz, golden_meta_r2.json (f11, f12, f13)")
+
+
 if __name__ == "__main__":
-    main()
+    which = sys.argv[1] if len(sys.argv) > 1 else "all"
+    if which in ("r1", "all"):
+        main_r1()
+    if which in ("r2", "all"):
+        main_r2()

@@ -30,3 +30,12 @@ def gen(kind: str, seed: int, shape) -> np.ndarray:
 
 def sha(x: np.ndarray) -> str:
     return hashlib.sha256(np.ascontiguousarray(x).tobytes()).hexdigest()
+
+
+def m1_tensor() -> np.ndarray:
+    """SURVEY §8(d) M1 / BASELINE configs[1]: one 4096x4096 bf16 tensor drawn from torch's CPU generator, as float32 values
+    (tests/golden/make_golden.py::m1_tensor must stay identical)."""
+    import torch
+
+    g = torch.Generator().manual_seed(0)
+    return (torch.randn(4096, 4096, generator=g) * 0.02).to(torch.bfloat16).float().numpy()
