@@ -73,27 +73,7 @@ def gather_summary(rows: torch.Tensor, seconds: float, dist, rank: int, world: i
     return (torch.cat(gathered).cpu().numpy() if rank == 0 else None), float(t_max.item())
 
 
-def cpu_budget() -> int:
-    """Hardware threads this process may really use: the cgroup CPU quota when there is one (a gpurun box shows 256
-    hardware threads but runs under a 16-CPU quota; exceeding a CFS quota stalls every thread of the job for the rest of
-    the 100 ms period), else the affinity mask."""
-    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    try:
-        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
-        if quota != "max":
-            n = min(n, max(1, int(quota) // int(period)))
-    except (OSError, ValueError):
-        pass
-    return n
-
-
-def default_workers() -> int:
-    """Scan threads per rank: the rank's share of the CPU budget (the driver's own threads mostly sleep), at most 32;
-    MTQ_SCAN_WORKERS overrides."""
-    if "MTQ_SCAN_WORKERS" in os.environ:
-        return int(os.environ["MTQ_SCAN_WORKERS"])
-    local = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")))
-    return max(4, min(32, cpu_budget() // max(local, 1)))
+from quantization_analysis_amd.pipeline import cpu_budget, default_workers  # noqa: E402  (no GPU call at import)
 
 
 def self_launch(n: int, argv: list[str]) -> int:

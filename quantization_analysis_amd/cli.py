@@ -47,6 +47,10 @@ def parse_args(argv=None) -> argparse.Namespace:
     parser.add_argument("--summary", action="store_true", help="Print the aggregate summary (default: off).")
     parser.add_argument("--results-dir", default="results", help="Root of the result artifacts (default: results).")
     parser.add_argument("--no-plots", action="store_true", help="Skip the PNG artifacts (maps, size-vs-accuracy, random samples).")
+    parser.add_argument("--literal-metrics", action="store_true",
+                        help="hip backend: materialise y (K2/K3), copy it to the host and print the reference's float32 PCC/MAE/ATOL "
+                             "expression (metrics.py:6-16, wq:683-687) instead of the float64-moment columns of the K1 records.")
+    parser.add_argument("--no-stream", action="store_true", help="hip backend: evaluate tensor by tensor instead of in streamed groups.")
     return parser.parse_args(argv)
 
 
@@ -181,6 +185,16 @@ def _none_rows_hip(x, formats, quantizer):
     return out
 
 
+def _none_rows_literal(x, formats, quantizer):
+    """--literal-metrics: every pure format's y through K2, to the host, into the reference's float32 expression (wq:683-687)."""
+    xh = x.float().cpu().numpy()
+    out = {}
+    for f in formats:
+        y = quantizer.quantize(x, f)
+        out[f] = _columns_emulation(xh, y.cpu().numpy() if hasattr(y, "cpu") else np.asarray(y, dtype=np.float32))
+    return out
+
+
 def _evaluate_tensor(idx, name, index, algorithms, formats, quantizer, args, run_tag, processed_root, results_dir):
     """One tensor through [none, selected] → list of summary rows (np.float64 [R, ROW_W])."""
     hip = args.backend == "hip"
@@ -200,7 +214,7 @@ def _evaluate_tensor(idx, name, index, algorithms, formats, quantizer, args, run
     for ci, algo in enumerate(algorithms):
         t0 = time.perf_counter()
         if hip and algo.name == "none":
-            cols = _none_rows_hip(x, formats, quantizer)
+            cols = _none_rows_literal(x, formats, quantizer) if args.literal_metrics else _none_rows_hip(x, formats, quantizer)
             elapsed = time.perf_counter() - t0
             for f in formats:
                 pcc, mae, atol = cols[f]
@@ -214,7 +228,7 @@ def _evaluate_tensor(idx, name, index, algorithms, formats, quantizer, args, run
             torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0  # wall time of run(), wq:680-682
         for res in results:
-            if hip and res.meta and "columns" in res.meta:
+            if hip and res.meta and "columns" in res.meta and not (args.literal_metrics and res.y is not None):
                 c = res.meta["columns"]
                 pcc, mae, atol = c["pcc"], c["mae"], c["atol"]
             else:
@@ -297,12 +311,78 @@ def _print_tables(names, rows, comp_names, shapes, table_lines, summary: bool, f
                 emit(f"  {comp.ljust(comp_w)} {f:>5}  pcc={pcc: .5f}  mae={mae:.3e}  atol={atol:.3e}{btxt}")
 
 
+HIP_COLUMNS_NOTE = ("# columns (--backend hip): PCC / MAE / ATOL from float64 moments of the K1 tile records; the reference prints a float32 "
+                    "BLAS Pearson that is itself off by up to 1e-4 at 4096x4096 (use --literal-metrics for that expression)")
+HIP_LITERAL_NOTE = "# columns (--backend hip --literal-metrics): the reference's float32 expression (metrics.py:6-16) on y from K2 / K3"
+
+
+class _JobError(Exception):
+    """An error every rank reports through the job's status exchange instead of leaving its peers in a collective."""
+
+
+def _any_rank_failed(dist, failed: bool, device) -> bool:
+    """MAX over ranks of a failure flag: every rank reaches every collective of the job whether or not its own work failed."""
+    if dist is None:
+        return failed
+    import torch
+
+    flag = torch.tensor([1 if failed else 0], dtype=torch.int32, device=device)
+    dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+    return bool(flag.item())
+
+
+def _evaluate_shard(shard, tensor_names, index, algorithms, selected_algo, formats, quantizer, args, run_tag, processed_root, results_dir, rank):
+    """This rank's tensors → (summary rows [R, ROW_W], note lines).  hip + a search algorithm: streamed groups (streamed.py)."""
+    from . import streamed
+
+    if os.environ.get("MTQ_FAULT_INJECT") == f"rank:{rank}":   # test hook: this rank's share fails (tests/test_cli.py)
+        raise RuntimeError(f"injected fault on rank {rank}")
+    notes = []
+    per_tensor = list(shard)
+    rows_by_idx = {}
+    deferred = []   # (idx, name, assignment): artifacts written after the GPU work
+    if not args.no_stream and streamed.streamable(selected_algo, formats, args):
+        import torch
+
+        device = torch.device("cuda", torch.cuda.current_device())
+        groups: dict = {}
+        per_tensor = []
+        for i in shard:
+            k = streamed.group_key(index, tensor_names[i])
+            if k is None:
+                per_tensor.append(i)
+            else:
+                groups.setdefault(k, []).append((i, tensor_names[i]))
+        ev = streamed.ShardEvaluator(index, selected_algo, formats, device, ROW_W, FORMAT_BYTES_PER_ELEM)
+        try:
+            for k, items in groups.items():
+                for idx, (rows, assignment) in ev.run_group(k, items).items():
+                    rows_by_idx[idx] = rows
+                    deferred.append((idx, tensor_names[idx], assignment))
+        finally:
+            ev.close()
+        if ev.compute_tiles:
+            k1 = f", K1 {ev.k1_tiles / max(ev.k1_ms, 1e-9) / 1e3:.1f} M tiles/s" if ev.k1_ms else ""
+            notes.append(f"[rank {rank}] streamed {len(deferred)} tensors in {len(groups)} shape groups: {ev.compute_tiles} tiles in {ev.compute_seconds:.3f} s "
+                         f"of GPU pipeline = {ev.compute_tiles / max(ev.compute_seconds, 1e-9) / 1e6:.1f} M tiles/s (loader and artifacts excluded{k1})")
+    for i in per_tensor:
+        rows_by_idx[i] = _evaluate_tensor(i, tensor_names[i], index, algorithms, formats, quantizer, args, run_tag, processed_root, results_dir)
+    algo_dir = selected_algo.name.replace("-", "_")
+    for idx, name, assignment in deferred:   # wq:696-750, after the GPU work
+        write_assignment_outputs(results_dir, name, assignment, algo_dir, not args.no_plots)
+        if not args.no_plots:
+            write_size_plot(results_dir, name, selected_algo.params.get("metric", "pcc"), rows_by_idx[idx], formats, selected_algo.name)
+    ordered = [rows_by_idx[i] for i in sorted(rows_by_idx)]
+    return (np.concatenate(ordered) if ordered else np.zeros((0, ROW_W))), notes
+
+
 def run(argv=None) -> int:
     args = parse_args(argv)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
+    coll_dev = None
     if args.backend == "hip":
         import torch
 
@@ -316,15 +396,30 @@ def run(argv=None) -> int:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.backend == "hip":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))  # RCCL
+        if args.backend == "hip" and torch.cuda.is_available():
+            coll_dev = torch.device("cuda", local_rank)
+            dist.init_process_group("nccl", device_id=coll_dev)  # RCCL
         else:
+            coll_dev = torch.device("cpu")
             dist.init_process_group("gloo")
 
+    # Every rank runs the same sequence of collectives — status, broadcast, status, gather, barrier — whatever happens to its
+    # own work: a failure is carried through the status exchanges and the whole job exits non-zero together.
     try:
-        config = load_compression_config(args.compression_config)
-        algo_params = dict(config.params)
-        used_seed, seed_source = resolve_seed(config, algo_params)
+        err = None
+        config = algo_params = used_seed = seed_source = None
+        try:
+            config = load_compression_config(args.compression_config)
+            algo_params = dict(config.params)
+            used_seed, seed_source = resolve_seed(config, algo_params)
+        except Exception as exc:  # noqa: BLE001
+            err = exc
+        if _any_rank_failed(dist, err is not None, coll_dev):
+            if err is not None:
+                if dist is None:
+                    raise err
+                print(f"error [rank {rank}]: {err}", file=sys.stderr)
+            return 1
         run_tag = datetime.now().strftime("%Y%m%d-%H%M%S")
         if dist is not None:  # one seed and one run tag for the whole job (rank 0 decides)
             box = [used_seed, seed_source, run_tag]
@@ -333,70 +428,87 @@ def run(argv=None) -> int:
             if used_seed is not None:
                 algo_params["seed"] = used_seed
 
-        selected_algo = create_algorithm(config.algorithm, algo_params)
-        baseline = create_algorithm("none", {})
-        algorithms = [baseline] if selected_algo.name == "none" else [baseline, selected_algo]
-        filter_query = " ".join(args.filter_query).strip() or None
-        formats = resolve_format_list(config.quantization_formats, SUPPORTED_FORMATS)
-
-        index = build_model_index(args.repo_or_url, revision=args.revision)
+        mine = np.zeros((0, ROW_W))
+        notes: list[str] = []
+        ctx = {}
         try:
-            tensor_names = resolve_selected_tensors(index, filter_query)
-        except RuntimeError:
-            tensor_names = []
-        if args.limit is not None:
-            tensor_names = tensor_names[: max(0, args.limit)]
-        if not tensor_names:
-            print("No tensors matched.", file=sys.stderr)
+            selected_algo = create_algorithm(config.algorithm, algo_params)
+            baseline = create_algorithm("none", {})
+            algorithms = [baseline] if selected_algo.name == "none" else [baseline, selected_algo]
+            filter_query = " ".join(args.filter_query).strip() or None
+            formats = resolve_format_list(config.quantization_formats, SUPPORTED_FORMATS)
+
+            index = build_model_index(args.repo_or_url, revision=args.revision)
+            try:
+                tensor_names = resolve_selected_tensors(index, filter_query)
+            except RuntimeError:
+                tensor_names = []
+            if args.limit is not None:
+                tensor_names = tensor_names[: max(0, args.limit)]
+            if not tensor_names:
+                raise _JobError("No tensors matched.")
+            try:
+                quantizer = Quantizer(backend=args.backend)
+                if args.backend == "ttnn":
+                    raise RuntimeError("TTNN backend requires `ttnn` in the active Python environment.")  # wq:603-609
+            except Exception as exc:  # noqa: BLE001
+                raise _JobError(f"error: {exc}") from exc
+
+            comp_names = [a.name for a in algorithms]
+            if rank == 0:
+                print(f"{index.repo_id} @{index.revision} - {len(tensor_names)} tensors")
+                print(f"formats: {', '.join(formats)}")
+                print(f"compression: {', '.join(comp_names)}")
+                print(f"backend: {args.backend}" + (f"  ranks: {world}" if world > 1 else ""))
+                if args.compression_config:
+                    print(f"config: {args.compression_config}")
+                print()
+
+            results_dir = Path(args.results_dir) / index.repo_id.replace("/", "__") / selected_algo.name / run_tag  # wq:629-631
+            results_dir.mkdir(parents=True, exist_ok=True)
+            if rank == 0:
+                used_params = dict(algo_params)
+                if used_seed is not None:
+                    used_params.pop("seed", None)
+                used_config = {"algorithm": config.algorithm, "quantization_formats": formats, "params": used_params}
+                if used_seed is not None:
+                    used_config["seed"] = used_seed
+                    if seed_source:
+                        used_config["seed_source"] = seed_source
+                with (results_dir / "compression_config.used.json").open("w", encoding="utf-8") as f:  # wq:636-647
+                    json.dump(used_config, f, indent=2)
+            processed_root = Path("data/processed") / safe_repo_revision_key(index.repo_id, index.revision)
+
+            shards = lpt_shards(tensor_names, index.numel, world)
+            per_tensor_rows = len(formats) + (0 if selected_algo.name == "none" else 1)
+            ctx = {"shards": shards, "per_tensor_rows": per_tensor_rows, "tensor_names": tensor_names, "index": index, "comp_names": comp_names,
+                   "formats": formats, "results_dir": results_dir}
+            mine, notes = _evaluate_shard(shards[rank], tensor_names, index, algorithms, selected_algo, formats, quantizer, args, run_tag,
+                                          processed_root, results_dir, rank)
+        except _JobError as exc:
+            err = exc
+            print(str(exc), file=sys.stderr)
+        except Exception as exc:  # noqa: BLE001
+            err = exc
+            if dist is None:
+                raise
+            import traceback
+
+            print(f"error [rank {rank}]: {exc}", file=sys.stderr)
+            traceback.print_exc()
+        if _any_rank_failed(dist, err is not None, coll_dev):
             return 1
-        try:
-            quantizer = Quantizer(backend=args.backend)
-            if args.backend == "ttnn":
-                raise RuntimeError("TTNN backend requires `ttnn` in the active Python environment.")  # wq:603-609
-        except Exception as exc:
-            print(f"error: {exc}", file=sys.stderr)
-            return 1
+        for line in notes:
+            print(line)
 
-        comp_names = [a.name for a in algorithms]
-        if rank == 0:
-            print(f"{index.repo_id} @{index.revision} - {len(tensor_names)} tensors")
-            print(f"formats: {', '.join(formats)}")
-            print(f"compression: {', '.join(comp_names)}")
-            print(f"backend: {args.backend}" + (f"  ranks: {world}" if world > 1 else ""))
-            if args.compression_config:
-                print(f"config: {args.compression_config}")
-            print()
-
-        results_dir = Path(args.results_dir) / index.repo_id.replace("/", "__") / selected_algo.name / run_tag  # wq:629-631
-        results_dir.mkdir(parents=True, exist_ok=True)
-        if rank == 0:
-            used_params = dict(algo_params)
-            if used_seed is not None:
-                used_params.pop("seed", None)
-            used_config = {"algorithm": config.algorithm, "quantization_formats": formats, "params": used_params}
-            if used_seed is not None:
-                used_config["seed"] = used_seed
-                if seed_source:
-                    used_config["seed_source"] = seed_source
-            with (results_dir / "compression_config.used.json").open("w", encoding="utf-8") as f:  # wq:636-647
-                json.dump(used_config, f, indent=2)
-        processed_root = Path("data/processed") / safe_repo_revision_key(index.repo_id, index.revision)
-
-        shards = lpt_shards(tensor_names, index.numel, world)
-        per_tensor_rows = len(formats) + (0 if selected_algo.name == "none" else 1)
-        my_rows = [
-            _evaluate_tensor(i, tensor_names[i], index, algorithms, formats, quantizer, args, run_tag, processed_root, results_dir)
-            for i in shards[rank]
-        ]
-        mine = np.concatenate(my_rows) if my_rows else np.zeros((0, ROW_W))
-
+        shards, per_tensor_rows, tensor_names, index = ctx["shards"], ctx["per_tensor_rows"], ctx["tensor_names"], ctx["index"]
+        comp_names, formats, results_dir = ctx["comp_names"], ctx["formats"], ctx["results_dir"]
         if dist is not None:  # the ONE data-path collective: fixed-width summary rows → rank 0
             import torch
 
             cap = max(len(s) for s in shards) * per_tensor_rows
-            dev = torch.device("cuda", local_rank) if args.backend == "hip" else torch.device("cpu")
-            buf = torch.full((cap, ROW_W), float("nan"), dtype=torch.float64, device=dev)
-            buf[: mine.shape[0]] = torch.from_numpy(mine).to(dev)
+            buf = torch.full((cap, ROW_W), float("nan"), dtype=torch.float64, device=coll_dev)
+            buf[: mine.shape[0]] = torch.from_numpy(mine).to(coll_dev)
             gathered = [torch.empty_like(buf) for _ in range(world)] if rank == 0 else None
             dist.gather(buf, gathered, dst=0)
             if rank == 0:
@@ -412,6 +524,10 @@ def run(argv=None) -> int:
             for i, n in enumerate(tensor_names):
                 shapes[i] = tuple(index.specs[n].shape) if n in index.specs else "?"
             table_lines: list[str] = []
+            if args.backend == "hip":   # which definition the float columns use (the reference's table has no such line)
+                note = HIP_LITERAL_NOTE if args.literal_metrics else HIP_COLUMNS_NOTE
+                print(note)
+                table_lines.append(note)
             _print_tables(tensor_names, allr, comp_names, shapes, table_lines, args.summary, formats)
             (results_dir / "table.txt").write_text("\n".join(table_lines) + "\n", encoding="utf-8")  # wq:881-882
             print(f"results: {results_dir}")

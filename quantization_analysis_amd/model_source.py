@@ -104,6 +104,16 @@ class ModelIndex:
         with safe_open(self.files[name], framework="pt") as f:
             return int(np.prod(f.get_slice(name).get_shape()))
 
+    def shape_dtype(self, name: str) -> tuple:
+        """(shape, "bf16" | "f32") of what load() returns, without loading (safetensors: from the header)."""
+        if name in self.specs:
+            return tuple(self.specs[name].shape), self.specs[name].dtype
+        from safetensors import safe_open
+
+        with safe_open(self.files[name], framework="pt") as f:
+            sl = f.get_slice(name)
+            return tuple(sl.get_shape()), ("bf16" if str(sl.get_dtype()).upper() in ("BF16", "BFLOAT16") and f"{name}_scale_inv" not in self.files else "f32")
+
     def load(self, name: str, device=None):
         """→ torch tensor (bf16 kept as bf16, everything else float32) on `device` (None = host)."""
         import torch

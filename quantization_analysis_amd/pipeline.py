@@ -29,6 +29,7 @@ class TensorResult:
     mae: float
     atol: float
     metric_value: float
+    pure: dict | None = None    # format name → (pcc, mae, atol) of the whole tensor in that one format (the `none` rows of wq), on request
 
 
 @dataclass
@@ -45,6 +46,29 @@ class KernelTiming:
             self.tiles += tiles
             self.launches += 1
         self.events.clear()
+
+
+def cpu_budget() -> int:
+    """Hardware threads this process may really use: the cgroup CPU quota when there is one (a gpurun box shows 256
+    hardware threads but runs under a 16-CPU quota; exceeding a CFS quota stalls every thread of the job for the rest of
+    the 100 ms period), else the affinity mask."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(quota) // int(period)))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+def default_workers() -> int:
+    """Scan threads per rank: the rank's share of the CPU budget (the driver's own threads mostly sleep), at most 32;
+    MTQ_SCAN_WORKERS overrides."""
+    if "MTQ_SCAN_WORKERS" in os.environ:
+        return int(os.environ["MTQ_SCAN_WORKERS"])
+    local = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")))
+    return max(4, min(32, cpu_budget() // max(local, 1)))
 
 
 def _scan_chunk(first, stats, mask, tiles_hw, numel, tile_formats, metric, threshold, seeds, n_threads) -> list[TensorResult]:
@@ -95,13 +119,15 @@ class GreedyPipeline:
     SLOTS = 3   # record slots = batches in flight: one on the GPU, one queued behind it, one being scanned (see run_steps)
 
     def __init__(self, tile_formats=None, metric: str = "pcc", threshold: float = 0.999, seed: int = 123,
-                 chunk: int = 8, workers: int = 8):
+                 chunk: int = 8, workers: int = 8, pure_formats=()):
         import torch
 
         hb.require_gpu()
         self.torch = torch
         self.tile_formats = list(tile_formats or MIXED_TILE_FORMATS)
         self.mask = hb.fmt_mask(self.tile_formats)
+        # whole-tensor columns of these formats on their own (wq's `none` rows) come out of the same records: no second K1 pass
+        self.pure_formats = [f for f in pure_formats if f in self.tile_formats]
         self.metric, self.threshold, self.seed = metric, float(threshold), int(seed)
         if self.seed == 0:
             raise ValueError("seed 0 means 'draw a random seed' in the reference; pass a non-zero seed")
@@ -184,7 +210,7 @@ class GreedyPipeline:
         hb.greedy_run_batch(np.zeros((self.workers, 1, hb.record_doubles(0xF))), 0xF, ["bf16"], self.metric, self.threshold, 1024.0,
                             [1] * self.workers, self.workers)
 
-    def enqueue(self, x3d, seeds=None) -> dict:
+    def enqueue(self, x3d, seeds=None, numel: int | None = None) -> dict:
         """GPU half of a batch, non-blocking: per chunk K1 on the launch stream (plus the slim copy of its records) and the
         records' D2H on the copy stream.  At most SLOTS batches may be enqueued and not yet finished."""
         torch = self.torch
@@ -235,7 +261,7 @@ class GreedyPipeline:
                     done = torch.cuda.Event(blocking=True)   # the driver thread sleeps while it waits: spinning would burn a core of the scan budget
                     done.record(self.copy_stream)
                 pending.append((done, first, n))
-        enq = {"host_np": host_np, "host_mask": host_mask, "tiles_hw": (th, tw), "numel": rows * cols,
+        enq = {"host_np": host_np, "host_mask": host_mask, "tiles_hw": (th, tw), "numel": rows * cols if numel is None else int(numel),
                "seeds": seeds, "x": x3d, "dev": dev, "k1_mask": k1_mask, "slim": slim, "chain": chain,
                "base_np": base_np if chain else None}
         # The scans are handed to the chunk-task pool HERE, each behind its records' event: they start the moment the records land,
@@ -279,7 +305,7 @@ class GreedyPipeline:
                 results.extend(_scan_chunk(*self._scan_args(enq, first, n, full, enq["host_mask"] & ~hb.MASK_SLIM)))
         self._open.pop(0)
         enq["x"] = None
-        if enq["slim"]:
+        if enq["slim"] or self.pure_formats:
             self._launch_columns(enq, results)
             if not defer_columns:
                 self.resolve(enq)
@@ -297,8 +323,10 @@ class GreedyPipeline:
             self._colbufs = {"key": key, "ring": [
                 {"maps_host": torch.empty((count, tiles), dtype=torch.int8, pin_memory=True),
                  "maps_dev": torch.empty((count, tiles), dtype=torch.int8, device=dev.device),
-                 "scratch": torch.empty((count, n_scratch), dtype=torch.float64, device=dev.device),
-                 "sums_host": torch.empty((count, 7), dtype=torch.float64, pin_memory=True)} for _ in range(self.SLOTS)], "next": 0}
+                 "scratch": torch.empty((1 + len(self.pure_formats), count, n_scratch), dtype=torch.float64, device=dev.device),
+                 "sums_host": torch.empty((1 + len(self.pure_formats), count, 7), dtype=torch.float64, pin_memory=True)} for _ in range(self.SLOTS)],
+                "pure_maps": [torch.full((count, tiles), MIXED_TILE_FORMATS.index(f), dtype=torch.int8, device=dev.device) for f in self.pure_formats],
+                "next": 0}
         cb = self._colbufs["ring"][self._colbufs["next"]]
         self._colbufs["next"] = (self._colbufs["next"] + 1) % self.SLOTS
         user = cb.get("user")                            # the batch SLOTS back read its sums out of this ring entry
@@ -318,13 +346,18 @@ class GreedyPipeline:
             maps_up = torch.cuda.Event()
             maps_up.record(self.col_stream)
         self.stream.wait_event(maps_up)
-        hb.check(hb.lib().mtq_column_sums_device_batched(dev.data_ptr(), count, tiles, enq["host_mask"] & ~hb.MASK_SLIM, cb["maps_dev"].data_ptr(),
-                                                         cb["scratch"].data_ptr(), self.stream.cuda_stream))
+        dec_mask = enq["host_mask"] & ~hb.MASK_SLIM
+        if enq["slim"]:   # the searched maps' columns (other metrics: the host scan already produced them)
+            hb.check(hb.lib().mtq_column_sums_device_batched(dev.data_ptr(), count, tiles, dec_mask, cb["maps_dev"].data_ptr(),
+                                                             cb["scratch"][0].data_ptr(), self.stream.cuda_stream))
+        for k, pm in enumerate(self._colbufs["pure_maps"]):   # one constant map per pure format
+            hb.check(hb.lib().mtq_column_sums_device_batched(dev.data_ptr(), count, tiles, dec_mask, pm.data_ptr(), cb["scratch"][1 + k].data_ptr(),
+                                                             self.stream.cuda_stream))
         summed = torch.cuda.Event()
         summed.record(self.stream)
         with torch.cuda.stream(self.col_stream):
             self.col_stream.wait_event(summed)
-            cb["sums_host"].copy_(cb["scratch"][:, :7], non_blocking=True)
+            cb["sums_host"].copy_(cb["scratch"][:, :, :7], non_blocking=True)
             done = torch.cuda.Event(blocking=True)
             done.record(self.col_stream)
         enq["col_pending"] = (done, cb["sums_host"], results)
@@ -336,16 +369,25 @@ class GreedyPipeline:
             return
         done, sums_host, results = pend
         done.synchronize()
-        cols = columns_from_sums_batch(sums_host.numpy(), float(enq["numel"]))
-        k = {"pcc": 0, "mae": 1, "atol": 2}[self.metric]
-        for r, c in zip(results, cols):
-            r.pcc, r.mae, r.atol, r.metric_value = float(c[0]), float(c[1]), float(c[2]), float(c[k])
+        sums = sums_host.numpy()
+        if enq["slim"]:
+            cols = columns_from_sums_batch(sums[0], float(enq["numel"]))
+            k = {"pcc": 0, "mae": 1, "atol": 2}[self.metric]
+            for r, c in zip(results, cols):
+                r.pcc, r.mae, r.atol, r.metric_value = float(c[0]), float(c[1]), float(c[2]), float(c[k])
+        for j, f in enumerate(self.pure_formats):
+            cols = columns_from_sums_batch(sums[1 + j], float(enq["numel"]))
+            for r, c in zip(results, cols):
+                if r.pure is None:
+                    r.pure = {}
+                r.pure[f] = (float(c[0]), float(c[1]), float(c[2]))
         enq["dev"] = None
 
-    def run(self, x3d, seeds=None) -> list[TensorResult]:
-        """One batch, start to end (enqueue + finish)."""
+    def run(self, x3d, seeds=None, numel: int | None = None) -> list[TensorResult]:
+        """One batch, start to end (enqueue + finish).  numel: the tensors' element count when the matrices are zero-filled
+        2-D images of shorter vectors (tile_utils.py:96-102); the greedy metric divides by it (mixed_tile_greedy.py:134)."""
         torch = self.torch
-        results = self.finish(self.enqueue(x3d, seeds))
+        results = self.finish(self.enqueue(x3d, seeds, numel))
         torch.cuda.current_stream().wait_stream(self.stream)
         torch.cuda.current_stream().wait_stream(self.copy_stream)
         return results
@@ -385,7 +427,7 @@ class ThresholdPipeline:
     compression_algorithms.mixed_tile_threshold does for one tensor) → patched maps back up → column sums on the device.
     There is no host scan: the GPU is the pacing resource."""
 
-    def __init__(self, tile_formats=None, metric: str = "pcc", threshold: float = 0.999, chunk: int = 16, band: float = 2e-6):
+    def __init__(self, tile_formats=None, metric: str = "pcc", threshold: float = 0.999, chunk: int = 16, band: float = 2e-6, pure_formats=()):
         import torch
 
         from .compression_algorithms.quantizer import Quantizer
@@ -393,6 +435,7 @@ class ThresholdPipeline:
         hb.require_gpu()
         self.torch = torch
         self.tile_formats = list(tile_formats or MIXED_TILE_FORMATS)
+        self.pure_formats = [f for f in pure_formats if f in self.tile_formats]
         self.mask = hb.fmt_mask(self.tile_formats)
         self.metric, self.threshold, self.band = metric, float(threshold), float(band)
         self.chunk = int(chunk)
@@ -426,11 +469,11 @@ class ThresholdPipeline:
 
         maps[jj, tt] = decide_knife_tiles(maps[jj, tt], near[jj, tt].astype(np.uint8), self.tile_formats, self.metric, self.threshold, literal_scores)
 
-    def run(self, x3d) -> list[TensorResult]:
+    def run(self, x3d, numel: int | None = None) -> list[TensorResult]:
         torch = self.torch
         count, rows, cols = x3d.shape
         th, tw = hb.tiles_hw(rows, cols)
-        tiles, numel = th * tw, rows * cols
+        tiles, numel = th * tw, (rows * cols if numel is None else int(numel))
         identity = x3d.dtype == torch.bfloat16 and (self.mask & 1) and (self.mask & 0xE)
         k1_mask = self.mask & 0xE if identity else self.mask
         dec_mask = k1_mask | hb.MASK_BF16_IDENTITY if identity else self.mask
@@ -454,15 +497,21 @@ class ThresholdPipeline:
                 self._rescore_chunk(x3d[first:first + n], maps, near, jj, tt, tw)
                 self.knife_tiles += int(jj.size)
             dmaps = (torch.from_numpy(maps).to(x3d.device) if dirty else both[0].view(n, tiles)).contiguous()
-            scratch = torch.empty((n, scratch_n), dtype=torch.float64, device=x3d.device)
-            hb.check(hb.lib().mtq_column_sums_device_batched(recs.data_ptr(), n, tiles, dec_mask, dmaps.data_ptr(), scratch.data_ptr(), hb._stream_ptr()))
+            scratch = torch.empty((1 + len(self.pure_formats), n, scratch_n), dtype=torch.float64, device=x3d.device)
+            hb.check(hb.lib().mtq_column_sums_device_batched(recs.data_ptr(), n, tiles, dec_mask, dmaps.data_ptr(), scratch[0].data_ptr(), hb._stream_ptr()))
+            for k, f in enumerate(self.pure_formats):   # wq's `none` rows from the same records
+                pm = torch.full((n, tiles), MIXED_TILE_FORMATS.index(f), dtype=torch.int8, device=x3d.device)
+                hb.check(hb.lib().mtq_column_sums_device_batched(recs.data_ptr(), n, tiles, dec_mask, pm.data_ptr(), scratch[1 + k].data_ptr(), hb._stream_ptr()))
             summed.append((first, n, maps, scratch, (dmaps.unsqueeze(-1) == codes).sum(dim=1)))   # counts ≡ np.bincount per tensor
         k = {"pcc": 0, "mae": 1, "atol": 2}[self.metric]
         for first, n, maps, scratch, counts_dev in summed:                                      # one wait for all chunks' sums
-            cols = columns_from_sums_batch(scratch[:, :7].cpu().numpy(), float(numel))
+            sums = scratch[:, :, :7].cpu().numpy()
+            cols = columns_from_sums_batch(sums[0], float(numel))
+            pure_cols = [columns_from_sums_batch(sums[1 + i], float(numel)) for i in range(len(self.pure_formats))]
             bc = counts_dev.cpu().numpy()
             for j in range(n):
                 counts = {f: int(bc[j, i]) for i, f in enumerate(MIXED_TILE_FORMATS)}
+                pure = {f: tuple(float(v) for v in pure_cols[i][j]) for i, f in enumerate(self.pure_formats)} or None
                 results.append(TensorResult(first + j, maps[j].reshape(th, tw), counts, mixed_tile_total_bytes(counts), float(cols[j, 0]),
-                                            float(cols[j, 1]), float(cols[j, 2]), float(cols[j, k])))
+                                            float(cols[j, 1]), float(cols[j, 2]), float(cols[j, k]), pure))
         return results

@@ -98,9 +98,6 @@ def main(argv=None) -> int:
 
         torch.cuda.set_device(local_rank)
         device = torch.device("cuda", local_rank)
-    base_out = Path(args.out_dir) if args.out_dir else Path("results") / index.repo_id.replace("/", "__") / "mixed_tile_threshold_sweep" / time.strftime("%Y%m%d-%H%M%S")
-    detail = base_out / "details"
-    detail.mkdir(parents=True, exist_ok=True)
     quantizer = Quantizer(args.backend)
     dist = None
     if world > 1:
@@ -108,16 +105,26 @@ def main(argv=None) -> int:
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl" if args.backend == "hip" else "gloo", **({"device_id": device} if device is not None else {}))
+    stamp = [time.strftime("%Y%m%d-%H%M%S")]
+    if dist is not None:   # one output directory for the whole job: rank 0's clock decides (ranks may start across a second boundary)
+        dist.broadcast_object_list(stamp, src=0)
+    base_out = Path(args.out_dir) if args.out_dir else Path("results") / index.repo_id.replace("/", "__") / "mixed_tile_threshold_sweep" / stamp[0]
+    detail = base_out / "details"
+    detail.mkdir(parents=True, exist_ok=True)
     lines = []  # (tensor name, frontier points, baseline points) of this rank's tensors
+    failed = None
     for i in lpt_shards(selected, index.numel, world)[rank]:
         name = selected[i]
-        x = index.load(name, device=device)
-        xf = x if device is not None else x.float().numpy()
         try:
+            if os.environ.get("MTQ_FAULT_INJECT") == f"rank:{rank}":   # test hook: one rank's tensor fails (tests/test_sweep.py)
+                raise RuntimeError(f"injected fault on rank {rank}")
+            x = index.load(name, device=device)
+            xf = x if device is not None else x.float().numpy()
             rows, baselines, _thr = sweep_tensor(xf, formats, args.metric, args.lowest_metric_val, args.steps, quantizer)
-        except ValueError as exc:
-            print(f"error: {exc}")
-            return 1
+        except Exception as exc:  # noqa: BLE001 — the rank still takes part in every collective below, then the job exits non-zero
+            print(f"error: {exc}" if isinstance(exc, ValueError) else f"error [rank {rank}] {name}: {exc}")
+            failed = exc
+            break
         out = detail / name.replace("/", "_").replace(".", "_")
         out.mkdir(parents=True, exist_ok=True)
         (out / "sweep_config.json").write_text(json.dumps({
@@ -133,13 +140,19 @@ def main(argv=None) -> int:
         lines.append((name, front, baselines))
         print(f"[rank {rank}] {name}: {len(rows)} steps, pareto {len(front)} points -> {out}")
 
-    if dist is not None:  # frontiers are a few KB per tensor
+    any_failed = failed is not None
+    if dist is not None:  # frontiers are a few KB per tensor; the failure flag rides along, so every rank makes the same calls
         box = [None] * world if rank == 0 else None
-        dist.gather_object(lines, box, dst=0)
+        dist.gather_object((lines, failed is not None), box, dst=0)
+        verdict = [any(f for _l, f in box)] if rank == 0 else [None]
+        dist.broadcast_object_list(verdict, src=0)
+        any_failed = bool(verdict[0])
         if rank == 0:
-            lines = [entry for part in box for entry in part]
+            lines = [entry for part, _f in box for entry in part]
         dist.barrier()
         dist.destroy_process_group()
+    if any_failed:
+        return 1
     if rank == 0 and not args.no_plots:
         by_weight, by_layer, base_weight, base_layer = {}, {}, {}, {}
         for name, front, baselines in sorted(lines, key=lambda e: e[0]):

@@ -159,6 +159,19 @@ def test_wq_two_ranks_gloo_matches_single_process(tmp_path):
         assert np.array_equal(np.load(d1 / rel), np.load(d2 / rel)), rel
 
 
+def test_wq_two_ranks_one_fails_gloo(tmp_path):
+    """A failure on one rank (MTQ_FAULT_INJECT) must not leave the other in a collective: both exit, the job returns non-zero
+    well inside the collective timeout, and the error names the rank."""
+    cfg = write_cfg(tmp_path, algo="mixed-tile-threshold", seed=None, params={"metric": "pcc", "threshold": 0.99})
+    env = dict(os.environ, PYTHONPATH=str(ROOT), HSA_ENABLE_IPC_MODE_LEGACY="0", MTQ_FAULT_INJECT="rank:1")
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", str(_free_port()), str(ROOT / "wq"), "synthetic:tiny", "--compression-config", cfg,
+                          "--results-dir", str(tmp_path / "r2"), "--no-plots"], cwd=tmp_path, env=env, capture_output=True, text=True, timeout=300)
+    assert two.returncode != 0
+    assert "injected fault on rank 1" in two.stderr and "Timeout" not in two.stderr and "timed out" not in two.stderr.lower()
+    assert not list((tmp_path / "r2").rglob("table.txt"))
+
+
 def test_bench_gather_two_ranks_gloo(tmp_path):
     """bench.py's multi-rank tail (one gather of summary rows + MAX of the timed region) on a world_size-2 gloo job."""
     script = tmp_path / "g.py"

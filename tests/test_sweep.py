@@ -86,6 +86,25 @@ def test_sweep_script_two_ranks_gloo(tmp_path):
     assert "[rank 1]" in two.stdout and "[rank 0]" in two.stdout
 
 
+def test_sweep_script_two_ranks_one_fails_gloo(tmp_path):
+    """One rank's tensor fails (MTQ_FAULT_INJECT): it still takes part in the gather / verdict broadcast / barrier, and every
+    rank exits non-zero instead of the job hanging in a collective."""
+    import os
+    import socket
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    script = str(ROOT / "scripts" / "sweep_mixed_tile_threshold.py")
+    env = dict(os.environ, PYTHONPATH=str(ROOT), HSA_ENABLE_IPC_MODE_LEGACY="0", MTQ_FAULT_INJECT="rank:0")
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", str(port), script, "synthetic:tiny", "layers", "--steps", "4", "--lowest-metric-val", "0.95", "--no-plots",
+                          "--out-dir", str(tmp_path / "two")], capture_output=True, text=True, timeout=300, env=env)
+    assert two.returncode != 0
+    assert "injected fault on rank 0" in two.stdout and "[rank 1]" in two.stdout and "Wrote sweep results" not in two.stdout
+
+
 def test_reconstruct_script(tmp_path):
     from oracle import mtq_oracle as orc
     from quantization_analysis_amd import model_source
