@@ -6,8 +6,9 @@ Step  = one pass of the hot path (K1 tile_stats on the GPU + stats D2H + host gr
         (BASELINE.json configs[1], streamed; the batch is > 256 MiB so the Infinity Cache cannot hold it).
 value = tiles/s, whole job, inputs resident in HBM when the timed region starts.
 roofline = the K1 kernel alone: algorithmic 2048 B read per tile / HIP-event launch duration vs 8 TB/s.
-cpu_baseline = the C oracle (oracle/, a port of the reference's CPU path) on rank 0's host, 1 thread,
-        on a bounded sample of the same tensors.
+cpu_baseline = the C oracle (oracle/, a port of the reference's CPU path) on rank 0's host, 1 thread, on a bounded sample of
+        the same tensors; cpu_baseline_threads = the same port on every core of the rank's CPU quota; cpu_baseline_emulation =
+        the NumPy host backend (how the reference executes) on one tensor.
 
   python bench.py --gpus 1 --steps 5 --warmup 1
   python bench.py --gpus N ...            (N > 1, not under a launcher: starts its own N ranks before any GPU call)
@@ -44,20 +45,63 @@ def make_batch(n: int, rank: int, device) -> torch.Tensor:
     return out
 
 
-def cpu_baseline(sample: torch.Tensor) -> dict:
-    """The CPU port (oracle) timed like wq:680-682 times algo.run: perf_counter around the whole search."""
+def cpu_model() -> str:
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(sample: torch.Tensor, threads: int) -> dict:
+    """Three CPU figures on rank 0's host, each timed like wq:680-682 times algo.run (perf_counter around the whole search):
+      cpu_baseline            the C port (oracle/mtq_oracle.c), 1 thread, `len(sample)` tensors            kind "port"
+      cpu_baseline_threads    the same port, one tensor per thread on `threads` threads (the rank's CPU quota) kind "port"
+      cpu_baseline_emulation  the package's NumPy host backend (`--backend emulation`: how the reference executes — single-threaded
+                              NumPy, quantize per format + per-tile sums + sequential scan, wq:680-682), one tensor  kind "emulation"
+    All three produce the same maps (asserted)."""
+    import concurrent.futures as cf
+
+    import numpy as np
+
     from oracle import mtq_oracle as orc
 
     xs = [sample[i].float().cpu().numpy() for i in range(sample.shape[0])]
     orc.lib()
     t0 = time.perf_counter()
     tiles = 0
+    maps = []
     for x in xs:
         a, _c, _s = orc.greedy(x, FORMATS, METRIC, THRESHOLD, SEED)
         tiles += a.size
+        maps.append(a)
     dt = time.perf_counter() - t0
-    return {"value": tiles / dt, "unit": "tiles/s", "cores": 1, "kind": "port",
-            "sample": f"{len(xs)} of the step's 4096x4096 bf16 tensors, oracle/mtq_oracle.c greedy (1 thread), {dt:.1f} s"}
+    out = {"cpu_baseline": {"value": tiles / dt, "unit": "tiles/s", "cores": 1, "kind": "port", "cpu": cpu_model(),
+                            "sample": f"{len(xs)} of the step's 4096x4096 bf16 tensors, oracle/mtq_oracle.c greedy (1 thread), {dt:.1f} s"}}
+    if threads > 1:
+        reps = max(1, -(-2 * threads // len(xs)))          # at least two tensors per thread
+        work = (xs * reps)[: max(2 * threads, len(xs))]
+        t0 = time.perf_counter()
+        with cf.ThreadPoolExecutor(max_workers=threads) as pool:   # ctypes releases the GIL inside the C port
+            got = list(pool.map(lambda x: orc.greedy(x, FORMATS, METRIC, THRESHOLD, SEED)[0], work))
+        dtt = time.perf_counter() - t0
+        assert all(np.array_equal(g, maps[i % len(xs)]) for i, g in enumerate(got))
+        out["cpu_baseline_threads"] = {"value": sum(g.size for g in got) / dtt, "unit": "tiles/s", "cores": threads, "kind": "port", "cpu": cpu_model(),
+                                       "sample": f"{len(work)} tensor searches (the same {len(xs)} tensors, repeated) over {threads} threads, one tensor per thread, {dtt:.1f} s"}
+    from quantization_analysis_amd.compression_algorithms import create_algorithm
+    from quantization_analysis_amd.compression_algorithms.cache import CacheContext
+    from quantization_analysis_amd.compression_algorithms.quantizer import Quantizer
+
+    algo = create_algorithm("mixed-tile-greedy", {"metric": METRIC, "threshold": THRESHOLD, "seed": SEED})
+    t0 = time.perf_counter()
+    res = algo.run(xs[0], FORMATS, Quantizer("emulation"), CacheContext(ROOT / "gpurun_out" / "bench-cache", "bench", "emulation", True, "bench"))[0]
+    dte = time.perf_counter() - t0
+    assert np.array_equal(res.meta["assignment"], maps[0])
+    out["cpu_baseline_emulation"] = {"value": maps[0].size / dte, "unit": "tiles/s", "cores": 1, "kind": "emulation", "cpu": cpu_model(),
+                                     "sample": f"1 of the step's tensors through `--backend emulation` (NumPy, y materialised as wq does), {dte:.1f} s"}
+    return out
 
 
 def gather_summary(rows: torch.Tensor, seconds: float, dist, rank: int, world: int):
@@ -220,7 +264,7 @@ def main() -> None:
                         "counts_bf16_bfp8_bfp4_bfp2": [int(all_rows[:, 6 + i].sum()) for i in range(4)]},
         }
         if args.cpu_sample > 0:
-            out["cpu_baseline"] = cpu_baseline(batch[: min(args.cpu_sample, args.tensors)])
+            out.update(cpu_baseline(batch[: min(args.cpu_sample, args.tensors)], cpu_budget()))
         print(json.dumps(out), flush=True)
     pipe.close()
     if dist is not None:
