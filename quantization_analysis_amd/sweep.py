@@ -16,7 +16,7 @@ from .compression_algorithms.tile_search import columns_from_stats, compute_tile
 from .compression_algorithms.tile_utils import MIXED_TILE_BYTES_PER_ELEM, MIXED_TILE_FORMATS, mixed_tile_total_bytes, tile_metrics
 
 
-MAX_LITERAL_START_TILES = 2048
+LITERAL_CHUNK_TILES = 16384   # tiles per literal re-scoring chunk (64 MiB of float32 tiles on the host)
 
 
 def compute_assignment(scores_stack: np.ndarray, metric: str, threshold: float) -> np.ndarray:
@@ -72,17 +72,19 @@ def sweep_tensor(xf, formats: list[str], metric: str, lowest_metric_val: float, 
         if lowest_metric_val < start:
             raise ValueError("lowest-metric-val must be >= start metric for mae/atol")
     # the start of the sweep is itself a float32 tile score of the reference: take the literal one for the extreme tile
+    literal_hi = np.zeros(s64.shape[1], dtype=bool)   # tiles of the highest-precision format that already carry their literal score
     if metric != "atol":
         t_ext = int(np.argmax(s32[hi]) if metric == "pcc" else np.argmin(s32[hi]))
         cand = np.unique(np.concatenate([[t_ext], np.where(np.abs(s64[hi] - s64[hi][t_ext]) <= knife_width(s64[hi][t_ext]))[0]]))
-        if cand.size > MAX_LITERAL_START_TILES:
-            # identity-like formats (bf16 of bf16 data): every tile is a candidate and the literal float32 scores are
-            # 1 ± 1 ulp; the maximum over a few thousand of them is the maximum over all (each tile rounds up with
-            # probability ~1/3), so a bounded sample pins the reference's start value without pulling the tensor to the host
-            cand = cand[:: max(1, cand.size // MAX_LITERAL_START_TILES)][:MAX_LITERAL_START_TILES]
-        xt = gather_tiles(ts, cand)
-        lit = tile_metrics(xt, np.asarray(_quantize_tiles(xt, highest, quantizer), dtype=np.float32), metric)
-        s32[hi, cand] = lit
+        # identity-like formats (bf16 of bf16 data, bf16 of fp8-block data) put EVERY tile inside the band: the literal float32 scores
+        # are 1 ± a few ulp and the reference's start value is their exact maximum (a 2-ulp outlier among 10^5 tiles decides it, so a
+        # sample is not enough: golden-size check tests/test_configs_gpu.py::test_config4_sweep_deepseek_layer0) — all of them are scored,
+        # in bounded chunks (4 KB per tile through the host)
+        for c0 in range(0, cand.size, LITERAL_CHUNK_TILES):
+            part = cand[c0:c0 + LITERAL_CHUNK_TILES]
+            xt = gather_tiles(ts, part)
+            s32[hi, part] = tile_metrics(xt, np.asarray(_quantize_tiles(xt, highest, quantizer), dtype=np.float32), metric)
+        literal_hi[cand] = True
         start = float(np.max(s32[hi])) if metric == "pcc" else float(np.min(s32[hi]))
     thresholds = np.linspace(start, lowest_metric_val, max(1, steps))
 
@@ -96,10 +98,13 @@ def sweep_tensor(xf, formats: list[str], metric: str, lowest_metric_val: float, 
             for off in (-1, 0):
                 idx = np.clip(pos + off, 0, srt.size - 1)
                 near |= np.abs(s64[fi] - srt[idx]) <= knife_width(srt[idx])
+            if fi == hi:
+                near &= ~literal_hi
             ids = np.where(near)[0]
-            if ids.size:
-                xt = gather_tiles(ts, ids)
-                s32[fi, ids] = tile_metrics(xt, np.asarray(_quantize_tiles(xt, f, quantizer), dtype=np.float32), metric)
+            for c0 in range(0, ids.size, LITERAL_CHUNK_TILES):
+                part = ids[c0:c0 + LITERAL_CHUNK_TILES]
+                xt = gather_tiles(ts, part)
+                s32[fi, part] = tile_metrics(xt, np.asarray(_quantize_tiles(xt, f, quantizer), dtype=np.float32), metric)
 
     baselines = []
     for f in formats:                                                                 # :688-715

@@ -246,6 +246,6 @@ def test_literal_metrics_equal_reference_expression(tmp_path, monkeypatch):
     assert cli.run(["synthetic:tiny", "--compression-config", cfg, "--backend", "emulation", "--results-dir", str(tmp_path / "emu"), "--no-plots"]) == 0
     lit = (run_dir(tmp_path / "lit") / "table.txt").read_text().splitlines()
     assert lit[0] == cli.HIP_LITERAL_NOTE
-    assert strip_time("\n".join(lit[1:])) == strip_time((run_dir(tmp_path / "emu") / "table.txt").read_text())
+    assert strip_time("\n".join(lit[1:]) + "\n") == strip_time((run_dir(tmp_path / "emu") / "table.txt").read_text())
     assert cli.run(["synthetic:tiny", "--compression-config", cfg, "--backend", "hip", "--results-dir", str(tmp_path / "mom"), "--no-plots"]) == 0
     assert (run_dir(tmp_path / "mom") / "table.txt").read_text().splitlines()[0] == cli.HIP_COLUMNS_NOTE
