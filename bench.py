@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """bench.py — mixed-tile-greedy (bf16 → BFP{8,4,2}) throughput on MI355X.
 
-Step  = one pass of the hot path (K1 tile_stats on the GPU + stats D2H + host greedy scan → per-tile
-        assignment maps + pcc/mae/atol) over a batch of `--tensors` (128) synthetic 4096x4096 bf16 tensors
+Step  = one pass of the hot path (K1 tile_stats + the sequential greedy scan, both on the GPU by default [--scan host: stats
+        D2H + host scan threads] → per-tile assignment maps + pcc/mae/atol on the host) over a batch of `--tensors` (128) synthetic 4096x4096 bf16 tensors
         (BASELINE.json configs[1], streamed; the batch is > 256 MiB so the Infinity Cache cannot hold it).
 value = tiles/s, whole job, inputs resident in HBM when the timed region starts.
 roofline = the K1 kernel alone: algorithmic 2048 B read per tile / HIP-event launch duration vs 8 TB/s.
@@ -164,9 +164,14 @@ def main() -> None:
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--tensors", type=int, default=128, help="4096x4096 bf16 tensors per step per GPU (128 = 4 GiB, SURVEY §8(d) M1 stream)")
-    ap.add_argument("--chunk", type=int, default=32, help="tensors per K1 launch")
+    ap.add_argument("--chunk", type=int, default=None,
+                    help="tensors per K1 launch (default: the whole step's batch with the scan on the device — one K1 launch and one scan launch per "
+                         "step; 32 with the host scan, where a chunk's records cross PCIe while the next chunk's K1 runs)")
     ap.add_argument("--workers", type=int, default=default_workers(), help="host scan threads per rank (default: this rank's share of the cgroup CPU quota / affinity mask, at most 32)")
     ap.add_argument("--cpu-sample", type=int, default=24, help="tensors timed on the CPU port, ~0.5 s each (0 = skip)")
+    ap.add_argument("--scan", choices=["auto", "host", "device"], default="auto",
+                    help="where the sequential greedy scan runs: device (csrc/mtq_scan.hip, records never leave the GPU), host (records over PCIe, "
+                         "host scan threads), auto = device where it serves the search")
     ap.add_argument("--dry-run", action="store_true", help="rank plumbing only, on the CPU over gloo (tests); prints no measurement")
     args = ap.parse_args()
 
@@ -198,7 +203,10 @@ def main() -> None:
 
     hb.require_gpu()
     batch = make_batch(args.tensors, rank, device)
-    pipe = GreedyPipeline(FORMATS, METRIC, THRESHOLD, SEED, chunk=args.chunk, workers=args.workers)
+    pipe = GreedyPipeline(FORMATS, METRIC, THRESHOLD, SEED, chunk=args.chunk or 32, workers=args.workers, scan=args.scan)
+    if args.chunk is None:
+        args.chunk = args.tensors if pipe.device_scan else 32
+    pipe.chunk = args.chunk
     tiles_per_step = args.tensors * (ROWS // 32) * (COLS // 32)
 
     def barrier():
@@ -219,10 +227,12 @@ def main() -> None:
     gc.collect()
     gc.freeze()
     barrier()
+    cpu0 = time.process_time()
     t0 = time.perf_counter()
     res = pipe.run_steps(batch for _ in range(args.steps))  # every step fully processed; step s+1's GPU work overlaps step s's scan tail
     barrier()
     dt = time.perf_counter() - t0
+    host_cpu_ms = (time.process_time() - cpu0) / args.steps * 1e3   # CPU time of every thread of this rank, per step
     pipe.timing.drain()
 
     # the only data-path collective: per-tensor summary rows to rank 0; outside the timed steps
@@ -254,7 +264,9 @@ def main() -> None:
             "config": {"workload": f"{args.tensors} x 4096x4096 bf16 N(0,0.02^2) per GPU per step, mixed-tile-greedy "
                                    f"{{bf16,bfp8,bfp4,bfp2}} pcc>=0.999 seed 123 (BASELINE.json configs[1], streamed)",
                        "tensors_per_step_per_gpu": args.tensors, "tiles_per_step_per_gpu": tiles_per_step,
-                       "k1_chunk": args.chunk, "scan_workers": args.workers, "numa_bind": numa, "sharding": f"tensors x{world}, RCCL gather of summary rows"},
+                       "k1_chunk": args.chunk, "scan": "device (csrc/mtq_scan.hip)" if pipe.device_scan else f"host ({args.workers} threads)",
+                       "host_cpu_ms_per_step": host_cpu_ms, "host_fallbacks": pipe.host_fallbacks,
+                       "driver_thread_ms_per_step": {k: v / (args.steps + args.warmup) * 1e3 for k, v in pipe.host_seconds.items()}, "scan_workers": args.workers, "numa_bind": numa, "sharding": f"tensors x{world}, RCCL gather of summary rows"},
             "roofline": {"bound": "hbm", "kernel": "tile_stats (K1)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_source": "profiles/k1_traffic.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, B/tile x this run's tiles per launch)" if traffic is not None else None,

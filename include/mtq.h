@@ -267,11 +267,30 @@ int mtq_column_sums_device(const double *stats, int64_t tiles, uint32_t fmt_mask
 int mtq_column_sums_device_batched(const double *stats, int64_t count, int64_t tiles, uint32_t fmt_mask, const int8_t *maps,
                                    double *scratch, void *stream);
 
+/* H1 on the device (csrc/mtq_scan.hip): mtq_greedy_run for `count` equally sized tensors whose FULL records
+ * [count][tiles][2+5F] are where K1 wrote them — replaces mixed_tile_greedy.py:133-346 without moving the records: one wave64
+ * per tensor performs the initial sums, NumPy's Generator.permutation of every pass (SeedSequence → PCG64, bit-compatible)
+ * and the sequential accept / reject scan with the host scan's IEEE operations in the host scan's order, so maps[count][tiles]
+ * (device, int8 codes) are the host's maps.  status[count] (device): 0 = done; 1 = a zero denominator turned up (the decision
+ * needs Σ|x−y|: run mtq_greedy_run on that tensor's records); 2 = internal budget exhausted (same remedy).  Serves the pcc
+ * metric, distinct formats (fmt_mask may carry MTQ_MASK_BF16_IDENTITY), tiles <= MTQ_SCAN_DEVICE_MAX_TILES; anything else
+ * returns MTQ_ERR_UNSUPPORTED and the caller uses the host scan.  seeds[count]: device array of non-zero seeds.  scratch:
+ * device memory of mtq_greedy_scan_scratch_bytes(count, tiles) bytes.  Asynchronous on `stream`. */
+#define MTQ_SCAN_DEVICE_MAX_TILES (1 << 22)
+size_t mtq_greedy_scan_scratch_bytes(int64_t count, int64_t tiles);
+int mtq_greedy_scan_device(const double *stats, int64_t count, int64_t tiles, uint32_t fmt_mask, const int *formats, int n_formats,
+                           int metric, double threshold, double elem_count, const uint64_t *seeds, int8_t *maps, int32_t *status,
+                           void *scratch, size_t scratch_bytes, void *stream);
+
 /* Diagnostics (no reference counterpart).  K1's persistent waves claim their units from device counters that come from a
  * per-device ring of slots (csrc/mtq_slot_ring.hpp): a slot is handed out again only behind the event recorded after its
  * previous launch's reset, so any number of launches may be pending on any streams.  This runs that bookkeeping against
  * mock event operations on the host (no GPU): 0 = every property holds, else the number of the first failed check. */
 int mtq_selftest_slot_ring(void);
+/* Shader-clock ticks the first tensor of the last mtq_greedy_scan_device launch spent per phase (tools/scan_device_bench.py):
+ * [0] start-up + initial sums, [1] base pass + draw-only shuffle, then for pass p = 1..3: [2+3(p-1)] candidates + shuffle,
+ * [3+3(p-1)] deltas, [4+3(p-1)] visits.  Synchronises the device. */
+int mtq_debug_scan_ticks(uint64_t out[16]);
 
 #ifdef __cplusplus
 }

@@ -26,6 +26,7 @@
 // No MFMA, no block barrier: waves never share data.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/mtq.h"
 #include "mtq_device.hpp"
@@ -229,7 +230,7 @@ __device__ __forceinline__ void glds16(const void *sbase, uint32_t voff, uint32_
 template <uint32_t BFP>
 __global__ __launch_bounds__(kFastWaves * 64, MTQ_ROLLED_WAVES_PER_SIMD) void tile_stats_bf16_rolled(
     const uint16_t *__restrict__ x, int64_t stride, int64_t ld, int tiles_w, int64_t tiles, int units_w, int units_per_tensor,
-    int total_units, uint32_t fmt_mask, int rec, double *__restrict__ stats, unsigned *__restrict__ work, unsigned launch_id)
+    int total_units, uint32_t fmt_mask, int rec, double *__restrict__ stats, unsigned *__restrict__ work, unsigned launch_id, int units_per_wave)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int lane = threadIdx.x & 63;
@@ -280,11 +281,17 @@ __global__ __launch_bounds__(kFastWaves * 64, MTQ_ROLLED_WAVES_PER_SIMD) void ti
         for (int i = 0; i < 8; ++i) glds16(base, dma_off[i], in_addr + i * 1024);
     };
 
+    // A wave retires after units_per_wave units (0: never — a fully persistent grid): the launch then consists of more blocks than
+    // are resident at once and slots keep opening up, so that the one-wave-per-tensor scan kernels of earlier chunks
+    // (csrc/mtq_scan.hip, other streams) are placed within a block's lifetime instead of waiting for the whole launch to drain.
+    int left = units_per_wave > 0 ? units_per_wave : 0x7FFFFFFF;
     int u = claim();
+    --left;
     if (u < total_units) issue_dma(u);
     while (u < total_units) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                     // image landed (and the previous records retired)
-        const int u_next = claim();                                           // its latency hides behind this unit's arithmetic
+        const int u_next = left > 0 ? claim() : 0x7FFFFFFF;                   // its latency hides behind this unit's arithmetic
+        --left;
 
         double acc[kSums];
 #pragma unroll
@@ -401,7 +408,17 @@ extern "C" int mtq_launch_tile_stats_bf16_fast(const void *x, int64_t count, int
     }
     const int64_t need = (total + kFastWaves - 1) / kFastWaves;
     const int64_t max_blocks = (int64_t)cus * MTQ_ROLLED_WAVES_PER_SIMD; // blocks of 4 waves per CU (one wave of each per SIMD)
-    const unsigned blocks = (unsigned)(need < max_blocks ? need : max_blocks);
+    // MTQ_K1_UNITS_PER_WAVE (default 16; 0 = persistent waves): with a bound, the grid is what the units need at that many per wave,
+    // rounded up to whole counter groups plus one spare block per group (a block that finds its group's queue empty exits at once)
+    static int upw = -1;
+    if (upw < 0) { const char *e = getenv("MTQ_K1_UNITS_PER_WAVE"); upw = e ? atoi(e) : 16; if (upw < 0) upw = 0; }
+    int64_t want = need < max_blocks ? need : max_blocks;
+    if (upw > 0 && need > max_blocks) {
+        const int64_t by_quota = (total + (int64_t)kFastWaves * upw - 1) / ((int64_t)kFastWaves * upw);
+        want = ((by_quota + kWorkGroups - 1) / kWorkGroups + 1) * kWorkGroups;
+        if (want < max_blocks) want = max_blocks;
+    }
+    const unsigned blocks = (unsigned)want;
     const dim3 grid(blocks), block(kFastWaves * 64);
     const size_t lds_bytes = kFastWaves * kRolledWaveLds;
     hipStream_t st = static_cast<hipStream_t>(stream);
@@ -409,7 +426,7 @@ extern "C" int mtq_launch_tile_stats_bf16_fast(const void *x, int64_t count, int
     if (int rc = work_counter_acquire(stream, work_out)) return rc;   // `st` now waits for the slot's previous launch to have reset it
     unsigned *work = work_out->counters;
 #define MTQ_LAUNCH_FAST(B) \
-    hipLaunchKernelGGL(tile_stats_bf16_rolled<B>, grid, block, lds_bytes, st, xp, stride_elems, ld, (int)tw, tiles, (int)units_w, (int)upt, (int)total, fmt_mask, rec, stats, work, launch_id)
+    hipLaunchKernelGGL(tile_stats_bf16_rolled<B>, grid, block, lds_bytes, st, xp, stride_elems, ld, (int)tw, tiles, (int)units_w, (int)upt, (int)total, fmt_mask, rec, stats, work, launch_id, (need > max_blocks ? upw : 0))
     switch ((fmt_mask >> 1) & 7u) { // one instantiation per requested BFP subset: unrequested formats cost nothing
     case 1: MTQ_LAUNCH_FAST(1u); break;
     case 2: MTQ_LAUNCH_FAST(2u); break;

@@ -1,0 +1,626 @@
+// mtq_scan.hip — H1 on the device: the sequential mixed-tile-greedy scan (mixed_tile_greedy.py:133-346, pcc metric) run where
+// K1 wrote the stats records, one wave64 per tensor.  Nothing but the finished maps (1 B/tile) crosses PCIe; the host neither
+// scans nor shuffles.  Same IEEE double operations in the same order as the host scan (csrc/mtq_host.cpp), same NumPy
+// generator stream (SeedSequence → PCG64 → Generator.permutation), hence the same maps bit for bit
+// (tests/test_hip_kernels.py::test_device_scan_*).
+//
+// What is sequential in the reference and how a 64-lane wave keeps it sequential in effect:
+//   * initial sums (:147-174): running sums in tile order — five dependent float64 chains, one lane each, fed from an LDS
+//     staging block that all 64 lanes fill;
+//   * visiting order (:222-231): Generator.permutation = Fisher–Yates from the top with masked rejection sampling on buffered
+//     32-bit halves of PCG64 outputs.  A batch is 64 stream positions: lane l evaluates position l by LCG jump-ahead
+//     (state_q = A_q·state + G_q·inc), acceptance `v <= i − (accepted before me)` is settled exactly (certain accepts, certain
+//     rejects, the few in between one by one), the batch is cut where the mask level changes, unused positions are handed
+//     back; the accepted steps' swaps are applied in parallel except those that share a position with another step of the
+//     batch (found with a tag table in LDS), which are applied one by one in step order.  Modelled and checked against NumPy
+//     in tools/scan_model/shuffle_model.py;
+//   * the scan (:234-278): 64 visits per round under a speculation on their outcome — accept mode: lane i holds the running
+//     sums plus the deltas of visits 0..i added one after the other (a serial chain of float64 additions on three lanes,
+//     through LDS: the order of the additions is the contract); reject mode: every lane holds the running sums plus its own
+//     delta.  The prefix the speculation was right for is kept (csrc/mtq_host.cpp greedy_pass_pcc8, eight lanes there).
+// Not handled here (status != 0, the caller falls back to the host scan for that tensor): a zero denominator anywhere in
+// the search (the decision then needs Σ|x−y|, :186-189).  The entry point refuses other metrics, repeated formats and tensors
+// of more than kMaxTiles tiles (callers use the host scan for those).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <mutex>
+
+#include "../../include/mtq.h"
+#include "mtq_decide.hpp"
+#include "mtq_error.hpp"
+
+namespace mtq {
+namespace {
+
+constexpr int kScanMaxTilesLds = 32768;   // visiting order kept in LDS as 16-bit tile ids up to here (64 KiB)
+constexpr int kTagSlots = 16384;          // conflict tags: one byte per hashed position
+constexpr int kHitWords = kTagSlots / 32;
+constexpr int kJump = 34;                 // jump-ahead table entries (q = 0..33)
+
+// Diagnostics: shader-clock ticks tensor 0 of the last launch spent per phase (mtq_debug_scan_ticks): 0 start-up + initial sums,
+// 1 base pass + draw-only shuffle, then per later pass p (1..3): 2+3(p−1) candidates + shuffle, +1 deltas, +2 visits.
+} }
+__device__ unsigned long long g_scan_ticks[16];
+namespace mtq { namespace {
+
+struct U128 { uint64_t lo, hi; };
+__host__ __device__ inline U128 mul128(U128 a, U128 b)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint64_t h = __umul64hi(a.lo, b.lo);
+#else
+    const uint64_t h = (uint64_t)(((unsigned __int128)a.lo * b.lo) >> 64);
+#endif
+    return {a.lo * b.lo, h + a.lo * b.hi + a.hi * b.lo};
+}
+__host__ __device__ inline U128 add128(U128 a, U128 b)
+{
+    const uint64_t lo = a.lo + b.lo;
+    return {lo, a.hi + b.hi + (lo < a.lo ? 1ull : 0ull)};
+}
+__host__ __device__ inline uint64_t pcg_out(U128 s)   // XSL-RR (numpy/random/src/pcg64/pcg64.h)
+{
+    const uint64_t x = s.hi ^ s.lo;
+    const unsigned rot = (unsigned)(s.hi >> 58);
+    return (x >> rot) | (x << ((64u - rot) & 63u));
+}
+constexpr uint64_t kMultHi = 0x2360ED051FC65DA4ull, kMultLo = 0x4385DF649FCCF645ull;
+
+// SeedSequence(seed) → PCG64 state and increment (csrc/mtq_host.cpp rng_seed, numpy/random/bit_generator.pyx)
+__device__ inline void seed_pcg(uint64_t seed, U128 &state, U128 &inc)
+{
+    uint32_t ent[2];
+    int n_ent = 1;
+    ent[0] = (uint32_t)seed;
+    ent[1] = 0u;
+    if (seed >> 32) { ent[1] = (uint32_t)(seed >> 32); n_ent = 2; }
+    uint32_t hc = 0x43b0d7e5u;
+    uint32_t pool[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        uint32_t v = i < n_ent ? ent[i] : 0u;
+        v ^= hc; hc *= 0x931e8875u; v *= hc; v ^= v >> 16;
+        pool[i] = v;
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int d = 0; d < 4; ++d)
+            if (s != d) {
+                uint32_t v = pool[s];
+                v ^= hc; hc *= 0x931e8875u; v *= hc; v ^= v >> 16;
+                uint32_t t = 0xca01f9ddu * pool[d] - 0x4973f715u * v;
+                t ^= t >> 16;
+                pool[d] = t;
+            }
+    uint32_t hb = 0x8b51f9ddu, w[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { uint32_t v = pool[i & 3]; v ^= hb; hb *= 0x58f38dedu; v *= hb; v ^= v >> 16; w[i] = v; }
+    const uint64_t u0 = w[0] | ((uint64_t)w[1] << 32), u1 = w[2] | ((uint64_t)w[3] << 32);
+    const uint64_t u2 = w[4] | ((uint64_t)w[5] << 32), u3 = w[6] | ((uint64_t)w[7] << 32);
+    const U128 initstate = {u1, u0}, initseq = {u3, u2};
+    const U128 mult = {kMultLo, kMultHi};
+    inc = {(initseq.lo << 1) | 1ull, (initseq.hi << 1) | (initseq.lo >> 63)};
+    state = {0ull, 0ull};
+    state = add128(mul128(state, mult), inc);
+    state = add128(state, initstate);
+    state = add128(mul128(state, mult), inc);
+}
+
+// loads / stores that are served by L2 (this wave re-reads what it wrote: never through the CU's vector L1)
+template <typename T>
+__device__ inline T ld_l2(const T *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ inline double ld_l2(const double *p) { return __longlong_as_double((long long)ld_l2(reinterpret_cast<const unsigned long long *>(p))); }
+__device__ inline void mem_wait() { __builtin_amdgcn_s_waitcnt(0); __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); }
+
+// keeps the compiler from moving memory operations across it; emits nothing (the hardware runs one wave's LDS operations in order)
+__device__ inline void compiler_fence() { asm volatile("" ::: "memory"); }
+__device__ inline uint64_t below(int lane) { return lane >= 64 ? ~0ull : ((1ull << lane) - 1ull); }
+__device__ inline double shfl_f64(double v, int src)
+{
+    const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+    const unsigned lo = (unsigned)__shfl((int)(unsigned)u, src, 64), hi = (unsigned)__shfl((int)(unsigned)(u >> 32), src, 64);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+__device__ inline uint64_t shfl_u64(uint64_t u, int src)
+{
+    const unsigned lo = (unsigned)__shfl((int)(unsigned)u, src, 64), hi = (unsigned)__shfl((int)(unsigned)(u >> 32), src, 64);
+    return ((uint64_t)hi << 32) | lo;
+}
+
+// The visiting order of one tensor: 16-bit ids in LDS (tiles <= kScanMaxTilesLds) or 32-bit ids in global scratch.
+struct OrderLds {
+    volatile uint16_t *p;
+    __device__ uint32_t get(uint32_t i) const { return p[i]; }
+    __device__ void set(uint32_t i, uint32_t v) const { p[i] = (uint16_t)v; }
+    __device__ void sync() const { __builtin_amdgcn_s_waitcnt(0xC07F); /* lgkmcnt(0) */ __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); }
+    // LDS operations of one wave execute in program order: reads before dependent writes need only the compiler's own wait for the
+    // loaded value, and a later read sees an earlier write without any wait
+    __device__ void sync_reads() const { compiler_fence(); }
+    __device__ void sync_writes() const { compiler_fence(); }
+};
+struct OrderGlobal {
+    uint32_t *p;
+    __device__ uint32_t get(uint32_t i) const { return ld_l2(p + i); }
+    __device__ void set(uint32_t i, uint32_t v) const { p[i] = v; }
+    __device__ void sync() const { mem_wait(); }
+    __device__ void sync_reads() const { mem_wait(); }    // global memory: loads and stores of one wave may complete out of order
+    __device__ void sync_writes() const { mem_wait(); }
+};
+
+struct Rng {
+    U128 state;       // wave-uniform
+    bool has32;       // a buffered high half is the next draw
+    uint32_t u32;
+    U128 a0, c0, a1, c1;   // per lane: jump multiplier / increment term for the lane's output index without / with a pending half
+};
+
+// Generator.permutation(candidates) in place on `ord[0..n)` (kSwap) or just the generator's advance (the base pass, where the
+// order does not matter: csrc/mtq_host.cpp rng_skip_shuffle).  → false if the batch budget ran out (cannot happen in practice:
+// every batch accepts at least one draw with probability 1 − 2^−64).
+template <bool kSwap, typename Order>
+__device__ bool wave_shuffle(Rng &r, const Order &ord, int n, volatile uint8_t *tag, uint32_t *hit, int lane)
+{
+    if (n < 2) return true;
+    int i0 = n - 1;
+    int budget = 8 * n + 4096;
+    while (i0 >= 1) {
+        if (--budget < 0) return false;
+        const uint32_t mask = 0xFFFFFFFFu >> __builtin_clz((unsigned)i0);
+        const int lo = (int)(mask >> 1);
+        const int pend = r.has32 ? 1 : 0;
+        // ---- this lane's stream position
+        const U128 A = pend ? r.a1 : r.a0, C = pend ? r.c1 : r.c0;
+        const U128 s = add128(mul128(A, r.state), C);
+        const uint64_t o = pcg_out(s);
+        const int half = (lane - pend) & 1;
+        uint32_t raw = half ? (uint32_t)(o >> 32) : (uint32_t)o;
+        if (pend && lane == 0) raw = r.u32;
+        const uint32_t v = raw & mask;
+        // ---- acceptance: v <= i0 − (accepted before me)
+        uint64_t okmask = __ballot((int)v <= i0 - lane);
+        uint64_t amb = ~(okmask | __ballot(v > (uint32_t)i0));
+        while (amb) {   // wave-uniform loop over the few undecided lanes, in lane order
+            const int a = __builtin_ctzll(amb);
+            const int P = __builtin_popcountll(okmask & below(a));
+            const uint32_t va = (uint32_t)__shfl((int)v, a, 64);
+            if ((int)va <= i0 - P) okmask |= 1ull << a;
+            amb &= amb - 1ull;
+        }
+        const int kmax = i0 - lo;                  // steps this mask level still has (i must stay above lo; lo == 0 at the last level)
+        const int total = __builtin_popcountll(okmask);
+        int c = 64, k = total;
+        if (total >= kmax) {                       // cut just after the kmax-th accepted position: the rest belongs to the next level
+            uint64_t mm = okmask;
+            for (int q = 1; q < kmax; ++q) mm &= mm - 1ull;
+            c = __builtin_ctzll(mm) + 1;
+            k = kmax;
+            okmask &= below(c);
+        }
+        if (kSwap && k > 0) {
+            const bool mine = (okmask >> lane) & 1ull;
+            const int tstep = __builtin_popcountll(okmask & below(lane));
+            const uint32_t pi = (uint32_t)(i0 - tstep), pj = v;
+            const uint32_t hi_ = pi & (kTagSlots - 1), hj = pj & (kTagSlots - 1);
+            // both operands of every step are fetched now: the reads travel while the conflict protocol below runs (steps that turn out
+            // to share a position read again when their turn comes)
+            uint32_t vi = 0, vj = 0;
+            if (mine) { vi = ord.get(pi); vj = ord.get(pj); }
+            // positions touched by two steps of the batch: tag protocol (losers of a slot raise its hit bit, the winner sees it).
+            // LDS operations of one wave execute in program order, so a read only needs the wait before its value is used.
+            if (mine) tag[hi_] = (uint8_t)lane;
+            compiler_fence();
+            if (mine && pj != pi) tag[hj] = (uint8_t)(64 + lane);
+            compiler_fence();
+            bool loser = false;
+            if (mine) loser = tag[hi_] != (uint8_t)lane || (pj != pi && tag[hj] != (uint8_t)(64 + lane));
+            if (loser) { atomicOr(&hit[hi_ >> 5], 1u << (hi_ & 31)); atomicOr(&hit[hj >> 5], 1u << (hj & 31)); }
+            compiler_fence();
+            bool flagged = loser;
+            if (mine) {
+                const volatile uint32_t *vh = hit;
+                flagged = loser || ((vh[hi_ >> 5] >> (hi_ & 31)) & 1u) || ((vh[hj >> 5] >> (hj & 31)) & 1u);
+            }
+            compiler_fence();
+            if (flagged) { atomicAnd(&hit[hi_ >> 5], ~(1u << (hi_ & 31))); atomicAnd(&hit[hj >> 5], ~(1u << (hj & 31))); }
+            const uint64_t fmask = __ballot(flagged);
+                // steps that share no position with another step commute with everything: all at once
+            const bool par = mine && !flagged;
+            ord.sync_reads();
+            if (par) { ord.set(pi, vj); ord.set(pj, vi); }
+            ord.sync_writes();
+                uint64_t fm = fmask;
+            while (fm) {   // the others one by one, in step order
+                const int f = __builtin_ctzll(fm);
+                if (lane == f) { vi = ord.get(pi); vj = ord.get(pj); }
+                ord.sync_reads();
+                if (lane == f) { ord.set(pi, vj); ord.set(pj, vi); }
+                ord.sync_writes();
+                fm &= fm - 1ull;
+            }
+            }
+        i0 -= k;
+        // ---- hand the unused positions back: the generator stands after the c-th position
+        const int used = c - pend;
+        if (used > 0) {
+            const int src = c - 1;
+            r.state.lo = shfl_u64(s.lo, src);
+            r.state.hi = shfl_u64(s.hi, src);
+            r.has32 = (used & 1) != 0;
+            r.u32 = (uint32_t)__shfl((int)(uint32_t)(o >> 32), src, 64);
+        } else {
+            r.has32 = false;
+        }
+    }
+    return true;
+}
+
+struct ScanArgs {
+    const double *stats;      // [count][tiles][rec]
+    int64_t tiles;
+    int rec;
+    int n_formats;
+    int fmt[MTQ_NUM_TILE_FORMATS];       // format codes in search order
+    int oy[MTQ_NUM_TILE_FORMATS], oy2[MTQ_NUM_TILE_FORMATS], oxy[MTQ_NUM_TILE_FORMATS];   // record offsets of Σy, Σy², Σxy BY FORMAT CODE (identity bf16: 0, 1, 1)
+    double thr, n;
+    const uint64_t *seeds;    // [count]
+    int8_t *maps;             // [count][tiles] out
+    int32_t *status;          // [count] out: 0 ok, 1 zero denominator (host scan needed), 2 internal budget exhausted
+    uint32_t *order_g;        // [count][tiles] scratch (tiles > kScanMaxTilesLds)
+    double *delta;            // [count][tiles][4] scratch: Δ(Σy, Σy², Σxy) of the visit and the tile's previous code
+    const U128 *jump_a, *jump_g;   // [kJump]
+};
+
+// pcc_hoisted of csrc/mtq_host.cpp (mixed_tile_greedy.py:176-190 with the x-only terms hoisted): the same operations in the
+// same order.  special: zero denominator.
+__device__ inline bool pcc_good(double n, double mean_x, double am2, double thr, double sy, double sy2, double sxy, bool &special)
+{
+    const double mean_y = sy / n;
+    double bm2 = sy2 - n * mean_y * mean_y;
+    if (bm2 < 0.0) bm2 = 0.0;
+    const double denom = __builtin_sqrt(am2 * bm2);
+    special = denom == 0.0;
+    const double val = (sxy - n * mean_x * mean_y) / denom;
+    return val >= thr;
+}
+
+template <typename Order>
+__device__ void scan_tensor(const ScanArgs &a, const Order &ord, int b, unsigned char *lds, int lane)
+{
+    const int T = (int)a.tiles;
+    const int rec = a.rec;
+    const double *st = a.stats + (int64_t)b * a.tiles * rec;
+    int8_t *map = a.maps + (int64_t)b * a.tiles;
+    double *delta = a.delta + (int64_t)b * a.tiles * 4;
+    double *lds_d = reinterpret_cast<double *>(lds);                 // [64][4] deltas / staging
+    double *lds_p = lds_d + 64 * 4;                                    // [64][4] prefixes
+    double *lds_i = lds_p + 64 * 4;                                    // [64][5] initial-sum staging
+    volatile uint8_t *tag = reinterpret_cast<volatile uint8_t *>(lds_i + 64 * 5);   // [kTagSlots]
+    uint32_t *hit = reinterpret_cast<uint32_t *>(const_cast<uint8_t *>(tag) + kTagSlots);   // [kHitWords]
+    int status = 0;
+    unsigned long long tick = clock64();
+    auto stamp = [&](int slot) {
+        const unsigned long long now = clock64();
+        if (b == 0 && lane == 0 && slot < 16) g_scan_ticks[slot] = now - tick;
+        tick = now;
+    };
+
+    for (int i = lane; i < kHitWords; i += 64) hit[i] = 0u;
+    const int base = a.fmt[0];
+    for (int t = lane; t < T; t += 64) map[t] = (int8_t)base;        // :99
+
+    // ---- generator
+    Rng r;
+    {
+        U128 inc;
+        seed_pcg(a.seeds[b], r.state, inc);
+        r.has32 = false;
+        r.u32 = 0u;
+        const int q0 = (lane >> 1) + 1, q1 = lane >= 1 ? ((lane - 1) >> 1) + 1 : 1;
+        r.a0 = a.jump_a[q0]; r.c0 = mul128(a.jump_g[q0], inc);
+        r.a1 = a.jump_a[q1]; r.c1 = mul128(a.jump_g[q1], inc);
+    }
+
+    // ---- initial sums in tile order (:147-174): chains Σx, Σx², Σy, Σy², Σxy on lanes 0..4
+    const int off5[5] = {0, 1, a.oy[base], a.oy2[base], a.oxy[base]};
+    double acc = 0.0;
+    double nx[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+    if (lane < T) {
+        const double *rt = st + (int64_t)lane * rec;
+#pragma unroll
+        for (int c = 0; c < 5; ++c) nx[c] = rt[off5[c]];
+    }
+    for (int t0 = 0; t0 < T; t0 += 64) {
+        const int m = min(64, T - t0);
+        if (lane < m) {
+#pragma unroll
+            for (int c = 0; c < 5; ++c) lds_i[lane * 5 + c] = nx[c];
+        }
+        if (t0 + 64 + lane < T) {   // the next block's records are on their way while this block's chain runs
+            const double *rt = st + (int64_t)(t0 + 64 + lane) * rec;
+#pragma unroll
+            for (int c = 0; c < 5; ++c) nx[c] = rt[off5[c]];
+        }
+        __syncthreads();
+        if (lane < 5) {
+            if (m == 64) {   // eight staged values at a time: the additions stay one dependent chain in tile order, the LDS reads do not wait for it
+#pragma unroll
+                for (int i0 = 0; i0 < 64; i0 += 8) {
+                    double v[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) v[u] = lds_i[(i0 + u) * 5 + lane];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) acc = acc + v[u];
+                }
+            } else {
+                for (int i = 0; i < m; ++i) acc = acc + lds_i[i * 5 + lane];
+            }
+        }
+        __syncthreads();
+    }
+    const double sum_x = shfl_f64(acc, 0), sum_x2 = shfl_f64(acc, 1);
+    double Sy = shfl_f64(acc, 2), Sy2 = shfl_f64(acc, 3), Sxy = shfl_f64(acc, 4);
+    const double n = a.n, thr = a.thr;
+    const double mean_x = sum_x / n;
+    double am2 = sum_x2 - n * mean_x * mean_x;
+    if (am2 < 0.0) am2 = 0.0;
+
+    stamp(0);
+    // ---- pass of the base format: every tile already has it, one question for all of them (:237-241)
+    bool all_fixed = false;
+    {
+        bool special = false;
+        const bool good = pcc_good(n, mean_x, am2, thr, Sy, Sy2, Sxy, special);
+        if (special) status = 1;
+        all_fixed = !good;
+        if (!wave_shuffle<false>(r, ord, T, tag, hit, lane)) status = 2;   // the generator advances as the permutation would have
+    }
+
+    stamp(1);
+    for (int p = 1; p < a.n_formats && status == 0 && !all_fixed; ++p) {
+        const int f = a.fmt[p];
+        // candidates = np.where(~fixed)[0] (:228): in tile order
+        int nc = 0;
+        for (int t0 = 0; t0 < T; t0 += 64) {
+            const int t = t0 + lane;
+            const bool cand = t < T && ((uint8_t)ld_l2(map + t) & 0x80u) == 0u;
+            const uint64_t bm = __ballot(cand);
+            if (cand) ord.set((uint32_t)(nc + __builtin_popcountll(bm & below(lane))), (uint32_t)t);
+            nc += __builtin_popcountll(bm);
+        }
+        ord.sync();
+        if (nc == 0) break;                                            // :229-230
+        if (!wave_shuffle<true>(r, ord, nc, tag, hit, lane)) { status = 2; break; }   // order = rng.permutation(candidates), :231
+        stamp(2 + 3 * (p - 1));
+        // deltas of every visit of the pass (a tile is visited once per pass, so its previous format is what the map holds now)
+        for (int k0 = 0; k0 < nc; k0 += 256) {   // four rounds of 64 visits in flight: the gathers are latency-bound
+            uint32_t tt[4];
+            int pv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int k = k0 + 64 * u + lane;
+                tt[u] = k < nc ? ord.get((uint32_t)k) : 0u;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) pv[u] = (int)((uint8_t)ld_l2(map + tt[u]) & 0x7Fu);
+            double dd[4][3];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const double *rt = st + (int64_t)tt[u] * rec;
+                dd[u][0] = rt[a.oy[f]] - rt[a.oy[pv[u]]];     // :259-261
+                dd[u][1] = rt[a.oy2[f]] - rt[a.oy2[pv[u]]];
+                dd[u][2] = rt[a.oxy[f]] - rt[a.oxy[pv[u]]];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int k = k0 + 64 * u + lane;
+                if (k < nc) {
+                    double *d = delta + (int64_t)k * 4;
+                    d[0] = dd[u][0]; d[1] = dd[u][1]; d[2] = dd[u][2]; d[3] = __longlong_as_double((long long)pv[u]);
+                }
+            }
+        }
+        mem_wait();
+        stamp(3 + 3 * (p - 1));
+        // ---- the visits (:234-278), 64 per round
+        int k = 0, pk = -1;
+        double pdy = 0.0, pdy2 = 0.0, pdxy = 0.0;
+        int pprev = 0;
+        uint32_t pt = 0;
+        bool accept_mode = true;
+        while (k < nc) {
+            const int m = min(64, nc - k);
+            const bool active = lane < m;
+            double dy = 0.0, dy2 = 0.0, dxy = 0.0;
+            int prev = 0;
+            uint32_t t = 0;
+            if (pk == k) {   // the window fetched ahead (the previous round consumed all of its visits)
+                dy = pdy; dy2 = pdy2; dxy = pdxy; prev = pprev; t = pt;
+            } else if (active) {
+                const double *d = delta + (int64_t)(k + lane) * 4;
+                dy = ld_l2(d); dy2 = ld_l2(d + 1); dxy = ld_l2(d + 2);
+                prev = (int)__double_as_longlong(ld_l2(d + 3));
+                t = ord.get((uint32_t)(k + lane));
+            }
+            pk = k + m;      // fetch the window after this one while this one is decided (useless only when the speculation fails)
+            pdy = pdy2 = pdxy = 0.0; pprev = 0; pt = 0;
+            if (pk + lane < nc) {
+                const double *d = delta + (int64_t)(pk + lane) * 4;
+                pdy = ld_l2(d); pdy2 = ld_l2(d + 1); pdxy = ld_l2(d + 2);
+                pprev = (int)__double_as_longlong(ld_l2(d + 3));
+                pt = ord.get((uint32_t)(pk + lane));
+            }
+            double cy, cy2, cxy;
+            if (accept_mode) {   // lane i: the running sums after visits 0..i, added one after the other as the sequential scan adds them
+                lds_d[lane * 4 + 0] = dy; lds_d[lane * 4 + 1] = dy2; lds_d[lane * 4 + 2] = dxy;
+                __syncthreads();
+                if (lane < 3) {   // inactive visits staged +0 deltas: their prefixes are never read
+                    double s = lane == 0 ? Sy : (lane == 1 ? Sy2 : Sxy);
+#pragma unroll
+                    for (int i0 = 0; i0 < 64; i0 += 8) {
+                        double v[8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) v[u] = lds_d[(i0 + u) * 4 + lane];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) { s = s + v[u]; lds_p[(i0 + u) * 4 + lane] = s; }
+                    }
+                }
+                __syncthreads();
+                cy = lds_p[lane * 4 + 0]; cy2 = lds_p[lane * 4 + 1]; cxy = lds_p[lane * 4 + 2];
+                __syncthreads();
+            } else {             // lane i: the running sums plus its own delta
+                cy = Sy + dy; cy2 = Sy2 + dy2; cxy = Sxy + dxy;
+            }
+            bool special = false;
+            const bool good = pcc_good(n, mean_x, am2, thr, cy, cy2, cxy, special);
+            const uint64_t act = below(m);
+            const uint64_t okm = __ballot(good && active) & act, spm = __ballot(special && active) & act;
+            int j, take = -1;
+            if (accept_mode) {
+                const uint64_t rej = ~okm & act;
+                j = rej ? __builtin_ctzll(rej) : m;            // first rejected visit
+                if (spm & below(min(j + 1, 64))) { status = 1; break; }   // a zero denominator among the visits this round settles
+                if (lane < j) map[t] = (int8_t)f;              // accepted (:264-276)
+                if (j > 0) take = j - 1;
+                if (j < m) { if (lane == j) map[t] = (int8_t)(prev | 0x80); k += j + 1; if (j == 0) accept_mode = false; }   // fixed (:277-278)
+                else k += m;
+            } else {
+                j = okm ? __builtin_ctzll(okm) : m;            // first accepted visit
+                if (spm & below(min(j + 1, 64))) { status = 1; break; }
+                if (lane < j) map[t] = (int8_t)(prev | 0x80);
+                if (j < m) { if (lane == j) map[t] = (int8_t)f; take = j; k += j + 1; if (j == 0) accept_mode = true; }
+                else k += m;
+            }
+            if (take >= 0) { Sy = shfl_f64(cy, take); Sy2 = shfl_f64(cy2, take); Sxy = shfl_f64(cxy, take); }
+        }
+        mem_wait();
+        stamp(4 + 3 * (p - 1));
+    }
+    mem_wait();
+    for (int t = lane; t < T; t += 64) map[t] = (int8_t)((uint8_t)ld_l2(map + t) & 0x7Fu);
+    if (lane == 0) a.status[b] = status;
+}
+
+__global__ __launch_bounds__(64) void greedy_scan_pcc_lds(ScanArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int lane = threadIdx.x;
+    OrderLds ord{reinterpret_cast<volatile uint16_t *>(lds)};
+    scan_tensor(a, ord, blockIdx.x, lds + 2 * ((a.tiles + 7) & ~(int64_t)7), lane);
+}
+
+__global__ __launch_bounds__(64) void greedy_scan_pcc_global(ScanArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int lane = threadIdx.x;
+    OrderGlobal ord{a.order_g + (int64_t)blockIdx.x * a.tiles};
+    scan_tensor(a, ord, blockIdx.x, lds, lane);
+}
+
+constexpr size_t kFixedLds = (64 * 4 + 64 * 4 + 64 * 5) * sizeof(double) + kTagSlots + kHitWords * 4;
+
+// jump-ahead tables A_q = a^q, G_q = 1 + a + … + a^(q−1) (mod 2^128), uploaded once per device
+const U128 *jump_tables(int dev)
+{
+    static U128 *tab[64] = {nullptr};
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lock(mu);
+    if (dev < 0 || dev >= 64) return nullptr;
+    if (!tab[dev]) {
+        U128 h[2 * kJump];
+        const U128 mult = {kMultLo, kMultHi};
+        h[0] = {1ull, 0ull};
+        h[kJump] = {0ull, 0ull};
+        for (int q = 1; q < kJump; ++q) {
+            h[kJump + q] = add128(mul128(h[kJump + q - 1], mult), U128{1ull, 0ull});
+            h[q] = mul128(h[q - 1], mult);
+        }
+        U128 *d = nullptr;
+        if (hipMalloc(reinterpret_cast<void **>(&d), sizeof(h)) != hipSuccess) return nullptr;
+        if (hipMemcpy(d, h, sizeof(h), hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(d); return nullptr; }
+        tab[dev] = d;
+    }
+    return tab[dev];
+}
+
+} // namespace
+} // namespace mtq
+
+using namespace mtq;
+
+extern "C" int mtq_debug_scan_ticks(uint64_t out[16])
+{
+    if (!out) return fail(MTQ_ERR_INVALID, "null argument");
+    if (int rc = require_device()) return rc;
+    unsigned long long h[16];
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_scan_ticks), sizeof(h)) != hipSuccess) return fail(MTQ_ERR_HIP, "hipMemcpyFromSymbol failed");
+    for (int i = 0; i < 16; ++i) out[i] = h[i];
+    return MTQ_OK;
+}
+
+extern "C" size_t mtq_greedy_scan_scratch_bytes(int64_t count, int64_t tiles)
+{
+    if (count <= 0 || tiles <= 0) return 0;
+    const size_t per = (size_t)tiles * 4 * sizeof(double) + (tiles > kScanMaxTilesLds ? (size_t)tiles * sizeof(uint32_t) : 0);
+    return (size_t)count * ((per + 255) & ~(size_t)255);
+}
+
+extern "C" int mtq_greedy_scan_device(const double *stats, int64_t count, int64_t tiles, uint32_t fmt_mask, const int *formats, int n_formats,
+                                      int metric, double threshold, double elem_count, const uint64_t *seeds, int8_t *maps, int32_t *status,
+                                      void *scratch, size_t scratch_bytes, void *stream)
+{
+    if (!stats || !formats || !seeds || !maps || !status || !scratch) return fail(MTQ_ERR_INVALID, "null argument");
+    if (count <= 0 || count > (1 << 20) || tiles <= 0) return fail(MTQ_ERR_INVALID, "count and tiles must be positive");
+    if (tiles > MTQ_SCAN_DEVICE_MAX_TILES) return fail(MTQ_ERR_UNSUPPORTED, "more tiles than the device scan takes: use the host scan");
+    if (metric != MTQ_METRIC_PCC) return fail(MTQ_ERR_UNSUPPORTED, "the device scan serves the pcc metric: use the host scan");
+    if (n_formats <= 0 || n_formats > MTQ_NUM_TILE_FORMATS) return fail(MTQ_ERR_INVALID, "n_formats must be 1..4");
+    if (fmt_mask & MTQ_MASK_SLIM) return fail(MTQ_ERR_INVALID, "the device scan reads full records");
+    if (!(elem_count > 0.0)) return fail(MTQ_ERR_INVALID, "elem_count must be positive");
+    if (scratch_bytes < mtq_greedy_scan_scratch_bytes(count, tiles)) return fail(MTQ_ERR_INVALID, "scratch is smaller than mtq_greedy_scan_scratch_bytes()");
+    ScanArgs a{};
+    a.stats = stats;
+    a.tiles = tiles;
+    a.rec = 2 + 5 * popcount4(fmt_mask);
+    a.n_formats = n_formats;
+    for (int f = 0; f < MTQ_NUM_TILE_FORMATS; ++f) {
+        const int s = slot_of(fmt_mask, f);
+        a.oy[f] = s >= 0 ? 2 + 5 * s : 0;
+        a.oy2[f] = s >= 0 ? 3 + 5 * s : 1;
+        a.oxy[f] = s >= 0 ? 4 + 5 * s : 1;
+    }
+    for (int i = 0; i < n_formats; ++i) {
+        if (!slot_ok(slot_of(fmt_mask, formats[i]))) return fail(MTQ_ERR_INVALID, "a format is not available under fmt_mask");
+        for (int j = 0; j < i; ++j) if (formats[j] == formats[i]) return fail(MTQ_ERR_UNSUPPORTED, "the device scan needs distinct formats: use the host scan");
+        a.fmt[i] = formats[i];
+    }
+    a.thr = threshold;
+    a.n = elem_count;
+    a.seeds = seeds;
+    a.maps = maps;
+    a.status = status;
+    if (int rc = require_device()) return rc;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return fail(MTQ_ERR_HIP, "hipGetDevice failed");
+    const U128 *jt = jump_tables(dev);
+    if (!jt) return fail(MTQ_ERR_HIP, "could not upload the jump-ahead tables");
+    a.jump_a = jt;
+    a.jump_g = jt + kJump;
+    // scratch: all deltas first, then (large tensors) all orders
+    a.delta = static_cast<double *>(scratch);
+    a.order_g = reinterpret_cast<uint32_t *>(static_cast<unsigned char *>(scratch) + (size_t)count * (size_t)tiles * 4 * sizeof(double));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (tiles <= kScanMaxTilesLds) {
+        const size_t lds = 2 * (size_t)((tiles + 7) & ~(int64_t)7) + kFixedLds;
+        static bool raised = false;
+        if (!raised) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void *>(greedy_scan_pcc_lds), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kScanMaxTilesLds + (int)kFixedLds) != hipSuccess)
+                return fail(MTQ_ERR_HIP, "could not raise the dynamic LDS limit");
+            raised = true;
+        }
+        hipLaunchKernelGGL(greedy_scan_pcc_lds, dim3((unsigned)count), dim3(64), lds, st, a);
+    } else {
+        hipLaunchKernelGGL(greedy_scan_pcc_global, dim3((unsigned)count), dim3(64), kFixedLds, st, a);
+    }
+    return check_launch("mtq_greedy_scan_device");
+}

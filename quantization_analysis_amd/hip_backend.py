@@ -31,7 +31,7 @@ EXPORTS = [
     "mtq_greedy_run_chain", "mtq_greedy_run_chain_batch", "mtq_pack_chain_records", "mtq_tile_scores", "mtq_threshold_assign", "mtq_columns_from_stats", "mtq_columns_from_sums", "mtq_tile_scores_device",
     "mtq_threshold_assign_device", "mtq_columns_scratch_doubles", "mtq_column_sums_device", "mtq_column_sums_device_batched",
     "mtq_rng_create", "mtq_rng_permutation", "mtq_rng_integers", "mtq_rng_destroy", "mtq_greedy_run", "mtq_greedy_run_batch",
-    "mtq_selftest_slot_ring",
+    "mtq_selftest_slot_ring", "mtq_greedy_scan_scratch_bytes", "mtq_greedy_scan_device", "mtq_debug_scan_ticks",
 ]
 
 
@@ -107,6 +107,10 @@ def lib() -> ctypes.CDLL:
     L.mtq_pack_chain_records.argtypes = [vp, i64, u32, vp, ci, vp, vp, ci, vp]
     L.mtq_greedy_run_chain.argtypes = [vp, vp, ci, i64, vp, ci, dbl, dbl, ctypes.c_uint64, vp, vp]
     L.mtq_greedy_run_chain_batch.argtypes = [vp, vp, ci, i64, i64, vp, ci, dbl, dbl, vp, vp, vp, ci]
+    L.mtq_greedy_scan_scratch_bytes.argtypes = [i64, i64]
+    L.mtq_greedy_scan_scratch_bytes.restype = ctypes.c_size_t
+    L.mtq_greedy_scan_device.argtypes = [vp, i64, i64, u32, vp, ci, ci, dbl, dbl, vp, vp, vp, vp, ctypes.c_size_t, vp]
+    L.mtq_selftest_slot_ring.restype = ci
     if L.mtq_version() < 123:
         raise MtqError("libmtq_hip.so is older than this package")
     _lib = L
@@ -420,6 +424,32 @@ def greedy_run(stats: np.ndarray, mask: int, formats, metric: str, threshold: fl
     check(lib().mtq_greedy_run(stats.ctypes.data, T, mask, fm, len(formats), METRIC_CODE[metric], float(threshold),
                                float(elem_count), int(seed), amap.ctypes.data, counts, out))
     return amap, {f: int(counts[i]) for i, f in enumerate(MIXED_TILE_FORMATS)}, {"pcc": out[0], "mae": out[1], "atol": out[2], "sums": tuple(out[3:9])}
+
+
+SCAN_DEVICE_MAX_TILES = 1 << 22
+
+
+def device_scan_supported(formats, metric: str, tiles: int) -> bool:
+    """What mtq_greedy_scan_device serves (include/mtq.h): the pcc metric, distinct formats, tiles up to SCAN_DEVICE_MAX_TILES."""
+    return metric == "pcc" and len(set(formats)) == len(formats) and 0 < tiles <= SCAN_DEVICE_MAX_TILES
+
+
+def greedy_scan_device(stats_dev, mask: int, formats, metric: str, threshold: float, elem_count: float, seeds_dev, maps_out=None,
+                       status_out=None, scratch=None):
+    """H1 on the device over FULL records [count, tiles, rec] where K1 wrote them → (int8 [count, tiles] maps, int32 [count]
+    status) device tensors, asynchronous on the current stream.  seeds_dev: uint64/int64 device tensor [count]."""
+    torch = _torch()
+    count, T = int(stats_dev.shape[0]), int(stats_dev.shape[1])
+    fm = (ctypes.c_int * len(formats))(*[MIXED_TILE_FORMATS.index(f) for f in formats])
+    maps = maps_out if maps_out is not None else torch.empty((count, T), dtype=torch.int8, device=stats_dev.device)
+    status = status_out if status_out is not None else torch.empty((count,), dtype=torch.int32, device=stats_dev.device)
+    need = int(lib().mtq_greedy_scan_scratch_bytes(count, T))
+    if scratch is None or scratch.numel() < need:
+        scratch = torch.empty((need,), dtype=torch.uint8, device=stats_dev.device)
+    check(lib().mtq_greedy_scan_device(stats_dev.data_ptr(), count, T, mask, fm, len(formats), METRIC_CODE[metric], float(threshold),
+                                       float(elem_count), seeds_dev.data_ptr(), maps.data_ptr(), status.data_ptr(), scratch.data_ptr(),
+                                       int(scratch.numel()), _stream_ptr()))
+    return maps, status
 
 
 def greedy_run_batch(stats: np.ndarray, mask: int, formats, metric: str, threshold: float, elem_count: float, seeds, n_threads: int):

@@ -116,10 +116,14 @@ def columns_from_sums_batch(sums: np.ndarray, n: float) -> np.ndarray:
 class GreedyPipeline:
     """mixed-tile-greedy over a (count, rows, cols) device tensor of equally shaped bf16/fp32 matrices."""
 
-    SLOTS = 3   # record slots = batches in flight: one on the GPU, one queued behind it, one being scanned (see run_steps)
+    SLOTS = int(os.environ.get("MTQ_PIPE_SLOTS", "3"))   # record slots = batches in flight: one on the GPU, one queued behind it, one being scanned (see run_steps)
 
     def __init__(self, tile_formats=None, metric: str = "pcc", threshold: float = 0.999, seed: int = 123,
-                 chunk: int = 8, workers: int = 8, pure_formats=()):
+                 chunk: int = 8, workers: int = 8, pure_formats=(), scan: str = "auto"):
+        """scan: "device" — the sequential scan runs on the GPU where K1 wrote the records (csrc/mtq_scan.hip: only maps, counts and
+        seven sums per tensor cross PCIe, the host does not scan); "host" — records over PCIe, scans on host threads; "auto" —
+        "device" where mtq_greedy_scan_device serves the search (pcc metric, distinct formats), else "host".  MTQ_DEVICE_SCAN=0
+        forces "host"."""
         import torch
 
         hb.require_gpu()
@@ -138,6 +142,20 @@ class GreedyPipeline:
         self.copy_stream = torch.cuda.Stream()   # records D2H, overlapped with the next chunk's K1
         self.col_stream = torch.cuda.Stream()    # maps up / column sums / sums down of a finished batch (must not queue behind the next batch's copies)
         self.timing = KernelTiming()
+        if scan not in ("auto", "host", "device"):
+            raise ValueError("scan must be 'auto', 'host' or 'device'")
+        can = hb.device_scan_supported(self.tile_formats, self.metric, 1)
+        if scan == "device" and not can:
+            raise ValueError("the device scan serves the pcc metric with distinct formats")
+        self.device_scan = can and scan != "host" and os.environ.get("MTQ_DEVICE_SCAN", "1") != "0"
+        # device scans + column sums: behind their chunk's K1, beside the next chunks' K1.  A scan is one wave per tensor for a few
+        # milliseconds (latency-bound), so consecutive chunks' scans must overlap each other: a ring of streams
+        self.scan_streams = [torch.cuda.Stream(priority=int(os.environ.get("MTQ_SCAN_PRIORITY", "-1")))
+                             for _ in range(int(os.environ.get("MTQ_SCAN_STREAMS", "8")))]   # priority -1: ahead of K1's blocks when a slot opens
+        self._scan_rr = 0
+        self.host_fallbacks = 0                  # tensors the device scan handed back (zero denominator)
+        self.host_seconds = {"enqueue": 0.0, "wait": 0.0, "wrap": 0.0}   # driver-thread time: launching, waiting for results, wrapping them
+        self._devbufs = {}
         self._bufs = {}
         self._chainbufs = {}
         self._colbufs = {}
@@ -195,6 +213,14 @@ class GreedyPipeline:
         count, rows, cols = x3d.shape
         th, tw = hb.tiles_hw(rows, cols)
         k1_mask, host_mask, slim = self._layout(x3d)
+        if self._use_device_scan(th * tw):
+            for slot in range(self.SLOTS):
+                b = self._device_buffers(slot, count, th * tw, hb.record_doubles(k1_mask), x3d.device)
+                b["dev"].zero_()
+                b["maps_host"].copy_(b["maps_dev"], non_blocking=True)
+                b["sums_host"].copy_(b["sums_dev"][:, :, :7], non_blocking=True)
+            torch.cuda.synchronize()
+            return
         chain = self._chain(slim)
         rec_host = 3 * (len(self.tile_formats) - 1) if chain else hb.record_doubles(host_mask)
         for slot in range(self.SLOTS):
@@ -222,6 +248,8 @@ class GreedyPipeline:
         tiles = th * tw
         slot = self._next_slot
         self._next_slot = (slot + 1) % self.SLOTS
+        if self._use_device_scan(tiles):
+            return self._enqueue_device(x3d, seeds, numel, slot, k1_mask, host_mask & ~hb.MASK_SLIM, th, tw)
         # the batch SLOTS back read this slot's records in its device-side column sums: those run on the K1 stream (see
         # _launch_columns), ahead of the K1 launches below in stream order — no host-side wait is needed here
         chain = self._chain(slim)
@@ -279,6 +307,145 @@ class GreedyPipeline:
         self._open.append(enq)
         return enq
 
+    # ---------------------------------------------------------------------------------------------------------------------
+    # device-resident scan (csrc/mtq_scan.hip)
+    # ---------------------------------------------------------------------------------------------------------------------
+    def _use_device_scan(self, tiles: int) -> bool:
+        return self.device_scan and hb.device_scan_supported(self.tile_formats, self.metric, tiles)
+
+    def _device_buffers(self, slot: int, count: int, tiles: int, rec: int, device) -> dict:
+        """Per record slot: K1's full records, the scan's maps / status / scratch, per-format tile counts and the column sums
+        (searched map + pure formats), with pinned host mirrors of what comes back: 1 B/tile + a few numbers per tensor."""
+        key = (count, tiles, rec, str(device))
+        b = self._devbufs.get(slot)
+        if b is None or b["key"] != key:
+            torch = self.torch
+            n_scratch = int(hb.lib().mtq_columns_scratch_doubles())
+            P = 1 + len(self.pure_formats)
+            b = {"key": key,
+                 "dev": torch.empty((count, tiles, rec), dtype=torch.float64, device=device),
+                 "maps_dev": torch.zeros((count, tiles), dtype=torch.int8, device=device),
+                 "status_dev": torch.zeros((count,), dtype=torch.int32, device=device),
+                 "counts_dev": torch.zeros((count, len(MIXED_TILE_FORMATS)), dtype=torch.int64, device=device),
+                 "seeds_dev": torch.zeros((count,), dtype=torch.int64, device=device),
+                 "seeds_host": torch.zeros((count,), dtype=torch.int64, pin_memory=True),
+                 "scratch": torch.empty((int(hb.lib().mtq_greedy_scan_scratch_bytes(count, tiles)),), dtype=torch.uint8, device=device),
+                 "sums_dev": torch.zeros((P, count, n_scratch), dtype=torch.float64, device=device),
+                 "pure_maps": [torch.full((count, tiles), MIXED_TILE_FORMATS.index(f), dtype=torch.int8, device=device) for f in self.pure_formats],
+                 "maps_host": torch.zeros((count, tiles), dtype=torch.int8, pin_memory=True),
+                 "status_host": torch.zeros((count,), dtype=torch.int32, pin_memory=True),
+                 "counts_host": torch.zeros((count, len(MIXED_TILE_FORMATS)), dtype=torch.int64, pin_memory=True),
+                 "sums_host": torch.zeros((P, count, 7), dtype=torch.float64, pin_memory=True),
+                 "free": None}
+            self._devbufs[slot] = b
+        return b
+
+    def _enqueue_device(self, x3d, seeds, numel, slot: int, k1_mask: int, dec_mask: int, th: int, tw: int) -> dict:
+        """GPU work of a batch with the scan on the device: per chunk K1 (launch stream) → scan + tile counts + column sums (scan
+        stream, behind the chunk's K1, beside the next chunk's K1) → maps, status, counts and sums D2H (copy stream)."""
+        import time
+
+        t_enq = time.perf_counter()
+        torch = self.torch
+        count, rows, cols = x3d.shape
+        tiles = th * tw
+        b = self._device_buffers(slot, count, tiles, hb.record_doubles(k1_mask), x3d.device)
+        n_el = rows * cols if numel is None else int(numel)
+        sh = b["seeds_host"].numpy()
+        sh[:] = self.seed if seeds is None else np.asarray([int(v) for v in seeds], dtype=np.int64)
+        if (sh == 0).any():
+            raise ValueError("seed 0 means 'draw a random seed' in the reference; pass non-zero seeds")
+        codes = torch.arange(len(MIXED_TILE_FORMATS), dtype=torch.int8, device=x3d.device)
+        per = int(hb.lib().mtq_greedy_scan_scratch_bytes(1, tiles))
+        pending = []
+        self.stream.wait_stream(torch.cuda.current_stream())
+        for ev in b["free"] or ():
+            self.stream.wait_event(ev)                  # the batch SLOTS back has finished reading this slot's records
+        b["free"] = []
+        for first in range(0, count, self.chunk):
+            n = min(self.chunk, count - first)
+            scan_stream = self.scan_streams[self._scan_rr]
+            self._scan_rr = (self._scan_rr + 1) % len(self.scan_streams)
+            with torch.cuda.stream(self.stream):
+                e0 = torch.cuda.Event(enable_timing=True)
+                e1 = torch.cuda.Event(enable_timing=True)
+                e0.record(self.stream)
+                hb.tile_stats_batched(x3d[first:first + n], k1_mask, out=b["dev"][first:first + n])
+                e1.record(self.stream)
+            self.timing.events.append((e0, e1, n * tiles))
+            scan_stream.wait_event(e1)
+            with torch.cuda.stream(scan_stream):
+                # the chunk's seeds go up on its own scan stream (on the copy stream they would queue behind the previous batch's
+                # downloads, i.e. behind the previous batch's scans: the scans of consecutive batches would run one after the other)
+                b["seeds_dev"][first:first + n].copy_(b["seeds_host"][first:first + n], non_blocking=True)
+                recs = b["dev"][first:first + n]
+                maps = b["maps_dev"][first:first + n]
+                hb.greedy_scan_device(recs, dec_mask, self.tile_formats, self.metric, self.threshold, float(n_el), b["seeds_dev"][first:first + n],
+                                      maps_out=maps, status_out=b["status_dev"][first:first + n], scratch=b["scratch"][first * per:(first + n) * per])
+                b["counts_dev"][first:first + n] = (maps.unsqueeze(-1) == codes).sum(dim=1)
+                hb.check(hb.lib().mtq_column_sums_device_batched(recs.data_ptr(), n, tiles, dec_mask, maps.data_ptr(),
+                                                                 b["sums_dev"][0, first:first + n].data_ptr(), scan_stream.cuda_stream))
+                for k, pm in enumerate(b["pure_maps"]):
+                    hb.check(hb.lib().mtq_column_sums_device_batched(recs.data_ptr(), n, tiles, dec_mask, pm[first:first + n].data_ptr(),
+                                                                     b["sums_dev"][1 + k, first:first + n].data_ptr(), scan_stream.cuda_stream))
+                scanned = torch.cuda.Event()
+                scanned.record(scan_stream)
+            self.copy_stream.wait_event(scanned)
+            with torch.cuda.stream(self.copy_stream):
+                b["maps_host"][first:first + n].copy_(maps, non_blocking=True)
+                b["status_host"][first:first + n].copy_(b["status_dev"][first:first + n], non_blocking=True)
+                b["counts_host"][first:first + n].copy_(b["counts_dev"][first:first + n], non_blocking=True)
+                b["sums_host"][:, first:first + n].copy_(b["sums_dev"][:, first:first + n, :7], non_blocking=True)
+                done = torch.cuda.Event(blocking=True)
+                done.record(self.copy_stream)
+            pending.append((done, first, n))
+            b["free"].append(scanned)
+        enq = {"device": True, "buf": b, "pending": pending, "tiles_hw": (th, tw), "numel": n_el, "x": x3d, "dec_mask": dec_mask,
+               "seeds": sh.copy()}
+        self._open.append(enq)
+        self.host_seconds["enqueue"] += time.perf_counter() - t_enq
+        return enq
+
+    def _finish_device(self, enq: dict) -> list[TensorResult]:
+        """Collects a device-scanned batch: waits for the chunks' copies and wraps maps / counts / columns; a tensor the device scan
+        handed back (status != 0: a zero denominator, the decision needs Σ|x−y|) is searched by the host scan on its records."""
+        import time
+
+        b = enq["buf"]
+        th, tw = enq["tiles_hw"]
+        n_el = float(enq["numel"])
+        k = {"pcc": 0, "mae": 1, "atol": 2}[self.metric]
+        results: list[TensorResult] = []
+        names = MIXED_TILE_FORMATS
+        for done, first, n in enq["pending"]:
+            t0 = time.perf_counter()
+            done.synchronize()
+            t1 = time.perf_counter()
+            maps = b["maps_host"][first:first + n].numpy().reshape(n, th, tw).copy()   # one copy per chunk: the pinned buffer is reused
+            status = b["status_host"][first:first + n].numpy()
+            counts = b["counts_host"][first:first + n].numpy().tolist()
+            sums = b["sums_host"][:, first:first + n].numpy()
+            cols = columns_from_sums_batch(sums[0], n_el).tolist()
+            pure_cols = [columns_from_sums_batch(sums[1 + i], n_el).tolist() for i in range(len(self.pure_formats))]
+            bad = np.flatnonzero(status)
+            for j in range(n):
+                pure = {f: tuple(pure_cols[i][j]) for i, f in enumerate(self.pure_formats)} if self.pure_formats else None
+                c = dict(zip(names, counts[j]))
+                cj = cols[j]
+                results.append(TensorResult(first + j, maps[j], c, mixed_tile_total_bytes(c), cj[0], cj[1], cj[2], cj[k], pure))
+            for j in bad:   # handed back by the device scan: the host scan on this tensor's records
+                self.host_fallbacks += 1
+                full = b["dev"][first + j].cpu().numpy()
+                amap, c, out = hb.greedy_run(full, enq["dec_mask"], self.tile_formats, self.metric, self.threshold, n_el, int(enq["seeds"][first + j]))
+                r = results[len(results) - n + j]
+                r.assignment, r.counts, r.tile_bytes = amap.reshape(th, tw), c, mixed_tile_total_bytes(c)
+                r.pcc, r.mae, r.atol, r.metric_value = out["pcc"], out["mae"], out["atol"], out[self.metric]
+            self.host_seconds["wait"] += t1 - t0
+            self.host_seconds["wrap"] += time.perf_counter() - t1
+        self._open.pop(0)
+        enq["x"] = None
+        return results
+
     def _scan_args(self, enq: dict, first: int, n: int, stats, mask):
         seeds = enq["seeds"]
         sd = [self.seed] * n if seeds is None else [int(v) for v in seeds[first:first + n]]
@@ -292,6 +459,8 @@ class GreedyPipeline:
         torch = self.torch
         if not self._open or self._open[0] is not enq:
             raise RuntimeError("batches finish in the order they were enqueued")
+        if enq.get("device"):
+            return self._finish_device(enq)
         futures = enq.pop("futures")
         results: list[TensorResult] = []
         for first, n, fut in futures:
@@ -388,8 +557,8 @@ class GreedyPipeline:
         2-D images of shorter vectors (tile_utils.py:96-102); the greedy metric divides by it (mixed_tile_greedy.py:134)."""
         torch = self.torch
         results = self.finish(self.enqueue(x3d, seeds, numel))
-        torch.cuda.current_stream().wait_stream(self.stream)
-        torch.cuda.current_stream().wait_stream(self.copy_stream)
+        for st in (self.stream, self.copy_stream, *self.scan_streams):
+            torch.cuda.current_stream().wait_stream(st)
         return results
 
     def run_steps(self, batches) -> list[TensorResult]:
@@ -412,8 +581,8 @@ class GreedyPipeline:
                 self._unresolved.append(done)
         while self._unresolved:
             self.resolve(self._unresolved.pop(0))
-        torch.cuda.current_stream().wait_stream(self.stream)
-        torch.cuda.current_stream().wait_stream(self.copy_stream)
+        for st in (self.stream, self.copy_stream, *self.scan_streams):
+            torch.cuda.current_stream().wait_stream(st)
         return results
 
     def close(self) -> None:

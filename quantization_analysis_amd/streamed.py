@@ -90,6 +90,8 @@ class ShardEvaluator:
             del xs
             torch.cuda.synchronize()
             pipe = self._pipeline(min(chunk, len(part)))
+            if getattr(pipe, "device_scan", False):
+                pipe.chunk = len(part)   # scan on the device: one K1 launch and one scan launch (a wave per tensor) per batch
             t0 = time.perf_counter()
             results = pipe.run(x3d)
             torch.cuda.synchronize()

@@ -455,8 +455,10 @@ def test_threshold_pipeline_matches_oracle():
         assert pipe.knife_tiles >= 1
 
 
-def test_streamed_pipeline_matches_oracle():
-    """GreedyPipeline (what bench.py times): chunked K1 launches, records over PCIe, threaded host scans.  bf16 storage takes
+@pytest.mark.parametrize("scan", ["device", "host"])
+def test_streamed_pipeline_matches_oracle(scan):
+    """GreedyPipeline (what bench.py times), with the scan on the device (csrc/mtq_scan.hip: maps come back, records stay) and
+    with records over PCIe + threaded host scans: chunked K1 launches.  bf16 storage takes
     the 17-double records + identity bf16 (MTQ_MASK_BF16_IDENTITY), float32 storage the full records; maps, counts and
     columns equal the oracle's greedy search tensor by tensor, with per-tensor seeds."""
     from quantization_analysis_amd.pipeline import GreedyPipeline
@@ -464,7 +466,8 @@ def test_streamed_pipeline_matches_oracle():
     for kind, shape, bf16 in (("normal_bf16", (128, 256), True), ("heavy_bf16", (96, 160), True), ("heavy_f32", (96, 160), False)):
         xs = np.stack([gen(kind, 30 + i, shape) for i in range(5)])
         seeds = [11, 12, 13, 14, 15]
-        pipe = GreedyPipeline(ALL, "pcc", 0.998, 123, chunk=2, workers=3)
+        pipe = GreedyPipeline(ALL, "pcc", 0.998, 123, chunk=2, workers=3, scan=scan)
+        assert pipe.device_scan == (scan == "device")
         try:
             res = pipe.run(dev(xs, bf16=bf16), seeds=seeds)
             res2 = pipe.run(dev(xs, bf16=bf16), seeds=seeds)   # buffers are reused: same answer again
@@ -480,11 +483,12 @@ def test_streamed_pipeline_matches_oracle():
             assert np.array_equal(res2[i].assignment, a)
     # a zero-variance tensor (constant) inside a chunk: the slim scan gives up, the chunk is repeated with the full records
     xs = np.stack([gen("normal_bf16", 90, (64, 128)), np.full((64, 128), 0.5, dtype=np.float32), gen("normal_bf16", 91, (64, 128))])
-    pipe = GreedyPipeline(ALL, "pcc", 0.998, 123, chunk=3, workers=2)
+    pipe = GreedyPipeline(ALL, "pcc", 0.998, 123, chunk=3, workers=2, scan=scan)
     try:
         res = pipe.run(dev(xs, bf16=True))
     finally:
         pipe.close()
+    assert pipe.host_fallbacks == (1 if scan == "device" else 0)   # the device scan hands a zero-denominator tensor back to the host scan
     for i, r in enumerate(res):
         a, counts, _st = orc.greedy(xs[i], ALL, "pcc", 0.998, 123)
         assert np.array_equal(r.assignment, a) and r.counts == counts, i
@@ -500,7 +504,7 @@ def test_streamed_pipeline_matches_oracle():
     # overlapped batches (three record slots): the last batch's results, each batch its own tensors
     b1 = dev(np.stack([gen("normal_bf16", 70 + i, (128, 256)) for i in range(4)]), bf16=True)
     b2x = np.stack([gen("heavy_bf16", 80 + i, (128, 256)) for i in range(4)])
-    pipe = GreedyPipeline(ALL, "pcc", 0.998, 123, chunk=3, workers=2)
+    pipe = GreedyPipeline(ALL, "pcc", 0.998, 123, chunk=3, workers=2, scan=scan)
     try:
         last = pipe.run_steps([b1, dev(b2x, bf16=True), b1, dev(b2x, bf16=True)])
         with pytest.raises(RuntimeError):
@@ -545,7 +549,7 @@ def test_chain_records_on_the_device(monkeypatch):
     got = {}
     for flag in ("1", "0"):
         monkeypatch.setenv("MTQ_CHAIN_RECORDS", flag)
-        pipe = GreedyPipeline(ALL, "pcc", 0.995, 123, chunk=2, workers=2)
+        pipe = GreedyPipeline(ALL, "pcc", 0.995, 123, chunk=2, workers=2, scan="host")
         try:
             got[flag] = pipe.run(xs, seeds=[3, 4, 5, 6, 7])
         finally:
@@ -572,3 +576,105 @@ def test_fast_kernel_strided_view_and_batch_stride():
     got = out.cpu().numpy()
     for i in range(3):
         assert np.array_equal(got[i].view(np.uint64), orc.tile_stats(xs[i], ALL).view(np.uint64)), i
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# H1 on the device (csrc/mtq_scan.hip): the whole greedy search where K1 wrote the records
+# ------------------------------------------------------------------------------------------------------------------
+def _device_scan_vs_host(xs, formats, thr, seeds, mask=None):
+    """xs: (count, rows, cols) device tensor.  Device scan maps == host scan maps (same records), status 0."""
+    import torch
+
+    ident = xs.dtype == torch.bfloat16 and "bf16" in formats and any(f != "bf16" for f in formats)
+    k1 = hb.fmt_mask(formats) & 0xE if ident else hb.fmt_mask(formats)
+    dec = k1 | hb.MASK_BF16_IDENTITY if ident else k1
+    recs = hb.tile_stats_batched(xs, k1)
+    numel = xs.shape[1] * xs.shape[2]
+    sd = torch.tensor(seeds, dtype=torch.int64, device=xs.device)
+    maps, status = hb.greedy_scan_device(recs, dec, formats, "pcc", thr, float(numel), sd)
+    torch.cuda.synchronize()
+    want, _counts, _outs = hb.greedy_run_batch(recs.cpu().numpy(), dec, formats, "pcc", thr, float(numel), seeds, 4)
+    assert status.cpu().tolist() == [0] * xs.shape[0]
+    got = maps.cpu().numpy()
+    for i in range(xs.shape[0]):
+        assert np.array_equal(got[i], want[i]), (i, int((got[i] != want[i]).sum()), formats, thr, seeds[i])
+    return got
+
+
+@pytest.mark.gpu
+def test_device_scan_golden_greedy_cases(golden_dir):
+    """Every pcc case of golden F4 (the reference's maps) through K1 + the device scan."""
+    import json
+
+    import torch
+
+    meta = json.loads((golden_dir / "golden_meta.json").read_text())["f4"]
+    d = np.load(golden_dir / "f4_greedy.npz")
+    n = 0
+    for name, m in meta.items():
+        if m["metric"] != "pcc":
+            continue
+        x = gen(m["kind"], m["seed"], tuple(m["shape"]))
+        x2d, info = hb.to_device_2d(torch.from_numpy(x).to(torch.bfloat16) if m["kind"].endswith("bf16") else x)
+        if x2d.shape[0] * x2d.shape[1] != x.size:
+            continue   # vectors with a ragged last row: their element count is not rows*cols (covered by the host scan)
+        got = _device_scan_vs_host(x2d[None].contiguous(), m["formats"], m["threshold"], [m["algo_seed"]])
+        th, tw = hb.tiles_hw(*x2d.shape)
+        assert np.array_equal(got[0].reshape(th, tw), d[f"{name}_assign"]), name
+        n += 1
+    assert n >= 7
+
+
+@pytest.mark.gpu
+def test_device_scan_headline_tensor_and_batches(golden_dir):
+    """The 4096x4096 headline tensor against the reference's map (golden F11) and a batch of tensors with different seeds."""
+    import hashlib
+    import json
+
+    import torch
+    from tests.inputs import m1_tensor
+
+    f11 = json.loads((golden_dir / "golden_meta_r2.json").read_text())["f11"]["greedy_pcc999_seed123"]
+    x = torch.from_numpy(m1_tensor()).to(torch.bfloat16).cuda()
+    got = _device_scan_vs_host(x[None], ALL, 0.999, [123])
+    assert hashlib.sha256(got[0].reshape(128, 128).tobytes()).hexdigest() == f11["assign_sha256"]
+    g = torch.Generator(device="cuda")
+    g.manual_seed(7)
+    xs = (torch.randn((6, 1024, 2048), generator=g, device="cuda") * 0.02).to(torch.bfloat16)
+    _device_scan_vs_host(xs, ALL, 0.999, [1, 2, 3, 2**31 - 1, 2**40 + 7, 123])
+    _device_scan_vs_host(xs, ["bfp8", "bfp4", "bfp2"], 0.995, [5, 6, 7, 8, 9, 10])
+    _device_scan_vs_host(xs.float(), ["bfp4", "bfp8", "bf16"], 0.99, [11, 12, 13, 14, 15, 16])     # float32 storage, base bfp4, "upgrades"
+    _device_scan_vs_host(xs, ["bf16", "bfp2"], 0.9, [21, 22, 23, 24, 25, 26])
+    _device_scan_vs_host(xs[:2], ALL, 0.9999999, [31, 32])                                           # base pass fails: every tile fixed at once
+    heavy = (torch.randn((3, 512, 512), generator=g, device="cuda") * 0.02 * torch.exp(1.5 * torch.randn((3, 512, 512), generator=g, device="cuda"))).to(torch.bfloat16)
+    for thr in (0.9, 0.99, 0.999, 0.99999):
+        _device_scan_vs_host(heavy, ALL, thr, [41, 42, 43])
+    small = (torch.randn((4, 32, 128), generator=g, device="cuda") * 0.02).to(torch.bfloat16)           # 4 tiles: shorter than a wave
+    _device_scan_vs_host(small, ALL, 0.999, [51, 52, 53, 54])
+    _device_scan_vs_host(small[:, :, :32].contiguous(), ALL, 0.999, [61, 62, 63, 64])                   # a single tile
+
+
+@pytest.mark.gpu
+def test_device_scan_large_tensor_global_order():
+    """More than 32768 tiles: the visiting order lives in global scratch instead of LDS (Llama-3-8B gate_proj shape)."""
+    import torch
+
+    g = torch.Generator(device="cuda")
+    g.manual_seed(3)
+    x = (torch.randn((2, 14336, 4096), generator=g, device="cuda") * 0.02).to(torch.bfloat16)
+    _device_scan_vs_host(x, ALL, 0.999, [123, 77])
+
+
+@pytest.mark.gpu
+def test_device_scan_refusals_and_zero_variance():
+    import torch
+
+    x = torch.zeros((2, 64, 128), dtype=torch.bfloat16, device="cuda")           # zero variance: status 1, the host scan is needed
+    recs = hb.tile_stats_batched(x, 0xE)
+    sd = torch.tensor([5, 6], dtype=torch.int64, device="cuda")
+    _maps, status = hb.greedy_scan_device(recs, 0xE | hb.MASK_BF16_IDENTITY, ALL, "pcc", 0.999, 64.0 * 128, sd)
+    assert status.cpu().tolist() == [1, 1]
+    with pytest.raises(hb.MtqError):
+        hb.greedy_scan_device(recs, 0xE | hb.MASK_BF16_IDENTITY, ALL, "mae", 1e-3, 64.0 * 128, sd)
+    with pytest.raises(hb.MtqError):
+        hb.greedy_scan_device(recs, 0xE | hb.MASK_BF16_IDENTITY, ["bfp8", "bfp8"], "pcc", 0.9, 64.0 * 128, sd)
