@@ -274,13 +274,14 @@ int mtq_column_sums_device_batched(const double *stats, int64_t count, int64_t t
  * (device, int8 codes) are the host's maps.  status[count] (device): 0 = done; 1 = a zero denominator turned up (the decision
  * needs Σ|x−y|: run mtq_greedy_run on that tensor's records); 2 = internal budget exhausted (same remedy).  Serves the pcc
  * metric, distinct formats (fmt_mask may carry MTQ_MASK_BF16_IDENTITY), tiles <= MTQ_SCAN_DEVICE_MAX_TILES; anything else
- * returns MTQ_ERR_UNSUPPORTED and the caller uses the host scan.  seeds[count]: device array of non-zero seeds.  scratch:
+ * returns MTQ_ERR_UNSUPPORTED and the caller uses the host scan.  seeds[count]: device array of non-zero seeds.  counts
+ * [count][4] (device, may be NULL): tiles per format code of every finished map (np.bincount of the map).  scratch:
  * device memory of mtq_greedy_scan_scratch_bytes(count, tiles) bytes.  Asynchronous on `stream`. */
 #define MTQ_SCAN_DEVICE_MAX_TILES (1 << 22)
 size_t mtq_greedy_scan_scratch_bytes(int64_t count, int64_t tiles);
 int mtq_greedy_scan_device(const double *stats, int64_t count, int64_t tiles, uint32_t fmt_mask, const int *formats, int n_formats,
                            int metric, double threshold, double elem_count, const uint64_t *seeds, int8_t *maps, int32_t *status,
-                           void *scratch, size_t scratch_bytes, void *stream);
+                           int32_t *counts, void *scratch, size_t scratch_bytes, void *stream);
 
 /* Diagnostics (no reference counterpart).  K1's persistent waves claim their units from device counters that come from a
  * per-device ring of slots (csrc/mtq_slot_ring.hpp): a slot is handed out again only behind the event recorded after its

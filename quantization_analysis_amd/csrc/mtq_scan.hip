@@ -267,6 +267,7 @@ struct ScanArgs {
     const uint64_t *seeds;    // [count]
     int8_t *maps;             // [count][tiles] out
     int32_t *status;          // [count] out: 0 ok, 1 zero denominator (host scan needed), 2 internal budget exhausted
+    int32_t *counts;          // [count][4] out (may be null): tiles per format code in the finished map
     uint32_t *order_g;        // [count][tiles] scratch (tiles > kScanMaxTilesLds)
     double *delta;            // [count][tiles][4] scratch: Δ(Σy, Σy², Σxy) of the visit and the tile's previous code
     const U128 *jump_a, *jump_g;   // [kJump]
@@ -498,8 +499,19 @@ __device__ void scan_tensor(const ScanArgs &a, const Order &ord, int b, unsigned
         stamp(4 + 3 * (p - 1));
     }
     mem_wait();
-    for (int t = lane; t < T; t += 64) map[t] = (int8_t)((uint8_t)ld_l2(map + t) & 0x7Fu);
-    if (lane == 0) a.status[b] = status;
+    int cnt[MTQ_NUM_TILE_FORMATS] = {0, 0, 0, 0};
+    for (int t0 = 0; t0 < T; t0 += 64) {
+        const int t = t0 + lane;
+        int code = -1;
+        if (t < T) { code = (int)((uint8_t)ld_l2(map + t) & 0x7Fu); map[t] = (int8_t)code; }
+#pragma unroll
+        for (int c = 0; c < MTQ_NUM_TILE_FORMATS; ++c) cnt[c] += __builtin_popcountll(__ballot(code == c));
+    }
+    if (lane == 0) {
+        a.status[b] = status;
+        if (a.counts)
+            for (int c = 0; c < MTQ_NUM_TILE_FORMATS; ++c) a.counts[b * MTQ_NUM_TILE_FORMATS + c] = cnt[c];
+    }
 }
 
 __global__ __launch_bounds__(64) void greedy_scan_pcc_lds(ScanArgs a)
@@ -568,7 +580,7 @@ extern "C" size_t mtq_greedy_scan_scratch_bytes(int64_t count, int64_t tiles)
 
 extern "C" int mtq_greedy_scan_device(const double *stats, int64_t count, int64_t tiles, uint32_t fmt_mask, const int *formats, int n_formats,
                                       int metric, double threshold, double elem_count, const uint64_t *seeds, int8_t *maps, int32_t *status,
-                                      void *scratch, size_t scratch_bytes, void *stream)
+                                      int32_t *counts, void *scratch, size_t scratch_bytes, void *stream)
 {
     if (!stats || !formats || !seeds || !maps || !status || !scratch) return fail(MTQ_ERR_INVALID, "null argument");
     if (count <= 0 || count > (1 << 20) || tiles <= 0) return fail(MTQ_ERR_INVALID, "count and tiles must be positive");
@@ -599,6 +611,7 @@ extern "C" int mtq_greedy_scan_device(const double *stats, int64_t count, int64_
     a.seeds = seeds;
     a.maps = maps;
     a.status = status;
+    a.counts = counts;
     if (int rc = require_device()) return rc;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return fail(MTQ_ERR_HIP, "hipGetDevice failed");

@@ -109,7 +109,7 @@ def lib() -> ctypes.CDLL:
     L.mtq_greedy_run_chain_batch.argtypes = [vp, vp, ci, i64, i64, vp, ci, dbl, dbl, vp, vp, vp, ci]
     L.mtq_greedy_scan_scratch_bytes.argtypes = [i64, i64]
     L.mtq_greedy_scan_scratch_bytes.restype = ctypes.c_size_t
-    L.mtq_greedy_scan_device.argtypes = [vp, i64, i64, u32, vp, ci, ci, dbl, dbl, vp, vp, vp, vp, ctypes.c_size_t, vp]
+    L.mtq_greedy_scan_device.argtypes = [vp, i64, i64, u32, vp, ci, ci, dbl, dbl, vp, vp, vp, vp, vp, ctypes.c_size_t, vp]
     L.mtq_selftest_slot_ring.restype = ci
     if L.mtq_version() < 123:
         raise MtqError("libmtq_hip.so is older than this package")
@@ -435,7 +435,7 @@ def device_scan_supported(formats, metric: str, tiles: int) -> bool:
 
 
 def greedy_scan_device(stats_dev, mask: int, formats, metric: str, threshold: float, elem_count: float, seeds_dev, maps_out=None,
-                       status_out=None, scratch=None):
+                       status_out=None, scratch=None, counts_out=None):
     """H1 on the device over FULL records [count, tiles, rec] where K1 wrote them → (int8 [count, tiles] maps, int32 [count]
     status) device tensors, asynchronous on the current stream.  seeds_dev: uint64/int64 device tensor [count]."""
     torch = _torch()
@@ -447,8 +447,8 @@ def greedy_scan_device(stats_dev, mask: int, formats, metric: str, threshold: fl
     if scratch is None or scratch.numel() < need:
         scratch = torch.empty((need,), dtype=torch.uint8, device=stats_dev.device)
     check(lib().mtq_greedy_scan_device(stats_dev.data_ptr(), count, T, mask, fm, len(formats), METRIC_CODE[metric], float(threshold),
-                                       float(elem_count), seeds_dev.data_ptr(), maps.data_ptr(), status.data_ptr(), scratch.data_ptr(),
-                                       int(scratch.numel()), _stream_ptr()))
+                                       float(elem_count), seeds_dev.data_ptr(), maps.data_ptr(), status.data_ptr(),
+                                       counts_out.data_ptr() if counts_out is not None else None, scratch.data_ptr(), int(scratch.numel()), _stream_ptr()))
     return maps, status
 
 

@@ -326,7 +326,7 @@ class GreedyPipeline:
                  "dev": torch.empty((count, tiles, rec), dtype=torch.float64, device=device),
                  "maps_dev": torch.zeros((count, tiles), dtype=torch.int8, device=device),
                  "status_dev": torch.zeros((count,), dtype=torch.int32, device=device),
-                 "counts_dev": torch.zeros((count, len(MIXED_TILE_FORMATS)), dtype=torch.int64, device=device),
+                 "counts_dev": torch.zeros((count, len(MIXED_TILE_FORMATS)), dtype=torch.int32, device=device),
                  "seeds_dev": torch.zeros((count,), dtype=torch.int64, device=device),
                  "seeds_host": torch.zeros((count,), dtype=torch.int64, pin_memory=True),
                  "scratch": torch.empty((int(hb.lib().mtq_greedy_scan_scratch_bytes(count, tiles)),), dtype=torch.uint8, device=device),
@@ -334,7 +334,7 @@ class GreedyPipeline:
                  "pure_maps": [torch.full((count, tiles), MIXED_TILE_FORMATS.index(f), dtype=torch.int8, device=device) for f in self.pure_formats],
                  "maps_host": torch.zeros((count, tiles), dtype=torch.int8, pin_memory=True),
                  "status_host": torch.zeros((count,), dtype=torch.int32, pin_memory=True),
-                 "counts_host": torch.zeros((count, len(MIXED_TILE_FORMATS)), dtype=torch.int64, pin_memory=True),
+                 "counts_host": torch.zeros((count, len(MIXED_TILE_FORMATS)), dtype=torch.int32, pin_memory=True),
                  "sums_host": torch.zeros((P, count, 7), dtype=torch.float64, pin_memory=True),
                  "free": None}
             self._devbufs[slot] = b
@@ -355,7 +355,6 @@ class GreedyPipeline:
         sh[:] = self.seed if seeds is None else np.asarray([int(v) for v in seeds], dtype=np.int64)
         if (sh == 0).any():
             raise ValueError("seed 0 means 'draw a random seed' in the reference; pass non-zero seeds")
-        codes = torch.arange(len(MIXED_TILE_FORMATS), dtype=torch.int8, device=x3d.device)
         per = int(hb.lib().mtq_greedy_scan_scratch_bytes(1, tiles))
         pending = []
         self.stream.wait_stream(torch.cuda.current_stream())
@@ -381,8 +380,8 @@ class GreedyPipeline:
                 recs = b["dev"][first:first + n]
                 maps = b["maps_dev"][first:first + n]
                 hb.greedy_scan_device(recs, dec_mask, self.tile_formats, self.metric, self.threshold, float(n_el), b["seeds_dev"][first:first + n],
-                                      maps_out=maps, status_out=b["status_dev"][first:first + n], scratch=b["scratch"][first * per:(first + n) * per])
-                b["counts_dev"][first:first + n] = (maps.unsqueeze(-1) == codes).sum(dim=1)
+                                      maps_out=maps, status_out=b["status_dev"][first:first + n], scratch=b["scratch"][first * per:(first + n) * per],
+                                      counts_out=b["counts_dev"][first:first + n])
                 hb.check(hb.lib().mtq_column_sums_device_batched(recs.data_ptr(), n, tiles, dec_mask, maps.data_ptr(),
                                                                  b["sums_dev"][0, first:first + n].data_ptr(), scan_stream.cuda_stream))
                 for k, pm in enumerate(b["pure_maps"]):

@@ -82,6 +82,21 @@ def run(cases: int, seed: int) -> int:
                 full = hb.tile_stats(xd, 0xF).cpu().numpy()
                 g, _c2, _o = hb.greedy_run(full, 0xF, ALL, "pcc", thr, float(x.size), 7)
                 ok_g = np.array_equal(g.reshape(a.shape), a)
+                # H1 on the device (csrc/mtq_scan.hip) on the same full records, and on a random format order / subset
+                recs_d = torch.from_numpy(full).cuda()[None]
+                sd = torch.tensor([7], dtype=torch.int64, device="cuda")
+                cnt = torch.zeros((1, 4), dtype=torch.int32, device="cuda")
+                dm, ds = hb.greedy_scan_device(recs_d, 0xF, ALL, "pcc", thr, float(x.size), sd, counts_out=cnt)
+                if int(ds.cpu()[0]) == 0:   # status 1 (zero denominator met) hands the tensor to the host scan
+                    ok_g &= np.array_equal(dm.cpu().numpy().reshape(a.shape), a)
+                    ok_g &= cnt.cpu().numpy()[0].tolist() == [int(np.sum(a == k)) for k in range(4)]
+                order = [ALL[k] for k in rng.permutation(4)[: int(rng.integers(1, 5))]]
+                s2 = int(rng.integers(1, 2**31))
+                gh, _ch, _oh = hb.greedy_run(full, 0xF, order, "pcc", thr, float(x.size), s2)
+                sd[0] = s2
+                dm, ds = hb.greedy_scan_device(recs_d, 0xF, order, "pcc", thr, float(x.size), sd)
+                if int(ds.cpu()[0]) == 0:
+                    ok_g &= np.array_equal(dm.cpu().numpy()[0], gh)
                 # the record layouts of the streamed driver: slim (3 doubles per format), slim + identity bf16, chain records
                 keep = [0, 1] + [2 + 5 * s_ + k for s_ in range(4) for k in range(3)]
                 try:

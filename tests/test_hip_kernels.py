@@ -591,10 +591,12 @@ def _device_scan_vs_host(xs, formats, thr, seeds, mask=None):
     recs = hb.tile_stats_batched(xs, k1)
     numel = xs.shape[1] * xs.shape[2]
     sd = torch.tensor(seeds, dtype=torch.int64, device=xs.device)
-    maps, status = hb.greedy_scan_device(recs, dec, formats, "pcc", thr, float(numel), sd)
+    cnt = torch.zeros((xs.shape[0], 4), dtype=torch.int32, device=xs.device)
+    maps, status = hb.greedy_scan_device(recs, dec, formats, "pcc", thr, float(numel), sd, counts_out=cnt)
     torch.cuda.synchronize()
-    want, _counts, _outs = hb.greedy_run_batch(recs.cpu().numpy(), dec, formats, "pcc", thr, float(numel), seeds, 4)
+    want, counts, _outs = hb.greedy_run_batch(recs.cpu().numpy(), dec, formats, "pcc", thr, float(numel), seeds, 4)
     assert status.cpu().tolist() == [0] * xs.shape[0]
+    assert np.array_equal(cnt.cpu().numpy(), counts)
     got = maps.cpu().numpy()
     for i in range(xs.shape[0]):
         assert np.array_equal(got[i], want[i]), (i, int((got[i] != want[i]).sum()), formats, thr, seeds[i])
