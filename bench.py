@@ -215,6 +215,20 @@ def main() -> None:
             dist.barrier()
         torch.cuda.synchronize()
 
+    # K1 alone (no scan, no copies beside it): the same launch the steps issue, HIP events on the current stream
+    k1_mask, _hm, _slim = pipe._layout(batch)
+    alone_out = hb.tile_stats_batched(batch[: args.chunk], k1_mask)
+    torch.cuda.synchronize()
+    alone = []
+    for _ in range(5):
+        a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a0.record()
+        hb.tile_stats_batched(batch[: args.chunk], k1_mask, out=alone_out)
+        a1.record()
+        a1.synchronize()
+        alone.append(a0.elapsed_time(a1))
+    k1_alone_ms = sorted(alone)[len(alone) // 2]
+    del alone_out
     pipe.reserve(batch)  # record buffers of both slots + scan threads: allocations, not steps
     res = pipe.run_steps(batch for _ in range(args.warmup))
     pipe.timing.drain()
@@ -253,6 +267,17 @@ def main() -> None:
                 traffic = json.loads(tfile.read_text()).get("hbm_bytes_per_tile") * tiles_per_launch  # measured B/tile x tiles of this run's launches
             except Exception:
                 traffic = None
+        valu = None
+        vfile = ROOT / "profiles" / "k1_valu.json"   # VALU instructions per tile from a separate rocprofv3 --pmc pass
+        if vfile.exists():
+            try:
+                v = json.loads(vfile.read_text())
+                valu = {"valu_insts_per_tile": v["valu_insts_per_tile"], "avg_issue_cycles_per_inst": v["avg_issue_cycles_per_inst"],
+                        "valu_frac": v["valu_insts_per_tile"] * tiles_per_launch / v["simds"] * v["avg_issue_cycles_per_inst"] / (k_ms * 1e-3 * v["clock_hz"]),
+                        "note": "share of the launch during which every SIMD's VALU issue port is taken (instructions per SIMD x issue cost / launch "
+                                "time at 2.4 GHz): the kernel is VALU-issue bound, not HBM bound", "source": "profiles/k1_valu.json"}
+            except Exception:
+                valu = None
         out = {
             "metric": "32x32 tiles/s for mixed-tile-greedy (bf16->BFP{8,4,2}); achieved HBM GB/s vs peak",
             "value": world * args.steps * tiles_per_step / dt,
@@ -271,7 +296,12 @@ def main() -> None:
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_source": "profiles/k1_traffic.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, B/tile x this run's tiles per launch)" if traffic is not None else None,
                          "launch_ms": k_ms, "tiles_per_launch": tiles_per_launch, "launches": kt.launches,
-                         "kernel_tiles_per_s": tiles_per_launch / (k_ms * 1e-3)},
+                         "kernel_tiles_per_s": tiles_per_launch / (k_ms * 1e-3),
+                         "note": "launch_ms / achieved / frac: HIP events around the K1 launches of the timed region, i.e. with the previous steps' scan "
+                                 "kernels (one wave per tensor) and copies running beside them; kernel_alone: the same launch with nothing beside it",
+                         "kernel_alone": {"launch_ms": k1_alone_ms, "achieved": BYTES_PER_TILE_READ * args.chunk * (ROWS // 32) * (COLS // 32) / (k1_alone_ms * 1e-3) / 1e9,
+                                          "frac": BYTES_PER_TILE_READ * args.chunk * (ROWS // 32) * (COLS // 32) / (k1_alone_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                         "valu": valu},
             "summary": {"tensors": int(all_rows.shape[0]), "mean_pcc": float(all_rows[:, 2].mean()),
                         "counts_bf16_bfp8_bfp4_bfp2": [int(all_rows[:, 6 + i].sum()) for i in range(4)]},
         }

@@ -355,10 +355,9 @@ def _evaluate_shard(shard, tensor_names, index, algorithms, selected_algo, forma
                 groups.setdefault(k, []).append((i, tensor_names[i]))
         ev = streamed.ShardEvaluator(index, selected_algo, formats, device, ROW_W, FORMAT_BYTES_PER_ELEM)
         try:
-            for k, items in groups.items():
-                for idx, (rows, assignment) in ev.run_group(k, items).items():
-                    rows_by_idx[idx] = rows
-                    deferred.append((idx, tensor_names[idx], assignment))
+            for idx, (rows, assignment) in ev.run_groups(groups).items():
+                rows_by_idx[idx] = rows
+                deferred.append((idx, tensor_names[idx], assignment))
         finally:
             ev.close()
         if ev.compute_tiles:

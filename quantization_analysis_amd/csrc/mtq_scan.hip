@@ -33,7 +33,8 @@
 namespace mtq {
 namespace {
 
-constexpr int kScanMaxTilesLds = 32768;   // visiting order kept in LDS as 16-bit tile ids up to here (64 KiB)
+constexpr int kScanMaxTilesLds = 32768;   // visiting order kept in LDS as 16-bit tile ids up to here (64 KiB: K1 blocks still fit beside the scan block;
+                                          // 65536 was measured: 7.6 against 8.4 ms per 57 344-tile tensor alone, but K1 loses the CU and `wq` Llama-3-8B got slower)
 constexpr int kTagSlots = 16384;          // conflict tags: one byte per hashed position
 constexpr int kHitWords = kTagSlots / 32;
 constexpr int kJump = 34;                 // jump-ahead table entries (q = 0..33)

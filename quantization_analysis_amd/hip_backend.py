@@ -427,6 +427,7 @@ def greedy_run(stats: np.ndarray, mask: int, formats, metric: str, threshold: fl
 
 
 SCAN_DEVICE_MAX_TILES = 1 << 22
+SCAN_LDS_MAX_TILES = 32768      # csrc/mtq_scan.hip kScanMaxTilesLds: visiting order in LDS up to here, in global scratch above
 
 
 def device_scan_supported(formats, metric: str, tiles: int) -> bool:

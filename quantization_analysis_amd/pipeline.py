@@ -142,6 +142,7 @@ class GreedyPipeline:
         self.copy_stream = torch.cuda.Stream()   # records D2H, overlapped with the next chunk's K1
         self.col_stream = torch.cuda.Stream()    # maps up / column sums / sums down of a finished batch (must not queue behind the next batch's copies)
         self.timing = KernelTiming()
+        self.SLOTS = type(self).SLOTS            # per instance: callers that stream many shape groups raise it (streamed.py)
         if scan not in ("auto", "host", "device"):
             raise ValueError("scan must be 'auto', 'host' or 'device'")
         can = hb.device_scan_supported(self.tile_formats, self.metric, 1)
@@ -214,6 +215,7 @@ class GreedyPipeline:
         th, tw = hb.tiles_hw(rows, cols)
         k1_mask, host_mask, slim = self._layout(x3d)
         if self._use_device_scan(th * tw):
+            self._warm_device_scan(x3d.device)
             for slot in range(self.SLOTS):
                 b = self._device_buffers(slot, count, th * tw, hb.record_doubles(k1_mask), x3d.device)
                 b["dev"].zero_()
@@ -315,29 +317,47 @@ class GreedyPipeline:
 
     def _device_buffers(self, slot: int, count: int, tiles: int, rec: int, device) -> dict:
         """Per record slot: K1's full records, the scan's maps / status / scratch, per-format tile counts and the column sums
-        (searched map + pure formats), with pinned host mirrors of what comes back: 1 B/tile + a few numbers per tensor."""
-        key = (count, tiles, rec, str(device))
+        (searched map + pure formats), with pinned host mirrors of what comes back: 1 B/tile + a few numbers per tensor.
+        The storage is flat and only ever grows: batches of another shape (a model's next shape group) get views of it, so that no
+        device or pinned allocation (milliseconds each) lands between two batches."""
+        torch = self.torch
         b = self._devbufs.get(slot)
-        if b is None or b["key"] != key:
-            torch = self.torch
-            n_scratch = int(hb.lib().mtq_columns_scratch_doubles())
-            P = 1 + len(self.pure_formats)
-            b = {"key": key,
-                 "dev": torch.empty((count, tiles, rec), dtype=torch.float64, device=device),
-                 "maps_dev": torch.zeros((count, tiles), dtype=torch.int8, device=device),
-                 "status_dev": torch.zeros((count,), dtype=torch.int32, device=device),
-                 "counts_dev": torch.zeros((count, len(MIXED_TILE_FORMATS)), dtype=torch.int32, device=device),
-                 "seeds_dev": torch.zeros((count,), dtype=torch.int64, device=device),
-                 "seeds_host": torch.zeros((count,), dtype=torch.int64, pin_memory=True),
-                 "scratch": torch.empty((int(hb.lib().mtq_greedy_scan_scratch_bytes(count, tiles)),), dtype=torch.uint8, device=device),
-                 "sums_dev": torch.zeros((P, count, n_scratch), dtype=torch.float64, device=device),
-                 "pure_maps": [torch.full((count, tiles), MIXED_TILE_FORMATS.index(f), dtype=torch.int8, device=device) for f in self.pure_formats],
-                 "maps_host": torch.zeros((count, tiles), dtype=torch.int8, pin_memory=True),
-                 "status_host": torch.zeros((count,), dtype=torch.int32, pin_memory=True),
-                 "counts_host": torch.zeros((count, len(MIXED_TILE_FORMATS)), dtype=torch.int32, pin_memory=True),
-                 "sums_host": torch.zeros((P, count, 7), dtype=torch.float64, pin_memory=True),
-                 "free": None}
+        if b is None or b["device"] != str(device):
+            b = {"device": str(device), "flat": {}, "key": None, "free": None}
             self._devbufs[slot] = b
+        key = (count, tiles, rec)
+        if b["key"] == key:
+            return b
+        n_scratch = int(hb.lib().mtq_columns_scratch_doubles())
+        P = 1 + len(self.pure_formats)
+        nf = len(MIXED_TILE_FORMATS)
+
+        def flat(name, numel, dtype, pinned=False):
+            t = b["flat"].get(name)
+            if t is None or t.numel() < numel:
+                t = torch.zeros((int(numel * 1.25) + 16,), dtype=dtype, pin_memory=True) if pinned else \
+                    torch.zeros((int(numel * 1.25) + 16,), dtype=dtype, device=device)
+                b["flat"][name] = t
+            return t[:numel]
+
+        b.update({
+            "key": key,
+            "dev": flat("dev", count * tiles * rec, torch.float64).view(count, tiles, rec),
+            "maps_dev": flat("maps_dev", count * tiles, torch.int8).view(count, tiles),
+            "status_dev": flat("status_dev", count, torch.int32),
+            "counts_dev": flat("counts_dev", count * nf, torch.int32).view(count, nf),
+            "seeds_dev": flat("seeds_dev", count, torch.int64),
+            "seeds_host": flat("seeds_host", count, torch.int64, pinned=True),
+            "scratch": flat("scratch", int(hb.lib().mtq_greedy_scan_scratch_bytes(count, tiles)), torch.uint8),
+            "sums_dev": flat("sums_dev", P * count * n_scratch, torch.float64).view(P, count, n_scratch),
+            "pure_maps": [flat(f"pure_{f}", count * tiles, torch.int8).view(count, tiles) for f in self.pure_formats],
+            "maps_host": flat("maps_host", count * tiles, torch.int8, pinned=True).view(count, tiles),
+            "status_host": flat("status_host", count, torch.int32, pinned=True),
+            "counts_host": flat("counts_host", count * nf, torch.int32, pinned=True).view(count, nf),
+            "sums_host": flat("sums_host", P * count * 7, torch.float64, pinned=True).view(P, count, 7),
+        })
+        for f, pm in zip(self.pure_formats, b["pure_maps"]):
+            pm.fill_(MIXED_TILE_FORMATS.index(f))
         return b
 
     def _enqueue_device(self, x3d, seeds, numel, slot: int, k1_mask: int, dec_mask: int, th: int, tw: int) -> dict:
@@ -346,10 +366,14 @@ class GreedyPipeline:
         import time
 
         t_enq = time.perf_counter()
+        trace = os.environ.get("MTQ_PIPE_TRACE") == "1"
+        marks = []
         torch = self.torch
         count, rows, cols = x3d.shape
         tiles = th * tw
         b = self._device_buffers(slot, count, tiles, hb.record_doubles(k1_mask), x3d.device)
+        if trace:
+            marks.append(("buffers", time.perf_counter()))
         n_el = rows * cols if numel is None else int(numel)
         sh = b["seeds_host"].numpy()
         sh[:] = self.seed if seeds is None else np.asarray([int(v) for v in seeds], dtype=np.int64)
@@ -372,6 +396,8 @@ class GreedyPipeline:
                 hb.tile_stats_batched(x3d[first:first + n], k1_mask, out=b["dev"][first:first + n])
                 e1.record(self.stream)
             self.timing.events.append((e0, e1, n * tiles))
+            if trace:
+                marks.append(("k1", time.perf_counter()))
             scan_stream.wait_event(e1)
             with torch.cuda.stream(scan_stream):
                 # the chunk's seeds go up on its own scan stream (on the copy stream they would queue behind the previous batch's
@@ -389,6 +415,8 @@ class GreedyPipeline:
                                                                      b["sums_dev"][1 + k, first:first + n].data_ptr(), scan_stream.cuda_stream))
                 scanned = torch.cuda.Event()
                 scanned.record(scan_stream)
+            if trace:
+                marks.append(("scan+sums", time.perf_counter()))
             self.copy_stream.wait_event(scanned)
             with torch.cuda.stream(self.copy_stream):
                 b["maps_host"][first:first + n].copy_(maps, non_blocking=True)
@@ -403,6 +431,14 @@ class GreedyPipeline:
                "seeds": sh.copy()}
         self._open.append(enq)
         self.host_seconds["enqueue"] += time.perf_counter() - t_enq
+        if trace:
+            marks.append(("copies", time.perf_counter()))
+            prev = t_enq
+            parts = []
+            for name, t in marks:
+                parts.append(f"{name} {1e3 * (t - prev):.2f}")
+                prev = t
+            print(f"[pipe] enqueue {count} x {tiles} tiles: " + ", ".join(parts) + " ms", flush=True)
         return enq
 
     def _finish_device(self, enq: dict) -> list[TensorResult]:
@@ -550,6 +586,60 @@ class GreedyPipeline:
                     r.pure = {}
                 r.pure[f] = (float(c[0]), float(c[1]), float(c[2]))
         enq["dev"] = None
+
+    def _warm_device_scan(self, device) -> None:
+        """One-time costs of the device-scan route, paid here instead of inside the first batches: every scan stream's hardware queue
+        (created on first use, milliseconds each) and the first launch of both scan kernel variants (code load, LDS limit)."""
+        if getattr(self, "_warmed", None) == str(device):
+            return
+        torch = self.torch
+        rec = hb.record_doubles(0xF)
+        seeds = torch.ones((1,), dtype=torch.int64, device=device)
+        for i, st in enumerate(self.scan_streams):
+            with torch.cuda.stream(st):
+                tiles = 1 if i % 2 == 0 else hb.SCAN_LDS_MAX_TILES + 1      # visiting order in LDS / in global scratch
+                hb.greedy_scan_device(torch.zeros((1, tiles, rec), dtype=torch.float64, device=device), 0xF, ["bf16", "bfp8"], "pcc", 0.5, float(tiles * 1024), seeds)
+        pinned = torch.zeros((16,), dtype=torch.int8, pin_memory=True)
+        for st in (self.stream, self.copy_stream):
+            with torch.cuda.stream(st):
+                pinned.copy_(torch.zeros((16,), dtype=torch.int8, device=device), non_blocking=True)
+        torch.cuda.synchronize()
+        self._warmed = str(device)
+
+    def prepare(self, batches) -> None:
+        """Grow every record slot's storage to the largest of `batches` (device and pinned allocations cost milliseconds: not between
+        two batches of a timed run) and pay the route's one-time costs.  Device-scan mode only; the host-scan mode allocates per
+        shape as before."""
+        first = True
+        for x3d in batches:
+            if first and self.device_scan:
+                self._warm_device_scan(x3d.device)
+                with self.torch.cuda.stream(self.stream):
+                    hb.tile_stats_batched(x3d[:1], self._layout(x3d)[0])  # K1's code object, the work-counter ring, the launch stream's queue
+                first = False
+            count, rows, cols = x3d.shape
+            th, tw = hb.tiles_hw(rows, cols)
+            if not self._use_device_scan(th * tw):
+                continue
+            k1_mask, _hm, _slim = self._layout(x3d)
+            for slot in range(self.SLOTS):
+                self._device_buffers(slot, count, th * tw, hb.record_doubles(k1_mask), x3d.device)
+        self.torch.cuda.synchronize()
+
+    def run_batches(self, batches, seeds=None) -> list[list[TensorResult]]:
+        """Batches of possibly different shapes (a model's shape groups), SLOTS of them in flight: a batch's scans and downloads
+        run beside the next batches' K1.  → the results of every batch, in order."""
+        torch = self.torch
+        out, open_ = [], []
+        for i, x3d in enumerate(batches):
+            open_.append(self.enqueue(x3d, None if seeds is None else seeds[i]))
+            if len(open_) == self.SLOTS:
+                out.append(self.finish(open_.pop(0)))
+        while open_:
+            out.append(self.finish(open_.pop(0)))
+        for st in (self.stream, self.copy_stream, *self.scan_streams):
+            torch.cuda.current_stream().wait_stream(st)
+        return out
 
     def run(self, x3d, seeds=None, numel: int | None = None) -> list[TensorResult]:
         """One batch, start to end (enqueue + finish).  numel: the tensors' element count when the matrices are zero-filled

@@ -20,7 +20,9 @@ from .quantization_formats import SUPPORTED_FORMATS
 
 STREAMED_ALGOS = {"mixed-tile-greedy", "mixed-tile-threshold"}
 MAX_BATCH_TILES = 1 << 21      # tiles per pipeline batch: bounds the record buffers (≈ 0.3 GB device + 0.2 GB pinned per slot)
-K1_LAUNCH_TILES = 1 << 19      # tiles per K1 launch, the size bench.py launches (32 x 4096²)
+K1_LAUNCH_TILES = 1 << 19      # tiles per K1 launch with the host scan (32 x 4096²: a chunk's records cross PCIe beside the next chunk's K1)
+MAX_SLOTS = int(__import__("os").environ.get("MTQ_WQ_MAX_SLOTS", "3"))   # record slots of the streamed pipeline (K1 records + scan scratch of a batch: a few hundred MB each)
+MAX_WINDOW_BYTES = 48 << 30    # inputs resident in HBM at once (288 GB per MI355X): the loader fills a window, the pipeline then streams it
 
 
 def streamable(algo, formats, args) -> bool:
@@ -56,7 +58,7 @@ class ShardEvaluator:
         self.k1_tiles = 0
         self._pipe = None
 
-    def _pipeline(self, chunk: int):
+    def _pipeline(self, chunk: int):   # one pipeline per evaluator: its record slots grow to the largest batch and are reused
         a = self.algo
         if a.name == "mixed-tile-greedy":
             if self._pipe is None:
@@ -68,54 +70,94 @@ class ShardEvaluator:
             self._pipe.chunk = chunk
         return self._pipe
 
-    def run_group(self, key, items):
-        """items: [(tensor idx, name)] of one (rows, cols, storage) group → {idx: (rows [R, ROW_W], assignment int8 map)}."""
+    def _load_batch(self, rows_, cols_, part):
+        """→ (x3d on the device, per-tensor (min, mean, max, mean|x|, max|x|)) — the loader; not part of the timed pipeline."""
         import torch
 
-        rows_, cols_, _dtype = key
-        tiles = -(-rows_ // 32) * -(-cols_ // 32)
-        per_batch = max(1, MAX_BATCH_TILES // tiles)
-        chunk = max(1, K1_LAUNCH_TILES // tiles)
+        xs = [self.index.load(n, device=self.device) for _i, n in part]
+        metas = []
+        for x in xs:
+            xf = x.float()
+            ax = xf.abs()
+            metas.append((float(xf.min()), float(xf.mean()), float(xf.max()), float(ax.mean()), float(ax.max())))
+            del xf, ax
+        return torch.stack([x.reshape(rows_, cols_) for x in xs]), metas
+
+    def _rows(self, part, results, metas, numel, per):
         out = {}
-        for b0 in range(0, len(items), per_batch):
-            part = items[b0:b0 + per_batch]
-            xs = [self.index.load(n, device=self.device) for _i, n in part]
-            x3d = torch.stack([x.reshape(rows_, cols_) for x in xs])
-            metas = []
-            for x in xs:
-                xf = x.float()
-                ax = xf.abs()
-                metas.append((float(xf.min()), float(xf.mean()), float(xf.max()), float(ax.mean()), float(ax.max())))
-                del xf, ax
-            del xs
+        for (idx, _name), r, m in zip(part, results, metas):
+            rows = []
+            for f in self.formats:   # comp 0 = none (wq:589-590)
+                if f in MIXED_TILE_FORMATS:
+                    pcc, mae, atol = r.pure[f]
+                else:                # fp0: y = 0 (metrics.py:14-15)
+                    pcc, mae, atol = (1.0 if m[4] == 0.0 else 0.0), m[3], m[4]
+                rows.append([idx, 0, SUPPORTED_FORMATS.index(f), pcc, mae, atol, per, numel * self.bytes_per_elem[f] / 1e9, np.nan, -1, -1, -1, -1, *m[:3]])
+            counts = [r.counts.get(k, 0) for k in MIXED_TILE_FORMATS]
+            rows.append([idx, 1, -1, r.pcc, r.mae, r.atol, per, float(r.tile_bytes) / 1e9, r.tile_bytes, *counts, *m[:3]])
+            out[idx] = (np.asarray(rows, dtype=np.float64).reshape(-1, self.row_w), r.assignment)
+        return out
+
+    def run_groups(self, groups: dict):
+        """groups: {(rows, cols, storage): [(tensor idx, name)]} → {idx: (rows [R, ROW_W], assignment int8 map)}.
+        The tensors of a window (at most MAX_WINDOW_BYTES of inputs) are loaded to HBM first; the window's batches then go through
+        the pipeline back to back — with the scan on the device, a batch's scans and downloads run beside the next batches' K1
+        (GreedyPipeline.run_batches), across shape groups."""
+        import torch
+
+        batches = []   # (key, part, tiles)
+        for key, items in groups.items():
+            rows_, cols_, _dtype = key
+            tiles = -(-rows_ // 32) * -(-cols_ // 32)
+            per_batch = max(1, MAX_BATCH_TILES // tiles)
+            for b0 in range(0, len(items), per_batch):
+                batches.append((key, items[b0:b0 + per_batch], tiles))
+        # the scan of a tensor is one wave whose time grows with the tensor's tiles: the longest scans are launched first so that
+        # the shorter batches' K1 and scans run beside them
+        batches.sort(key=lambda b: -b[2])
+        out = {}
+        w0 = 0
+        while w0 < len(batches):
+            w1, nbytes = w0, 0
+            while w1 < len(batches) and (w1 == w0 or nbytes + self._batch_bytes(batches[w1]) <= MAX_WINDOW_BYTES):
+                nbytes += self._batch_bytes(batches[w1])
+                w1 += 1
+            window = batches[w0:w1]
+            loaded = [self._load_batch(k[0], k[1], part) for k, part, _t in window]
             torch.cuda.synchronize()
-            pipe = self._pipeline(min(chunk, len(part)))
-            if getattr(pipe, "device_scan", False):
-                pipe.chunk = len(part)   # scan on the device: one K1 launch and one scan launch (a wave per tensor) per batch
+            greedy = self.algo.name == "mixed-tile-greedy"
+            pipe = self._pipeline(1)
+            if greedy and getattr(pipe, "device_scan", False):
+                pipe.SLOTS = max(pipe.SLOTS, min(len(window), MAX_SLOTS))   # every batch of a short window in flight at once
+                pipe.prepare([x for x, _m in loaded])     # record slots grown to the window's largest batch: allocations are not pipeline time
             t0 = time.perf_counter()
-            results = pipe.run(x3d)
+            if greedy and getattr(pipe, "device_scan", False):
+                pipe.chunk = 1 << 30                      # one K1 launch and one scan launch (a wave per tensor) per batch
+                all_results = pipe.run_batches([x for x, _m in loaded])
+            else:
+                all_results = []
+                for (key, part, tiles), (x3d, _m) in zip(window, loaded):
+                    pipe.chunk = min(max(1, K1_LAUNCH_TILES // tiles), len(part))
+                    all_results.append(pipe.run(x3d))
             torch.cuda.synchronize()
             dt = time.perf_counter() - t0
+            n_tiles = sum(t * len(part) for _k, part, t in window)
             self.compute_seconds += dt
-            self.compute_tiles += tiles * len(part)
+            self.compute_tiles += n_tiles
             if hasattr(pipe, "timing"):
                 pipe.timing.drain()
                 self.k1_ms, self.k1_tiles = pipe.timing.kernel_ms, pipe.timing.tiles
-            numel = rows_ * cols_
-            per = dt / len(part)   # TIME(s): the batch's wall time shared equally (wq:680-682 times one tensor's run())
-            for (idx, _name), r, m in zip(part, results, metas):
-                rows = []
-                for f in self.formats:   # comp 0 = none (wq:589-590)
-                    if f in MIXED_TILE_FORMATS:
-                        pcc, mae, atol = r.pure[f]
-                    else:                # fp0: y = 0 (metrics.py:14-15)
-                        pcc, mae, atol = (1.0 if m[4] == 0.0 else 0.0), m[3], m[4]
-                    rows.append([idx, 0, SUPPORTED_FORMATS.index(f), pcc, mae, atol, per, numel * self.bytes_per_elem[f] / 1e9, np.nan, -1, -1, -1, -1, *m[:3]])
-                counts = [r.counts.get(k, 0) for k in MIXED_TILE_FORMATS]
-                rows.append([idx, 1, -1, r.pcc, r.mae, r.atol, per, float(r.tile_bytes) / 1e9, r.tile_bytes, *counts, *m[:3]])
-                out[idx] = (np.asarray(rows, dtype=np.float64).reshape(-1, self.row_w), r.assignment)
-            del x3d
+            for (key, part, tiles), (_x, metas), results in zip(window, loaded, all_results):
+                per = dt * (tiles * len(part) / n_tiles) / len(part)   # TIME(s): the window's wall time shared by tiles (wq:680-682 times one tensor's run())
+                out.update(self._rows(part, results, metas, key[0] * key[1], per))
+            del loaded
+            w0 = w1
         return out
+
+    @staticmethod
+    def _batch_bytes(batch) -> int:
+        (rows_, cols_, dtype), part, _tiles = batch
+        return rows_ * cols_ * (2 if dtype == "bf16" else 4) * len(part)
 
     def close(self):
         if self._pipe is not None and hasattr(self._pipe, "close"):

@@ -658,13 +658,15 @@ def test_device_scan_headline_tensor_and_batches(golden_dir):
 
 @pytest.mark.gpu
 def test_device_scan_large_tensor_global_order():
-    """More than 32768 tiles: the visiting order lives in global scratch instead of LDS (Llama-3-8B gate_proj shape)."""
+    """More than 32 768 tiles (Llama-3-8B gate_proj shape: 57 344; and 66 560): the visiting order lives in global scratch instead of LDS."""
     import torch
 
     g = torch.Generator(device="cuda")
     g.manual_seed(3)
     x = (torch.randn((2, 14336, 4096), generator=g, device="cuda") * 0.02).to(torch.bfloat16)
     _device_scan_vs_host(x, ALL, 0.999, [123, 77])
+    x = (torch.randn((1, 8192, 8320), generator=g, device="cuda") * 0.02).to(torch.bfloat16)      # 66 560 tiles
+    _device_scan_vs_host(x, ALL, 0.999, [5])
 
 
 @pytest.mark.gpu
