@@ -382,6 +382,15 @@ def run(argv=None) -> int:
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
     coll_dev = None
+    try:   # torch sizes its CPU thread pool by the machine (256 hardware threads on a GPU box); under a cgroup CPU quota that
+        # oversubscribes the quota in the loader and gets every thread of the job — the GPU driver's included — throttled
+        import torch
+
+        from .pipeline import cpu_budget
+
+        torch.set_num_threads(max(1, min(torch.get_num_threads(), cpu_budget() // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1"))))))
+    except Exception:  # noqa: BLE001
+        pass
     if args.backend == "hip":
         import torch
 

@@ -399,6 +399,10 @@ class GreedyPipeline:
             if trace:
                 marks.append(("k1", time.perf_counter()))
             scan_stream.wait_event(e1)
+            if trace:
+                if getattr(self, "_trace_ref", None) is None:
+                    self._trace_ref = e0
+                    self._trace_t0 = time.perf_counter()
             with torch.cuda.stream(scan_stream):
                 # the chunk's seeds go up on its own scan stream (on the copy stream they would queue behind the previous batch's
                 # downloads, i.e. behind the previous batch's scans: the scans of consecutive batches would run one after the other)
@@ -413,19 +417,22 @@ class GreedyPipeline:
                 for k, pm in enumerate(b["pure_maps"]):
                     hb.check(hb.lib().mtq_column_sums_device_batched(recs.data_ptr(), n, tiles, dec_mask, pm[first:first + n].data_ptr(),
                                                                      b["sums_dev"][1 + k, first:first + n].data_ptr(), scan_stream.cuda_stream))
-                scanned = torch.cuda.Event()
+                scanned = torch.cuda.Event(enable_timing=trace)
                 scanned.record(scan_stream)
             if trace:
                 marks.append(("scan+sums", time.perf_counter()))
-            self.copy_stream.wait_event(scanned)
-            with torch.cuda.stream(self.copy_stream):
+            copy_stream = self.copy_stream
+            copy_stream.wait_event(scanned)
+            with torch.cuda.stream(copy_stream):
                 b["maps_host"][first:first + n].copy_(maps, non_blocking=True)
                 b["status_host"][first:first + n].copy_(b["status_dev"][first:first + n], non_blocking=True)
                 b["counts_host"][first:first + n].copy_(b["counts_dev"][first:first + n], non_blocking=True)
                 b["sums_host"][:, first:first + n].copy_(b["sums_dev"][:, first:first + n, :7], non_blocking=True)
-                done = torch.cuda.Event(blocking=True)
-                done.record(self.copy_stream)
+                done = torch.cuda.Event(blocking=True, enable_timing=trace)
+                done.record(copy_stream)
             pending.append((done, first, n))
+            if trace:
+                self._trace_rows = getattr(self, "_trace_rows", []) + [(count, tiles, e0, e1, scanned, done, time.perf_counter())]
             b["free"].append(scanned)
         enq = {"device": True, "buf": b, "pending": pending, "tiles_hw": (th, tw), "numel": n_el, "x": x3d, "dec_mask": dec_mask,
                "seeds": sh.copy()}
@@ -477,6 +484,8 @@ class GreedyPipeline:
                 r.pcc, r.mae, r.atol, r.metric_value = out["pcc"], out["mae"], out["atol"], out[self.metric]
             self.host_seconds["wait"] += t1 - t0
             self.host_seconds["wrap"] += time.perf_counter() - t1
+            if os.environ.get("MTQ_PIPE_TRACE") == "1":
+                print(f"[pipe] finish {n} x {th * tw}: waited {1e3 * (t1 - t0):.2f} ms, wrapped in {1e3 * (time.perf_counter() - t1):.2f} ms, handed back {bad.size}", flush=True)
         self._open.pop(0)
         enq["x"] = None
         return results
@@ -605,6 +614,14 @@ class GreedyPipeline:
                 pinned.copy_(torch.zeros((16,), dtype=torch.int8, device=device), non_blocking=True)
         torch.cuda.synchronize()
         self._warmed = str(device)
+        # one tiny batch end to end: the host side's first-use costs too (the first Tensor.numpy() of a process took ~55 ms on the
+        # GPU boxes — inside the first batch's wrap-up otherwise)
+        g = torch.Generator(device=device)
+        g.manual_seed(1)
+        tiny = (torch.randn((2, 64, 128), generator=g, device=device) * 0.02).to(torch.bfloat16)
+        if self._use_device_scan(8):
+            self.finish(self.enqueue(tiny))
+            torch.cuda.synchronize()
 
     def prepare(self, batches) -> None:
         """Grow every record slot's storage to the largest of `batches` (device and pinned allocations cost milliseconds: not between
@@ -639,6 +656,13 @@ class GreedyPipeline:
             out.append(self.finish(open_.pop(0)))
         for st in (self.stream, self.copy_stream, *self.scan_streams):
             torch.cuda.current_stream().wait_stream(st)
+        if os.environ.get("MTQ_PIPE_TRACE") == "1" and getattr(self, "_trace_rows", None):
+            torch.cuda.synchronize()
+            ref = self._trace_ref
+            for count, tiles, e0, e1, scanned, done, t_host in self._trace_rows:
+                print(f"[pipe] batch {count} x {tiles}: host launch {1e3 * (t_host - self._trace_t0):7.2f} | K1 {ref.elapsed_time(e0):7.2f} .. {ref.elapsed_time(e1):7.2f} | "
+                      f"scan+sums done {ref.elapsed_time(scanned):7.2f} | copies done {ref.elapsed_time(done):7.2f} ms", flush=True)
+            self._trace_rows, self._trace_ref = [], None
         return out
 
     def run(self, x3d, seeds=None, numel: int | None = None) -> list[TensorResult]:

@@ -21,7 +21,7 @@ from .quantization_formats import SUPPORTED_FORMATS
 STREAMED_ALGOS = {"mixed-tile-greedy", "mixed-tile-threshold"}
 MAX_BATCH_TILES = 1 << 21      # tiles per pipeline batch: bounds the record buffers (≈ 0.3 GB device + 0.2 GB pinned per slot)
 K1_LAUNCH_TILES = 1 << 19      # tiles per K1 launch with the host scan (32 x 4096²: a chunk's records cross PCIe beside the next chunk's K1)
-MAX_SLOTS = int(__import__("os").environ.get("MTQ_WQ_MAX_SLOTS", "3"))   # record slots of the streamed pipeline (K1 records + scan scratch of a batch: a few hundred MB each)
+MAX_SLOTS = int(__import__("os").environ.get("MTQ_WQ_MAX_SLOTS", "8"))   # record slots of the streamed pipeline (K1 records + scan scratch of a batch: a few hundred MB each)
 MAX_WINDOW_BYTES = 48 << 30    # inputs resident in HBM at once (288 GB per MI355X): the loader fills a window, the pipeline then streams it
 
 
@@ -127,20 +127,31 @@ class ShardEvaluator:
             torch.cuda.synchronize()
             greedy = self.algo.name == "mixed-tile-greedy"
             pipe = self._pipeline(1)
+            # a generation-2 collection of the interpreter's heap (torch's module graph: tens of ms) would land inside the window's few
+            # tens of milliseconds: collect now, and keep the collector off while the window runs
+            import gc
+
+            gc.collect()
+            gc_was_on = gc.isenabled()
+            gc.disable()
             if greedy and getattr(pipe, "device_scan", False):
                 pipe.SLOTS = max(pipe.SLOTS, min(len(window), MAX_SLOTS))   # every batch of a short window in flight at once
                 pipe.prepare([x for x, _m in loaded])     # record slots grown to the window's largest batch: allocations are not pipeline time
-            t0 = time.perf_counter()
-            if greedy and getattr(pipe, "device_scan", False):
-                pipe.chunk = 1 << 30                      # one K1 launch and one scan launch (a wave per tensor) per batch
-                all_results = pipe.run_batches([x for x, _m in loaded])
-            else:
-                all_results = []
-                for (key, part, tiles), (x3d, _m) in zip(window, loaded):
-                    pipe.chunk = min(max(1, K1_LAUNCH_TILES // tiles), len(part))
-                    all_results.append(pipe.run(x3d))
-            torch.cuda.synchronize()
-            dt = time.perf_counter() - t0
+            try:
+                t0 = time.perf_counter()
+                if greedy and getattr(pipe, "device_scan", False):
+                    pipe.chunk = 1 << 30                  # one K1 launch and one scan launch (a wave per tensor) per batch
+                    all_results = pipe.run_batches([x for x, _m in loaded])
+                else:
+                    all_results = []
+                    for (key, part, tiles), (x3d, _m) in zip(window, loaded):
+                        pipe.chunk = min(max(1, K1_LAUNCH_TILES // tiles), len(part))
+                        all_results.append(pipe.run(x3d))
+                torch.cuda.synchronize()
+                dt = time.perf_counter() - t0
+            finally:
+                if gc_was_on:
+                    gc.enable()
             n_tiles = sum(t * len(part) for _k, part, t in window)
             self.compute_seconds += dt
             self.compute_tiles += n_tiles
