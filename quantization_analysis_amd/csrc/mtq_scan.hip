@@ -12,7 +12,7 @@
 //     (state_q = A_q·state + G_q·inc), acceptance `v <= i − (accepted before me)` is settled exactly (certain accepts, certain
 //     rejects, the few in between one by one), the batch is cut where the mask level changes, unused positions are handed
 //     back; the accepted steps' swaps are applied in parallel except those that share a position with another step of the
-//     batch (found with a tag table in LDS), which are applied one by one in step order.  Modelled and checked against NumPy
+//     batch (found with byte counters in LDS), which are resolved in registers in step order (lane broadcasts).  Modelled and checked against NumPy
 //     in tools/scan_model/shuffle_model.py;
 //   * the scan (:234-278): 64 visits per round under a speculation on their outcome — accept mode: lane i holds the running
 //     sums plus the deltas of visits 0..i added one after the other (a serial chain of float64 additions on three lanes,
@@ -35,8 +35,7 @@ namespace {
 
 constexpr int kScanMaxTilesLds = 32768;   // visiting order kept in LDS as 16-bit tile ids up to here (64 KiB: K1 blocks still fit beside the scan block;
                                           // 65536 was measured: 7.6 against 8.4 ms per 57 344-tile tensor alone, but K1 loses the CU and `wq` Llama-3-8B got slower)
-constexpr int kTagSlots = 16384;          // conflict tags: one byte per hashed position
-constexpr int kHitWords = kTagSlots / 32;
+constexpr int kTagSlots = 16384;          // conflict detection: one byte counter per hashed position
 constexpr int kJump = 34;                 // jump-ahead table entries (q = 0..33)
 
 // Diagnostics: shader-clock ticks tensor 0 of the last launch spent per phase (mtq_debug_scan_ticks): 0 start-up + initial sums,
@@ -161,7 +160,7 @@ struct Rng {
 // order does not matter: csrc/mtq_host.cpp rng_skip_shuffle).  → false if the batch budget ran out (cannot happen in practice:
 // every batch accepts at least one draw with probability 1 − 2^−64).
 template <bool kSwap, typename Order>
-__device__ bool wave_shuffle(Rng &r, const Order &ord, int n, volatile uint8_t *tag, uint32_t *hit, int lane)
+__device__ bool wave_shuffle(Rng &r, const Order &ord, int n, uint32_t *cnt, int lane)
 {
     if (n < 2) return true;
     int i0 = n - 1;
@@ -204,43 +203,46 @@ __device__ bool wave_shuffle(Rng &r, const Order &ord, int n, volatile uint8_t *
             const int tstep = __builtin_popcountll(okmask & below(lane));
             const uint32_t pi = (uint32_t)(i0 - tstep), pj = v;
             const uint32_t hi_ = pi & (kTagSlots - 1), hj = pj & (kTagSlots - 1);
-            // both operands of every step are fetched now: the reads travel while the conflict protocol below runs (steps that turn out
-            // to share a position read again when their turn comes)
+            // both operands of every step are fetched now: the reads travel while the conflict detection below runs
             uint32_t vi = 0, vj = 0;
             if (mine) { vi = ord.get(pi); vj = ord.get(pj); }
-            // positions touched by two steps of the batch: tag protocol (losers of a slot raise its hit bit, the winner sees it).
-            // LDS operations of one wave execute in program order, so a read only needs the wait before its value is used.
-            if (mine) tag[hi_] = (uint8_t)lane;
+            // positions touched by two steps of the batch: every step adds 1 to the byte counters of its two (hashed) positions, reads
+            // them back — 2 or more means the position is shared (or aliased: harmless, the step is just taken out of the parallel
+            // part) — and takes its additions back.  LDS operations of one wave execute in program order: one wait, for the read-back.
+            const uint32_t wi = hi_ >> 2, wj = hj >> 2, si = (hi_ & 3u) * 8u, sj = (hj & 3u) * 8u;
+            if (mine) { atomicAdd(&cnt[wi], 1u << si); if (pj != pi) atomicAdd(&cnt[wj], 1u << sj); }
             compiler_fence();
-            if (mine && pj != pi) tag[hj] = (uint8_t)(64 + lane);
-            compiler_fence();
-            bool loser = false;
-            if (mine) loser = tag[hi_] != (uint8_t)lane || (pj != pi && tag[hj] != (uint8_t)(64 + lane));
-            if (loser) { atomicOr(&hit[hi_ >> 5], 1u << (hi_ & 31)); atomicOr(&hit[hj >> 5], 1u << (hj & 31)); }
-            compiler_fence();
-            bool flagged = loser;
+            bool flagged = false;
             if (mine) {
-                const volatile uint32_t *vh = hit;
-                flagged = loser || ((vh[hi_ >> 5] >> (hi_ & 31)) & 1u) || ((vh[hj >> 5] >> (hj & 31)) & 1u);
+                const volatile uint32_t *vc = cnt;
+                flagged = ((vc[wi] >> si) & 0xFFu) >= 2u || (pj != pi && ((vc[wj] >> sj) & 0xFFu) >= 2u);
             }
             compiler_fence();
-            if (flagged) { atomicAnd(&hit[hi_ >> 5], ~(1u << (hi_ & 31))); atomicAnd(&hit[hj >> 5], ~(1u << (hj & 31))); }
+            if (mine) { atomicSub(&cnt[wi], 1u << si); if (pj != pi) atomicSub(&cnt[wj], 1u << sj); }
             const uint64_t fmask = __ballot(flagged);
-                // steps that share no position with another step commute with everything: all at once
-            const bool par = mine && !flagged;
             ord.sync_reads();
-            if (par) { ord.set(pi, vj); ord.set(pj, vi); }
-            ord.sync_writes();
-                uint64_t fm = fmask;
-            while (fm) {   // the others one by one, in step order
+            // steps that share a position with another step: resolved in registers, in step order.  Every such lane holds the current
+            // values of its two positions (vi, vj: nothing else in the batch touches them); step f puts lane f's vj at its pi and its
+            // vi at its pj, and every lane that holds one of those positions — lane f included — takes the new value over.
+            uint64_t fm = fmask;
+            while (fm) {
                 const int f = __builtin_ctzll(fm);
-                if (lane == f) { vi = ord.get(pi); vj = ord.get(pj); }
-                ord.sync_reads();
-                if (lane == f) { ord.set(pi, vj); ord.set(pj, vi); }
-                ord.sync_writes();
+                const uint32_t pif = (uint32_t)__builtin_amdgcn_readlane((int)pi, f), pjf = (uint32_t)__builtin_amdgcn_readlane((int)pj, f);
+                const uint32_t vif = (uint32_t)__builtin_amdgcn_readlane((int)vi, f), vjf = (uint32_t)__builtin_amdgcn_readlane((int)vj, f);
+                if (flagged) {
+                    const uint32_t nvi = pi == pif ? vjf : (pi == pjf ? vif : vi);
+                    const uint32_t nvj = pj == pif ? vjf : (pj == pjf ? vif : vj);
+                    vi = nvi; vj = nvj;
+                }
                 fm &= fm - 1ull;
             }
+            // write-back: a step that shares nothing swaps its two values; the others hold the final values of their positions
+            if (mine) {
+                if (flagged) { ord.set(pi, vi); ord.set(pj, vj); }
+                else { ord.set(pi, vj); ord.set(pj, vi); }
             }
+            ord.sync_writes();
+        }
         i0 -= k;
         // ---- hand the unused positions back: the generator stands after the c-th position
         const int used = c - pend;
@@ -298,8 +300,7 @@ __device__ void scan_tensor(const ScanArgs &a, const Order &ord, int b, unsigned
     double *lds_d = reinterpret_cast<double *>(lds);                 // [64][4] deltas / staging
     double *lds_p = lds_d + 64 * 4;                                    // [64][4] prefixes
     double *lds_i = lds_p + 64 * 4;                                    // [64][5] initial-sum staging
-    volatile uint8_t *tag = reinterpret_cast<volatile uint8_t *>(lds_i + 64 * 5);   // [kTagSlots]
-    uint32_t *hit = reinterpret_cast<uint32_t *>(const_cast<uint8_t *>(tag) + kTagSlots);   // [kHitWords]
+    uint32_t *cnt = reinterpret_cast<uint32_t *>(lds_i + 64 * 5);   // [kTagSlots / 4] byte counters of the shuffle's conflict detection
     int status = 0;
     unsigned long long tick = clock64();
     auto stamp = [&](int slot) {
@@ -308,7 +309,7 @@ __device__ void scan_tensor(const ScanArgs &a, const Order &ord, int b, unsigned
         tick = now;
     };
 
-    for (int i = lane; i < kHitWords; i += 64) hit[i] = 0u;
+    for (int i = lane; i < kTagSlots / 4; i += 64) cnt[i] = 0u;
     const int base = a.fmt[0];
     for (int t = lane; t < T; t += 64) map[t] = (int8_t)base;        // :99
 
@@ -346,14 +347,20 @@ __device__ void scan_tensor(const ScanArgs &a, const Order &ord, int b, unsigned
         }
         __syncthreads();
         if (lane < 5) {
-            if (m == 64) {   // eight staged values at a time: the additions stay one dependent chain in tile order, the LDS reads do not wait for it
+            if (m == 64) {   // sixteen staged values ahead: the additions stay one dependent chain in tile order, the LDS reads do not wait for it
+                double v[16], w[16];
 #pragma unroll
-                for (int i0 = 0; i0 < 64; i0 += 8) {
-                    double v[8];
+                for (int u = 0; u < 16; ++u) v[u] = lds_i[u * 5 + lane];
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) v[u] = lds_i[(i0 + u) * 5 + lane];
+                for (int i0 = 0; i0 < 64; i0 += 16) {
+                    if (i0 + 16 < 64) {
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) acc = acc + v[u];
+                        for (int u = 0; u < 16; ++u) w[u] = lds_i[(i0 + 16 + u) * 5 + lane];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) acc = acc + v[u];
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) v[u] = w[u];
                 }
             } else {
                 for (int i = 0; i < m; ++i) acc = acc + lds_i[i * 5 + lane];
@@ -376,7 +383,7 @@ __device__ void scan_tensor(const ScanArgs &a, const Order &ord, int b, unsigned
         const bool good = pcc_good(n, mean_x, am2, thr, Sy, Sy2, Sxy, special);
         if (special) status = 1;
         all_fixed = !good;
-        if (!wave_shuffle<false>(r, ord, T, tag, hit, lane)) status = 2;   // the generator advances as the permutation would have
+        if (!wave_shuffle<false>(r, ord, T, cnt, lane)) status = 2;   // the generator advances as the permutation would have
     }
 
     stamp(1);
@@ -393,7 +400,7 @@ __device__ void scan_tensor(const ScanArgs &a, const Order &ord, int b, unsigned
         }
         ord.sync();
         if (nc == 0) break;                                            // :229-230
-        if (!wave_shuffle<true>(r, ord, nc, tag, hit, lane)) { status = 2; break; }   // order = rng.permutation(candidates), :231
+        if (!wave_shuffle<true>(r, ord, nc, cnt, lane)) { status = 2; break; }   // order = rng.permutation(candidates), :231
         stamp(2 + 3 * (p - 1));
         // deltas of every visit of the pass (a tile is visited once per pass, so its previous format is what the map holds now)
         for (int k0 = 0; k0 < nc; k0 += 256) {   // four rounds of 64 visits in flight: the gathers are latency-bound
@@ -459,13 +466,19 @@ __device__ void scan_tensor(const ScanArgs &a, const Order &ord, int b, unsigned
                 __syncthreads();
                 if (lane < 3) {   // inactive visits staged +0 deltas: their prefixes are never read
                     double s = lane == 0 ? Sy : (lane == 1 ? Sy2 : Sxy);
+                    double v[16], w[16];
 #pragma unroll
-                    for (int i0 = 0; i0 < 64; i0 += 8) {
-                        double v[8];
+                    for (int u = 0; u < 16; ++u) v[u] = lds_d[u * 4 + lane];
 #pragma unroll
-                        for (int u = 0; u < 8; ++u) v[u] = lds_d[(i0 + u) * 4 + lane];
+                    for (int i0 = 0; i0 < 64; i0 += 16) {   // the next sixteen deltas are on their way while these sixteen are added, one after the other
+                        if (i0 + 16 < 64) {
 #pragma unroll
-                        for (int u = 0; u < 8; ++u) { s = s + v[u]; lds_p[(i0 + u) * 4 + lane] = s; }
+                            for (int u = 0; u < 16; ++u) w[u] = lds_d[(i0 + 16 + u) * 4 + lane];
+                        }
+#pragma unroll
+                        for (int u = 0; u < 16; ++u) { s = s + v[u]; lds_p[(i0 + u) * 4 + lane] = s; }
+#pragma unroll
+                        for (int u = 0; u < 16; ++u) v[u] = w[u];
                     }
                 }
                 __syncthreads();
@@ -500,18 +513,18 @@ __device__ void scan_tensor(const ScanArgs &a, const Order &ord, int b, unsigned
         stamp(4 + 3 * (p - 1));
     }
     mem_wait();
-    int cnt[MTQ_NUM_TILE_FORMATS] = {0, 0, 0, 0};
+    int per_fmt[MTQ_NUM_TILE_FORMATS] = {0, 0, 0, 0};
     for (int t0 = 0; t0 < T; t0 += 64) {
         const int t = t0 + lane;
         int code = -1;
         if (t < T) { code = (int)((uint8_t)ld_l2(map + t) & 0x7Fu); map[t] = (int8_t)code; }
 #pragma unroll
-        for (int c = 0; c < MTQ_NUM_TILE_FORMATS; ++c) cnt[c] += __builtin_popcountll(__ballot(code == c));
+        for (int c = 0; c < MTQ_NUM_TILE_FORMATS; ++c) per_fmt[c] += __builtin_popcountll(__ballot(code == c));
     }
     if (lane == 0) {
         a.status[b] = status;
         if (a.counts)
-            for (int c = 0; c < MTQ_NUM_TILE_FORMATS; ++c) a.counts[b * MTQ_NUM_TILE_FORMATS + c] = cnt[c];
+            for (int c = 0; c < MTQ_NUM_TILE_FORMATS; ++c) a.counts[b * MTQ_NUM_TILE_FORMATS + c] = per_fmt[c];
     }
 }
 
@@ -531,7 +544,7 @@ __global__ __launch_bounds__(64) void greedy_scan_pcc_global(ScanArgs a)
     scan_tensor(a, ord, blockIdx.x, lds, lane);
 }
 
-constexpr size_t kFixedLds = (64 * 4 + 64 * 4 + 64 * 5) * sizeof(double) + kTagSlots + kHitWords * 4;
+constexpr size_t kFixedLds = (64 * 4 + 64 * 4 + 64 * 5) * sizeof(double) + kTagSlots;
 
 // jump-ahead tables A_q = a^q, G_q = 1 + a + … + a^(q−1) (mod 2^128), uploaded once per device
 const U128 *jump_tables(int dev)
