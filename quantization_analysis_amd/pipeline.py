@@ -94,6 +94,16 @@ def _scan_chunk_chain(first, chain, base, tiles_hw, numel, tile_formats, thresho
     return res
 
 
+def _sleep_until(event, tick: float = 1e-4) -> None:
+    """Wait for a HIP event without burning the core: hipEventSynchronize spins on this runtime even for events created with the
+    blocking flag (the driver thread showed 100 % CPU while 'waiting'), so the event is polled between short sleeps.  The pipeline
+    has a whole step of slack on this wait (three record slots)."""
+    import time
+
+    while not event.query():
+        time.sleep(tick)
+
+
 def _when_landed(event, fn, *args):
     """Chunk task of the streamed driver: sleep until the chunk's records are on the host (a blocking HIP event), then scan."""
     event.synchronize()
@@ -461,7 +471,7 @@ class GreedyPipeline:
         names = MIXED_TILE_FORMATS
         for done, first, n in enq["pending"]:
             t0 = time.perf_counter()
-            done.synchronize()
+            _sleep_until(done)
             t1 = time.perf_counter()
             maps = b["maps_host"][first:first + n].numpy().reshape(n, th, tw).copy()   # one copy per chunk: the pinned buffer is reused
             status = b["status_host"][first:first + n].numpy()

@@ -8,7 +8,7 @@ steps = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 hb.require_gpu()
 print(hb.bind_to_gpu_numa_node(0))
 batch = bench.make_batch(128, 0, torch.device('cuda', 0))
-pipe = pl.GreedyPipeline(bench.FORMATS, bench.METRIC, bench.THRESHOLD, bench.SEED, chunk=16, workers=bench.default_workers())
+pipe = pl.GreedyPipeline(bench.FORMATS, bench.METRIC, bench.THRESHOLD, bench.SEED, chunk=128, workers=bench.default_workers())
 pipe.reserve(batch); pipe.run_steps(batch for _ in range(3)); torch.cuda.synchronize()
 def snap():
     out = {}
