@@ -45,7 +45,13 @@ __device__ __forceinline__ s2 as_s2(uint32_t x) { return __builtin_bit_cast(s2, 
 __device__ __forceinline__ uint32_t as_u32(us2 x) { return __builtin_bit_cast(uint32_t, x); }
 __device__ __forceinline__ uint32_t as_u32(s2 x) { return __builtin_bit_cast(uint32_t, x); }
 
-constexpr int kFastWaves = 4;                        // waves per block
+#ifndef MTQ_FAST_WAVES
+#define MTQ_FAST_WAVES 2
+#endif
+// waves per block.  Waves never share data, so any block size works; it decides what a co-resident kernel displaces: a scan wave
+// of csrc/mtq_scan.hip (126 VGPRs on one SIMD) keeps a whole 4-wave block off its CU but only half of two 2-wave blocks — measured
+// inside the bench (round 2, two interleaved runs): 4 waves 735 M tiles/s (K1 2.72 ms), 2 waves 777 M (2.55 ms), 1 wave 759 M (2.52 ms).
+constexpr int kFastWaves = MTQ_FAST_WAVES;
 constexpr int kUnitTiles = 4;                        // tiles per wave unit
 constexpr int kUnitCols = kUnitTiles * kTile;        // 128
 constexpr int kInBytes = kTile * kUnitCols * 2;      // 8192 B of bf16 per unit
@@ -407,11 +413,11 @@ extern "C" int mtq_launch_tile_stats_bf16_fast(const void *x, int64_t count, int
         cus = p.multiProcessorCount;
     }
     const int64_t need = (total + kFastWaves - 1) / kFastWaves;
-    const int64_t max_blocks = (int64_t)cus * MTQ_ROLLED_WAVES_PER_SIMD; // blocks of 4 waves per CU (one wave of each per SIMD)
-    // MTQ_K1_UNITS_PER_WAVE (default 16; 0 = persistent waves): with a bound, the grid is what the units need at that many per wave,
+    const int64_t max_blocks = (int64_t)cus * MTQ_ROLLED_WAVES_PER_SIMD * 4 / kFastWaves; // resident blocks: MTQ_ROLLED_WAVES_PER_SIMD waves on each of a CU's 4 SIMDs
+    // MTQ_K1_UNITS_PER_WAVE (default 8; 0 = persistent waves): with a bound, the grid is what the units need at that many per wave,
     // rounded up to whole counter groups plus one spare block per group (a block that finds its group's queue empty exits at once)
     static int upw = -1;
-    if (upw < 0) { const char *e = getenv("MTQ_K1_UNITS_PER_WAVE"); upw = e ? atoi(e) : 16; if (upw < 0) upw = 0; }
+    if (upw < 0) { const char *e = getenv("MTQ_K1_UNITS_PER_WAVE"); upw = e ? atoi(e) : 8; if (upw < 0) upw = 0; }
     int64_t want = need < max_blocks ? need : max_blocks;
     if (upw > 0 && need > max_blocks) {
         const int64_t by_quota = (total + (int64_t)kFastWaves * upw - 1) / ((int64_t)kFastWaves * upw);
