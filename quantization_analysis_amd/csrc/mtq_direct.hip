@@ -24,6 +24,7 @@
 // Loads are direct (4 × 16 B per lane for float32); the next tile's group is fetched before the current one is processed.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/mtq.h"
 #include "mtq_device.hpp"
@@ -35,7 +36,7 @@
 
 namespace mtq {
 
-constexpr int kDirectWaves = 4;                                   // waves per block
+constexpr int kDirectWaves = 2;                                   // waves per block (independent waves; 2 instead of 4 for the same reason as mtq_fast.hip's kFastWaves)
 constexpr unsigned long long kRedoMagicDirect = 0x7FF8C0DE5EED0001ull; // same pattern as mtq_fast.hip / mtq_kernels.hip
 constexpr int kMaxSums = 2 + 4 * kNumFmt;                         // Σx, Σx², 4 × (Σy, Σy², Σxy, Σ|d|)
 
@@ -188,7 +189,7 @@ __device__ __forceinline__ void direct_group(const uint32_t (&u)[kGroup], double
 template <typename T, uint32_t FM>
 __global__ __launch_bounds__(kDirectWaves * 64, MTQ_DIRECT_WAVES_PER_SIMD) void tile_stats_direct(
     const T *__restrict__ x, int64_t stride, int64_t rows, int64_t cols, int64_t ld, uint32_t tiles_w, uint32_t tiles,
-    uint32_t total_tiles, double *__restrict__ stats, int vec_ok, unsigned *__restrict__ work, unsigned launch_id)
+    uint32_t total_tiles, double *__restrict__ stats, int vec_ok, unsigned *__restrict__ work, unsigned launch_id, int tiles_per_wave)
 {
     constexpr int nf = popc4(FM), nsum = 2 + 4 * nf, pad = direct_pad(FM), rec = 2 + 5 * nf;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -211,14 +212,19 @@ __global__ __launch_bounds__(kDirectWaves * 64, MTQ_DIRECT_WAVES_PER_SIMD) void 
                          cols, ld, vec_ok != 0, u);
     };
 
+    // a wave retires after tiles_per_wave tiles (0: never), so that co-resident kernels of other streams — the device scans of
+    // earlier batches — are placed within a block's lifetime (mtq_fast.hip, MTQ_K1_UNITS_PER_WAVE)
+    int left = tiles_per_wave > 0 ? tiles_per_wave : 0x7FFFFFFF;
     uint32_t gt = claim();
+    --left;
     uint32_t nxt[kGroup];
     if (gt < total_tiles) fetch(gt, nxt);
     while (gt < total_tiles) {
         uint32_t u[kGroup];
 #pragma unroll
         for (int i = 0; i < kGroup; ++i) u[i] = nxt[i];
-        const uint32_t gt_next = claim();
+        const uint32_t gt_next = left > 0 ? claim() : 0xFFFFFFFFu;
+        --left;
         if (gt_next < total_tiles) fetch(gt_next, nxt);                         // in flight while this tile is processed
 
         double s[kMaxSums];
@@ -269,12 +275,12 @@ __global__ __launch_bounds__(kDirectWaves * 64, MTQ_DIRECT_WAVES_PER_SIMD) void 
 
 template <typename T>
 static void launch_direct(uint32_t fm, dim3 grid, hipStream_t st, const T *x, int64_t stride, int64_t rows, int64_t cols, int64_t ld,
-                          uint32_t tiles_w, uint32_t tiles, uint32_t total, double *stats, int vec_ok, unsigned *work, unsigned launch_id)
+                          uint32_t tiles_w, uint32_t tiles, uint32_t total, double *stats, int vec_ok, unsigned *work, unsigned launch_id, int tiles_per_wave)
 {
     const dim3 block(kDirectWaves * 64);
 #define MTQ_LAUNCH_DIRECT(M) \
     case M: hipLaunchKernelGGL((tile_stats_direct<T, M>), grid, block, (size_t)kDirectWaves * 64 * direct_pad(M) * sizeof(double), st, x, \
-                               stride, rows, cols, ld, tiles_w, tiles, total, stats, vec_ok, work, launch_id); break;
+                               stride, rows, cols, ld, tiles_w, tiles, total, stats, vec_ok, work, launch_id, tiles_per_wave); break;
     switch (fm) { // one instantiation per requested format subset: unrequested formats cost nothing
         MTQ_LAUNCH_DIRECT(1u) MTQ_LAUNCH_DIRECT(2u) MTQ_LAUNCH_DIRECT(3u) MTQ_LAUNCH_DIRECT(4u) MTQ_LAUNCH_DIRECT(5u)
         MTQ_LAUNCH_DIRECT(6u) MTQ_LAUNCH_DIRECT(7u) MTQ_LAUNCH_DIRECT(8u) MTQ_LAUNCH_DIRECT(9u) MTQ_LAUNCH_DIRECT(10u)
@@ -303,16 +309,28 @@ extern "C" int mtq_launch_tile_stats_direct(const void *x, int in_dtype, int64_t
         cus = p.multiProcessorCount;
     }
     const int64_t need = (total + kDirectWaves - 1) / kDirectWaves;
-    const int64_t max_blocks = (int64_t)cus * MTQ_DIRECT_WAVES_PER_SIMD;   // blocks of 4 waves: one wave of each per SIMD
-    const dim3 grid((unsigned)(need < max_blocks ? need : max_blocks));
+    const int64_t max_blocks = (int64_t)cus * MTQ_DIRECT_WAVES_PER_SIMD * 4 / kDirectWaves;   // resident blocks: that many waves on each of a CU's 4 SIMDs
+    // MTQ_K1_UNITS_PER_WAVE (mtq_fast.hip; default 8) x 16 tiles: a wave of this kernel restarts more expensively (its prefetch chain),
+    // measured on 8 x 4096² float32: 32 tiles per wave cost 10 % of the launch, 128 tiles 1 %
+    static int tpw = -1;
+    if (tpw < 0) { const char *e = getenv("MTQ_K1_UNITS_PER_WAVE"); tpw = 16 * (e ? atoi(e) : 8); if (tpw < 0) tpw = 0; }
+    int64_t want = need < max_blocks ? need : max_blocks;
+    int quota = 0;
+    if (tpw > 0 && need > max_blocks) {
+        const int64_t by_quota = (total + (int64_t)kDirectWaves * tpw - 1) / ((int64_t)kDirectWaves * tpw);
+        want = ((by_quota + kWorkGroups - 1) / kWorkGroups + 1) * kWorkGroups;
+        if (want < max_blocks) want = max_blocks;
+        quota = tpw;
+    }
+    const dim3 grid((unsigned)want);
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (int rc = work_counter_acquire(stream, work_out)) return rc;   // `st` now waits for the slot's previous launch to have reset it
     unsigned *work = work_out->counters;
     if (in_dtype == MTQ_DTYPE_BF16)
         launch_direct<uint16_t>(fmt_mask & MTQ_MASK_ALL, grid, st, static_cast<const uint16_t *>(x), stride_elems, rows, cols, ld, (uint32_t)tw,
-                                (uint32_t)tiles, (uint32_t)total, stats, vec_ok, work, launch_id);
+                                (uint32_t)tiles, (uint32_t)total, stats, vec_ok, work, launch_id, quota);
     else
         launch_direct<float>(fmt_mask & MTQ_MASK_ALL, grid, st, static_cast<const float *>(x), stride_elems, rows, cols, ld, (uint32_t)tw,
-                             (uint32_t)tiles, (uint32_t)total, stats, vec_ok, work, launch_id);
+                             (uint32_t)tiles, (uint32_t)total, stats, vec_ok, work, launch_id, quota);
     return check_launch("mtq_tile_stats (direct)");
 }
