@@ -2,5 +2,9 @@ set -o pipefail
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r2ab; rm -rf $O; mkdir -p $O
 cd $R
 show() { python -c "
-import json,sys; d=json.load(open(sys.argv[1])); print(sys.argv[2], '%.1f M tiles/s' % (d['value']/1e6), '%.3f ms/step' % d['ms_per_step'], 'K1 %.3f ms' % d['roofline']['launch_ms'], 'alone %.3f' % d['roofline']['kernel_alone']['launch_ms'])" $1 $2; }
-for w in 2 1; do for u in 8 16 32 64; do MTQ_K1_UNITS_PER_WAVE=$u MTQ_LIB=$R/quantization_analysis_amd/libmtq_hip_w$w.so python bench.py --cpu-sample 0 > $O/b_w${w}_u$u.json 2>/dev/null; show $O/b_w${w}_u$u.json waves${w}_upw$u; done; done
+import json,sys; d=json.load(open(sys.argv[1])); print(sys.argv[2], '%.1f M tiles/s' % (d['value']/1e6), '%.3f ms/step' % d['ms_per_step'], 'K1 %.3f ms' % d['roofline']['launch_ms'], 'alone %.3f' % d['roofline']['kernel_alone']['launch_ms'], 'cpu %.1f' % d['config']['host_cpu_ms_per_step'])" $1 $2; }
+run() { tag=$1; shift; env "$@" python bench.py --cpu-sample 0 > $O/b_$tag.json 2>/dev/null; show $O/b_$tag.json $tag; }
+run base X=1
+run prio0 MTQ_SCAN_PRIORITY=0
+run upw4 MTQ_K1_UNITS_PER_WAVE=4
+python bench.py --cpu-sample 0 --tensors 256 > $O/b_t256.json 2>/dev/null; show $O/b_t256.json tensors256
