@@ -28,6 +28,13 @@ from .compression_algorithms.tile_utils import MIXED_TILE_FORMATS
 from .model_source import build_model_index, lpt_shards, resolve_format_list, resolve_selected_tensors, safe_repo_revision_key
 from .quantization_formats import SUPPORTED_FORMATS
 
+# The HIP runtime maps a process's streams onto this many hardware queues (its default is 4), and kernels of streams that share a
+# queue run one after the other.  A window of the streamed search (streamed.py) has the scans of several shape groups in flight
+# beside K1 and the copies: with 4 queues the scans of a model's third and fourth group waited for the first group's to end
+# (the Llama-3-8B shapes: 25 ms per window against 19 ms with 8 queues; bench.py's one-shape steps lose 2 % with 8 and keep 4).
+# Read by the runtime at its first call — nothing in this process has touched the GPU yet; a value already in the environment wins.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 FORMAT_BYTES_PER_ELEM = {"bf16": 2.0, "bfp8": 1.088, "bfp4": 0.50097, "bfp2": 0.25097, "fp0": 0.0}  # wq:132-140
 MIXED_ALGOS = {"mixed-tile-greedy", "mixed-tile-random", "mixed-tile-threshold"}
 ROW_W = 16  # summary row: idx, comp, fmt, pcc, mae, atol, time, gb, tile_bytes, 4 counts, xmin, xmean, xmax

@@ -11,6 +11,7 @@ from __future__ import annotations
 
 import concurrent.futures as cf
 import os
+import time
 from dataclasses import dataclass, field
 
 import numpy as np
@@ -159,6 +160,11 @@ class GreedyPipeline:
         if scan == "device" and not can:
             raise ValueError("the device scan serves the pcc metric with distinct formats")
         self.device_scan = can and scan != "host" and os.environ.get("MTQ_DEVICE_SCAN", "1") != "0"
+        # A device scan is ONE wave per tensor (≈ 0.14–0.19 µs per tile, three passes): right when a batch holds many tensors, a long
+        # pole when a batch is a few very large ones — a host core scans a tile in ≈ 0.025 µs.  Callers whose batches are latency-bound
+        # (streamed.py: a model's shape groups) lower this limit; batches above it take the host route, the others the device route.
+        self.device_scan_max_tiles = int(os.environ.get("MTQ_DEVICE_SCAN_MAX_TILES", str(hb.SCAN_DEVICE_MAX_TILES)))
+        self.host_chunk_tiles = None             # host route: tiles per K1 launch / records copy / scan task (None: self.chunk tensors)
         # device scans + column sums: behind their chunk's K1, beside the next chunks' K1.  A scan is one wave per tensor for a few
         # milliseconds (latency-bound), so consecutive chunks' scans must overlap each other: a ring of streams
         self.scan_streams = [torch.cuda.Stream(priority=int(os.environ.get("MTQ_SCAN_PRIORITY", "-1")))
@@ -265,16 +271,20 @@ class GreedyPipeline:
         # the batch SLOTS back read this slot's records in its device-side column sums: those run on the K1 stream (see
         # _launch_columns), ahead of the K1 launches below in stream order — no host-side wait is needed here
         chain = self._chain(slim)
+        trace = os.environ.get("MTQ_PIPE_TRACE") == "1"
+        t_enq = time.perf_counter()
         rec_host = 3 * (len(self.tile_formats) - 1) if chain else hb.record_doubles(host_mask)
         dev, stage, host, host_np = self._buffers(slot, count, tiles, hb.record_doubles(k1_mask), rec_host, x3d.device)
         if chain:
             base_dev, base_host, base_np = self._chain_buffers(slot, count, tiles, hb.chain_base_doubles(host_mask, self.tile_formats), x3d.device)
+        t_buf = time.perf_counter()
         dec_mask = host_mask & ~hb.MASK_SLIM             # what the full records on the device hold (identity bf16 included)
         pending = []  # (event, first_index, n)
         self.stream.wait_stream(torch.cuda.current_stream())
+        chunk = self._host_chunk(count, tiles)
         with torch.cuda.stream(self.stream):
-            for first in range(0, count, self.chunk):
-                n = min(self.chunk, count - first)
+            for first in range(0, count, chunk):
+                n = min(chunk, count - first)
                 e0 = torch.cuda.Event(enable_timing=True)
                 e1 = torch.cuda.Event(enable_timing=True)
                 e0.record(self.stream)
@@ -317,13 +327,20 @@ class GreedyPipeline:
                 futures.append((first, n, self.pool.submit(_when_landed, done, _scan_chunk, *self._scan_args(enq, first, n, host_np[first:first + n], host_mask))))
         enq["futures"] = futures
         self._open.append(enq)
+        if trace:
+            print(f"[pipe] enqueue (host route) {count} x {tiles} tiles in chunks of {chunk}: buffers {1e3 * (t_buf - t_enq):.2f}, launches {1e3 * (time.perf_counter() - t_buf):.2f} ms", flush=True)
         return enq
 
     # ---------------------------------------------------------------------------------------------------------------------
     # device-resident scan (csrc/mtq_scan.hip)
     # ---------------------------------------------------------------------------------------------------------------------
     def _use_device_scan(self, tiles: int) -> bool:
-        return self.device_scan and hb.device_scan_supported(self.tile_formats, self.metric, tiles)
+        return self.device_scan and tiles <= self.device_scan_max_tiles and hb.device_scan_supported(self.tile_formats, self.metric, tiles)
+
+    def _host_chunk(self, count: int, tiles: int) -> int:
+        if self.host_chunk_tiles is None:
+            return self.chunk
+        return min(max(1, self.host_chunk_tiles // tiles), count)
 
     def _device_buffers(self, slot: int, count: int, tiles: int, rec: int, device) -> dict:
         """Per record slot: K1's full records, the scan's maps / status / scratch, per-format tile counts and the column sums
@@ -517,6 +534,7 @@ class GreedyPipeline:
             return self._finish_device(enq)
         futures = enq.pop("futures")
         results: list[TensorResult] = []
+        t_fin = time.perf_counter()
         for first, n, fut in futures:
             try:
                 results.extend(fut.result())
@@ -528,10 +546,13 @@ class GreedyPipeline:
                 results.extend(_scan_chunk(*self._scan_args(enq, first, n, full, enq["host_mask"] & ~hb.MASK_SLIM)))
         self._open.pop(0)
         enq["x"] = None
+        t_scanned = time.perf_counter()
         if enq["slim"] or self.pure_formats:
             self._launch_columns(enq, results)
             if not defer_columns:
                 self.resolve(enq)
+        if os.environ.get("MTQ_PIPE_TRACE") == "1":
+            print(f"[pipe] finish (host route) {len(results)} tensors: scans collected after {1e3 * (t_scanned - t_fin):.2f} ms, columns after {1e3 * (time.perf_counter() - t_scanned):.2f} ms", flush=True)
         return results
 
     def _launch_columns(self, enq: dict, results: list) -> None:
@@ -540,23 +561,19 @@ class GreedyPipeline:
         torch = self.torch
         dev = enq["dev"]
         count, tiles = dev.shape[0], dev.shape[1]
-        key = (count, tiles, str(dev.device))
-        if self._colbufs.get("key") != key:
-            n_scratch = int(hb.lib().mtq_columns_scratch_doubles())
-            self._colbufs = {"key": key, "ring": [
-                {"maps_host": torch.empty((count, tiles), dtype=torch.int8, pin_memory=True),
-                 "maps_dev": torch.empty((count, tiles), dtype=torch.int8, device=dev.device),
-                 "scratch": torch.empty((1 + len(self.pure_formats), count, n_scratch), dtype=torch.float64, device=dev.device),
-                 "sums_host": torch.empty((1 + len(self.pure_formats), count, 7), dtype=torch.float64, pin_memory=True)} for _ in range(self.SLOTS)],
-                "pure_maps": [torch.full((count, tiles), MIXED_TILE_FORMATS.index(f), dtype=torch.int8, device=dev.device) for f in self.pure_formats],
-                "next": 0}
-        cb = self._colbufs["ring"][self._colbufs["next"]]
-        self._colbufs["next"] = (self._colbufs["next"] + 1) % self.SLOTS
-        user = cb.get("user")                            # the batch SLOTS back read its sums out of this ring entry
+        self._column_buffers(count, tiles, dev.device)
+        ring = self._colbufs["ring"]
+        flat = ring[self._colbufs["next"] % len(ring)]
+        self._colbufs["next"] = (self._colbufs["next"] + 1) % len(ring)
+        user = flat.get("user")                          # the batch a ring length back read its sums out of this ring entry
         if user is not None and "col_pending" in user:
             self.resolve(user)
             self._unresolved = [e for e in self._unresolved if e is not user]
-        cb["user"] = enq
+        flat["user"] = enq
+        n_sets, n_scratch = 1 + len(self.pure_formats), self._colbufs["n_scratch"]
+        cb = {"maps_host": flat["maps_host"][:count * tiles].view(count, tiles), "maps_dev": flat["maps_dev"][:count * tiles].view(count, tiles),
+              "scratch": flat["scratch"][:n_sets * count * n_scratch].view(n_sets, count, n_scratch),
+              "sums_host": flat["sums_host"][:n_sets * count * 7].view(n_sets, count, 7)}
         mh = cb["maps_host"].numpy()
         for i, r in enumerate(results):
             mh[i] = r.assignment.reshape(-1)
@@ -573,7 +590,7 @@ class GreedyPipeline:
         if enq["slim"]:   # the searched maps' columns (other metrics: the host scan already produced them)
             hb.check(hb.lib().mtq_column_sums_device_batched(dev.data_ptr(), count, tiles, dec_mask, cb["maps_dev"].data_ptr(),
                                                              cb["scratch"][0].data_ptr(), self.stream.cuda_stream))
-        for k, pm in enumerate(self._colbufs["pure_maps"]):   # one constant map per pure format
+        for k, pm in enumerate(self._colbufs["pure_maps"]):   # one constant map per pure format (flat: any (count, tiles) view of it is constant)
             hb.check(hb.lib().mtq_column_sums_device_batched(dev.data_ptr(), count, tiles, dec_mask, pm.data_ptr(), cb["scratch"][1 + k].data_ptr(),
                                                              self.stream.cuda_stream))
         summed = torch.cuda.Event()
@@ -584,6 +601,29 @@ class GreedyPipeline:
             done = torch.cuda.Event(blocking=True)
             done.record(self.col_stream)
         enq["col_pending"] = (done, cb["sums_host"], results)
+
+    def _column_buffers(self, count: int, tiles: int, device) -> None:
+        """Ring of flat, only-growing buffers for _launch_columns (maps up, reduction scratch, sums down): batches of another shape get
+        views, so that no device or pinned allocation lands between two batches of a run that prepare() has seen."""
+        torch = self.torch
+        cb = self._colbufs
+        n_sets = 1 + len(self.pure_formats)
+        if (cb.get("device") == str(device) and cb["cap_tiles"] >= count * tiles and cb["cap_count"] >= count and len(cb["ring"]) >= self.SLOTS):
+            return
+        for e in cb.get("ring", []):                     # sums still in flight live in the old buffers: collect them first
+            user = e.get("user")
+            if user is not None and "col_pending" in user:
+                self.resolve(user)
+                self._unresolved = [u for u in self._unresolved if u is not user]
+        cap_tiles = max(count * tiles, cb.get("cap_tiles", 0) if cb.get("device") == str(device) else 0)
+        cap_count = max(count, cb.get("cap_count", 0) if cb.get("device") == str(device) else 0)
+        n_scratch = int(hb.lib().mtq_columns_scratch_doubles())
+        self._colbufs = {"device": str(device), "cap_tiles": cap_tiles, "cap_count": cap_count, "n_scratch": n_scratch, "next": 0, "ring": [
+            {"maps_host": torch.empty((cap_tiles,), dtype=torch.int8, pin_memory=True),
+             "maps_dev": torch.empty((cap_tiles,), dtype=torch.int8, device=device),
+             "scratch": torch.empty((n_sets * cap_count * n_scratch,), dtype=torch.float64, device=device),
+             "sums_host": torch.empty((n_sets * cap_count * 7,), dtype=torch.float64, pin_memory=True)} for _ in range(self.SLOTS)],
+            "pure_maps": [torch.full((cap_tiles,), MIXED_TILE_FORMATS.index(f), dtype=torch.int8, device=device) for f in self.pure_formats]}
 
     def resolve(self, enq: dict) -> None:
         """Wait for the columns launched by finish(..., defer_columns=True) and fill them into the batch's results."""
@@ -635,10 +675,10 @@ class GreedyPipeline:
 
     def prepare(self, batches) -> None:
         """Grow every record slot's storage to the largest of `batches` (device and pinned allocations cost milliseconds: not between
-        two batches of a timed run) and pay the route's one-time costs.  Device-scan mode only; the host-scan mode allocates per
-        shape as before."""
+        two batches of a timed run) and pay the routes' one-time costs.  `batches` in the order run_batches() will get them."""
         first = True
-        for x3d in batches:
+        host_route = []
+        for i, x3d in enumerate(batches):
             if first and self.device_scan:
                 self._warm_device_scan(x3d.device)
                 with self.torch.cuda.stream(self.stream):
@@ -646,11 +686,26 @@ class GreedyPipeline:
                 first = False
             count, rows, cols = x3d.shape
             th, tw = hb.tiles_hw(rows, cols)
+            k1_mask, host_mask, slim = self._layout(x3d)
             if not self._use_device_scan(th * tw):
+                host_route.append((i, count, th * tw, hb.record_doubles(k1_mask), 3 * (len(self.tile_formats) - 1) if self._chain(slim) else hb.record_doubles(host_mask),
+                                   hb.chain_base_doubles(host_mask, self.tile_formats) if self._chain(slim) else 0, x3d.device, slim))
                 continue
-            k1_mask, _hm, _slim = self._layout(x3d)
             for slot in range(self.SLOTS):
                 self._device_buffers(slot, count, th * tw, hb.record_doubles(k1_mask), x3d.device)
+        # host-route batches: the record slot each one will land on (slots rotate per enqueue), its pinned mirror touched once, the
+        # column buffers at the largest shape, the scan threads started
+        for i, count, tiles, rec, rec_host, bd, device, slim in host_route:
+            slot = (self._next_slot + i) % self.SLOTS
+            dev, stage, host, _np = self._buffers(slot, count, tiles, rec, rec_host, device)
+            host.copy_(stage, non_blocking=True)   # first DMA into the pinned pages (mappings are set up lazily)
+            if bd:
+                self._chain_buffers(slot, count, tiles, bd, device)
+            if slim or self.pure_formats:
+                self._column_buffers(count, tiles, device)
+        if host_route:
+            hb.greedy_run_batch(np.zeros((self.workers, 1, hb.record_doubles(0xF))), 0xF, ["bf16"], self.metric, self.threshold, 1024.0,
+                                [1] * self.workers, self.workers)
         self.torch.cuda.synchronize()
 
     def run_batches(self, batches, seeds=None) -> list[list[TensorResult]]:

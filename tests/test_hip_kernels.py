@@ -519,6 +519,44 @@ def test_streamed_pipeline_matches_oracle(scan):
         assert np.array_equal(r.assignment, a) and r.counts == counts, i
 
 
+def test_streamed_pipeline_mixed_routes_in_one_run():
+    """run_batches over batches of three shapes with a tile limit on the device scan: the batch above the limit takes the host route
+    (records over PCIe, threaded scans, columns from the flat column buffers), the others the device route, all in flight together
+    and prepared up front; pure-format columns (wq's `none` rows) come with both.  Maps, counts and columns equal the oracle's."""
+    from quantization_analysis_amd.pipeline import GreedyPipeline
+
+    shapes = [(160, 256), (64, 128), (96, 384)]   # 40, 8 and 36 tiles
+    xs = [np.stack([gen("normal_bf16" if k != 1 else "heavy_bf16", 300 + 10 * k + i, shp) for i in range(3 + k)]) for k, shp in enumerate(shapes)]
+    pipe = GreedyPipeline(ALL, "pcc", 0.998, 77, chunk=2, workers=3, pure_formats=["bfp8", "bfp2"])
+    assert pipe.device_scan
+    pipe.device_scan_max_tiles = 36
+    pipe.host_chunk_tiles = 80
+    pipe.SLOTS = 3
+    batches = [dev(x, bf16=True) for x in xs]
+    try:
+        pipe.prepare(batches)
+        routes = [pipe._use_device_scan(-(-s[0] // 32) * -(-s[1] // 32)) for s in shapes]
+        assert routes == [False, True, True]
+        out = pipe.run_batches(batches)
+        again = pipe.run_batches(batches[::-1])[::-1]   # other slots, other column-buffer views: same answers
+    finally:
+        pipe.close()
+    for k, (x3, res) in enumerate(zip(xs, out)):
+        assert [r.index for r in res] == list(range(len(x3)))
+        for i, r in enumerate(res):
+            a, counts, st = orc.greedy(x3[i], ALL, "pcc", 0.998, 77)
+            assert np.array_equal(r.assignment, a) and r.counts == counts, (k, i)
+            assert np.array_equal(again[k][i].assignment, a), (k, i)
+            pcc, mae, atol = orc.columns_from_stats(st["stats"], orc.mask_slots(0xF), a, x3[i].size)
+            assert abs(r.pcc - pcc) <= 1e-13 and abs(r.mae - mae) <= 1e-13 * max(mae, 1e-30) + 1e-18 and r.atol == atol, (k, i)
+            for f in ("bfp8", "bfp2"):
+                code = ALL.index(f)
+                p2, m2, a2 = orc.columns_from_stats(st["stats"], orc.mask_slots(0xF), np.full_like(a, code), x3[i].size)
+                got = r.pure[f]
+                assert abs(got[0] - p2) <= 1e-13 and abs(got[1] - m2) <= 1e-13 * max(m2, 1e-30) + 1e-18 and got[2] == a2, (k, i, f)
+                assert again[k][i].pure[f] == got
+
+
 def test_chain_records_on_the_device(monkeypatch):
     """mtq_pack_chain_records against NumPy on the same records (bit for bit: one subtraction per value), for the identity-bf16
     layout (2-double side array) and stored-bf16 layouts (5 doubles); and the pipeline with chain records switched off gives the
