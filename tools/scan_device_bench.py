@@ -14,7 +14,8 @@ g = torch.Generator(device='cuda'); g.manual_seed(0)
 x = (torch.randn((n, rows, cols), generator=g, device='cuda') * 0.02).to(torch.bfloat16)
 recs = hb.tile_stats_batched(x, 0xE)
 T = recs.shape[1]
-sd = torch.full((n,), 123, dtype=torch.int64, device='cuda')
+seed_list = [123 + 7919 * i for i in range(n)]   # tensor 0: the headline case's seed; the others distinct
+sd = torch.tensor(seed_list, dtype=torch.int64, device='cuda')
 dec = 0xE | hb.MASK_BF16_IDENTITY
 maps = torch.empty((n, T), dtype=torch.int8, device='cuda'); status = torch.empty((n,), dtype=torch.int32, device='cuda')
 scratch = torch.empty((int(hb.lib().mtq_greedy_scan_scratch_bytes(n, T)),), dtype=torch.uint8, device='cuda')
@@ -27,7 +28,7 @@ for _ in range(reps):
 ts.sort()
 print(f"device scan: {n} tensors x {T} tiles, one wave each: median {ts[len(ts)//2]:.3f} ms per launch (min {ts[0]:.3f}); status {status.cpu().unique().tolist()}")
 h = recs.cpu().numpy()
-t0 = time.perf_counter(); want, _c, _o = hb.greedy_run_batch(h, dec, ALL, "pcc", 0.999, float(rows * cols), [123] * n, 16); dt = time.perf_counter() - t0
+t0 = time.perf_counter(); want, _c, _o = hb.greedy_run_batch(h, dec, ALL, "pcc", 0.999, float(rows * cols), seed_list, 16); dt = time.perf_counter() - t0
 print(f"host scan, 16 threads: {dt*1e3:.2f} ms for {n} tensors; maps equal: {np.array_equal(want, maps.cpu().numpy())}")
 import ctypes
 tk = (ctypes.c_uint64 * 16)()
