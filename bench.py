@@ -305,7 +305,7 @@ def main() -> None:
             "summary": {"tensors": int(all_rows.shape[0]), "mean_pcc": float(all_rows[:, 2].mean()),
                         "counts_bf16_bfp8_bfp4_bfp2": [int(all_rows[:, 6 + i].sum()) for i in range(4)]},
         }
-        if args.cpu_sample > 0:
+        if args.cpu_sample > 0 and world == 1:   # the CPU legs are a N = 1 report: the other ranks would wait in the barrier below
             out.update(cpu_baseline(batch[: min(args.cpu_sample, args.tensors)], cpu_budget()))
         print(json.dumps(out), flush=True)
     pipe.close()
