@@ -24,6 +24,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
 #include <mutex>
 
 #include "../../include/mtq.h"
@@ -639,11 +640,11 @@ extern "C" int mtq_greedy_scan_device(const double *stats, int64_t count, int64_
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (tiles <= kScanMaxTilesLds) {
         const size_t lds = 2 * (size_t)((tiles + 7) & ~(int64_t)7) + kFixedLds;
-        static bool raised = false;
-        if (!raised) {
+        static std::atomic<bool> raised[64];   // per device: the attribute belongs to the function's code object on the current device
+        if (dev >= 64 || !raised[dev].load(std::memory_order_acquire)) {
             if (hipFuncSetAttribute(reinterpret_cast<const void *>(greedy_scan_pcc_lds), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kScanMaxTilesLds + (int)kFixedLds) != hipSuccess)
                 return fail(MTQ_ERR_HIP, "could not raise the dynamic LDS limit");
-            raised = true;
+            if (dev < 64) raised[dev].store(true, std::memory_order_release);
         }
         hipLaunchKernelGGL(greedy_scan_pcc_lds, dim3((unsigned)count), dim3(64), lds, st, a);
     } else {
