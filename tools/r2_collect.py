@@ -1,0 +1,65 @@
+"""Copies the judged summaries of the last `tools/r2_final.sh` run (gpurun_out/r2f/) into profiles/ (tracked) and recomputes
+profiles/k1_traffic.json from the FETCH_SIZE / WRITE_SIZE passes.  gpurun merges every call into gpurun_out/, so each
+directory may hold several runs: the newest file of each kind is taken."""
+import csv, glob, json, os, shutil, sys
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parents[1]
+O, P = ROOT / "gpurun_out" / "r2f", ROOT / "profiles"
+
+
+def newest(pattern):
+    files = sorted(glob.glob(str(O / pattern)), key=os.path.getmtime)
+    if not files:
+        sys.exit(f"nothing matches {pattern}")
+    return files[-1]
+
+
+def rows_of(path, kernel_part):
+    """Mean counter value per dispatch of the kernels whose name contains kernel_part (dimension instances summed)."""
+    per = {}
+    for r in csv.DictReader(open(path)):
+        if kernel_part in r["Kernel_Name"]:
+            per[r["Dispatch_Id"]] = per.get(r["Dispatch_Id"], 0.0) + float(r["Counter_Value"])
+    vals = [v for v in per.values() if v > 1000.0] or list(per.values())   # the warm-up launch of one tensor is not the measured launch
+    big = [v for v in vals if v > 0.5 * max(vals)]
+    return sum(big) / len(big)
+
+
+def slim_counter_csv(src, dst):
+    keep = ["Dispatch_Id", "Kernel_Name", "Grid_Size", "Counter_Name", "Counter_Value"]
+    agg = {}
+    for r in csv.DictReader(open(src)):
+        k = (r["Dispatch_Id"], r["Kernel_Name"][:70], r["Grid_Size"], r["Counter_Name"])
+        agg[k] = agg.get(k, 0.0) + float(r["Counter_Value"])
+    with open(dst, "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(keep)
+        for (d, n, g, c), v in agg.items():
+            w.writerow([d, n, g, c, f"{v:.6f}"])
+
+
+shutil.copy(O / "bench.json", P / "r2_b_bench.json")
+shutil.copy(O / "bench_host_scan.json", P / "r2_b_bench_host_scan.json")
+shutil.copy(O / "bench_under_rocprof.json", P / "r2_b_bench_under_rocprofv3.json")
+shutil.copy(newest("prof_bench/*/*_kernel_stats.csv"), P / "r2_b_bench_kernel_stats.csv")
+shutil.copy(newest("prof_k1/*/*_kernel_stats.csv"), P / "r2_b_k1_only_kernel_stats.csv")
+shutil.copy(O / "scan_device_bench.txt", P / "r2_b_scan_device_bench.txt")
+fetch, write = newest("pmc_fetch/*/*_counter_collection.csv"), newest("pmc_write/*/*_counter_collection.csv")
+slim_counter_csv(fetch, P / "r2_b_pmc_fetch_size.csv")
+slim_counter_csv(write, P / "r2_b_pmc_write_size.csv")
+
+tiles = 128 * 128 * 128
+t = json.loads((P / "k1_traffic.json").read_text())
+k = t["tile_stats_bf16_rolled"]
+k["FETCH_SIZE_KB"], k["WRITE_SIZE_KB"] = rows_of(fetch, "tile_stats_bf16_rolled"), rows_of(write, "tile_stats_bf16_rolled")
+k["read_bytes_corrected"] = 2.0 * 1024.0 * k["FETCH_SIZE_KB"]
+r = t["tile_stats_redo_flagged"]
+r["FETCH_SIZE_KB"], r["WRITE_SIZE_KB"] = rows_of(fetch, "redo_flagged"), rows_of(write, "redo_flagged")
+t["tiles_per_launch"] = tiles
+t["hbm_bytes_per_launch"] = k["read_bytes_corrected"] + 1024.0 * (k["WRITE_SIZE_KB"] + r["FETCH_SIZE_KB"] + r["WRITE_SIZE_KB"])
+t["hbm_bytes_per_tile"] = t["hbm_bytes_per_launch"] / tiles
+(P / "k1_traffic.json").write_text(json.dumps(t, indent=1) + "\n")
+b = json.loads((O / "bench.json").read_text())
+print(f"bench {b['value'] / 1e6:.1f} M tiles/s, {b['ms_per_step']:.3f} ms/step, K1 {b['roofline']['launch_ms']:.3f} ms ({b['roofline']['frac']:.3f}), "
+      f"alone {b['roofline']['kernel_alone']['launch_ms']:.3f} ms ({b['roofline']['kernel_alone']['frac']:.3f}); traffic {t['hbm_bytes_per_tile']:.1f} B/tile")
