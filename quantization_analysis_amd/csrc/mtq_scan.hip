@@ -124,15 +124,18 @@ __device__ inline double shfl_f64(double v, int src)
     const unsigned lo = (unsigned)__shfl((int)(unsigned)u, src, 64), hi = (unsigned)__shfl((int)(unsigned)(u >> 32), src, 64);
     return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
 }
-__device__ inline uint64_t shfl_u64(uint64_t u, int src)
+
+__device__ inline uint64_t readlane_u64(uint64_t u, int src)   // src wave-uniform
 {
-    const unsigned lo = (unsigned)__shfl((int)(unsigned)u, src, 64), hi = (unsigned)__shfl((int)(unsigned)(u >> 32), src, 64);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)u, src), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(u >> 32), src);
     return ((uint64_t)hi << 32) | lo;
 }
 
+__device__ inline double readlane_f64(double v, int src) { return __longlong_as_double((long long)readlane_u64((uint64_t)__double_as_longlong(v), src)); }
+
 // The visiting order of one tensor: 16-bit ids in LDS (tiles <= kScanMaxTilesLds) or 32-bit ids in global scratch.
 struct OrderLds {
-    volatile uint16_t *p;
+    uint16_t *p;   // plain accesses between compiler fences: a volatile pointer loses its LDS address space and every access becomes a FLAT instruction with its own wait
     __device__ uint32_t get(uint32_t i) const { return p[i]; }
     __device__ void set(uint32_t i, uint32_t v) const { p[i] = (uint16_t)v; }
     __device__ void sync() const { __builtin_amdgcn_s_waitcnt(0xC07F); /* lgkmcnt(0) */ __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); }
@@ -160,10 +163,19 @@ struct Rng {
 // Generator.permutation(candidates) in place on `ord[0..n)` (kSwap) or just the generator's advance (the base pass, where the
 // order does not matter: csrc/mtq_host.cpp rng_skip_shuffle).  → false if the batch budget ran out (cannot happen in practice:
 // every batch accepts at least one draw with probability 1 − 2^−64).
+#ifdef MTQ_SCAN_PROFILE   // tools: ticks of block 0 inside the shuffle batches, slots 12 (draws + acceptance), 13 (swaps), 14 (hand-back), 15 (batches)
+#define MTQ_SHUF_TICK(slot) do { const unsigned long long now_ = clock64(); if (blockIdx.x == 0 && lane == 0) g_scan_ticks[slot] += now_ - tick_; tick_ = now_; } while (0)
+#else
+#define MTQ_SHUF_TICK(slot) do { } while (0)
+#endif
+
 template <bool kSwap, typename Order>
 __device__ bool wave_shuffle(Rng &r, const Order &ord, int n, uint32_t *cnt, int lane)
 {
     if (n < 2) return true;
+#ifdef MTQ_SCAN_PROFILE
+    unsigned long long tick_ = clock64();
+#endif
     int i0 = n - 1;
     int budget = 8 * n + 4096;
     while (i0 >= 1) {
@@ -185,7 +197,7 @@ __device__ bool wave_shuffle(Rng &r, const Order &ord, int n, uint32_t *cnt, int
         while (amb) {   // wave-uniform loop over the few undecided lanes, in lane order
             const int a = __builtin_ctzll(amb);
             const int P = __builtin_popcountll(okmask & below(a));
-            const uint32_t va = (uint32_t)__shfl((int)v, a, 64);
+            const uint32_t va = (uint32_t)__builtin_amdgcn_readlane((int)v, a);
             if ((int)va <= i0 - P) okmask |= 1ull << a;
             amb &= amb - 1ull;
         }
@@ -199,6 +211,7 @@ __device__ bool wave_shuffle(Rng &r, const Order &ord, int n, uint32_t *cnt, int
             k = kmax;
             okmask &= below(c);
         }
+        MTQ_SHUF_TICK(12);
         if (kSwap && k > 0) {
             const bool mine = (okmask >> lane) & 1ull;
             const int tstep = __builtin_popcountll(okmask & below(lane));
@@ -215,8 +228,9 @@ __device__ bool wave_shuffle(Rng &r, const Order &ord, int n, uint32_t *cnt, int
             compiler_fence();
             bool flagged = false;
             if (mine) {
-                const volatile uint32_t *vc = cnt;
-                flagged = ((vc[wi] >> si) & 0xFFu) >= 2u || (pj != pi && ((vc[wj] >> sj) & 0xFFu) >= 2u);
+                const uint32_t ci = cnt[wi], cj = cnt[wj];   // both reads issued, one wait
+                const uint32_t fi = ((ci >> si) & 0xFFu) >= 2u ? 1u : 0u, fj = (((cj >> sj) & 0xFFu) >= 2u ? 1u : 0u) & (pj != pi ? 1u : 0u);
+                flagged = (fi | fj) != 0u;                   // no short circuit: the second read must not wait for the first
             }
             compiler_fence();
             if (mine) { atomicSub(&cnt[wi], 1u << si); if (pj != pi) atomicSub(&cnt[wj], 1u << sj); }
@@ -244,18 +258,23 @@ __device__ bool wave_shuffle(Rng &r, const Order &ord, int n, uint32_t *cnt, int
             }
             ord.sync_writes();
         }
+        MTQ_SHUF_TICK(13);
         i0 -= k;
         // ---- hand the unused positions back: the generator stands after the c-th position
         const int used = c - pend;
         if (used > 0) {
-            const int src = c - 1;
-            r.state.lo = shfl_u64(s.lo, src);
-            r.state.hi = shfl_u64(s.hi, src);
+            const int src = c - 1;                 // wave-uniform: lane broadcasts, not LDS permutes
+            r.state.lo = readlane_u64(s.lo, src);
+            r.state.hi = readlane_u64(s.hi, src);
             r.has32 = (used & 1) != 0;
-            r.u32 = (uint32_t)__shfl((int)(uint32_t)(o >> 32), src, 64);
+            r.u32 = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(o >> 32), src);
         } else {
             r.has32 = false;
         }
+        MTQ_SHUF_TICK(14);
+#ifdef MTQ_SCAN_PROFILE
+        if (blockIdx.x == 0 && lane == 0) g_scan_ticks[15] += 1;
+#endif
     }
     return true;
 }
@@ -303,6 +322,9 @@ __device__ void scan_tensor(const ScanArgs &a, const Order &ord, int b, unsigned
     double *lds_i = lds_p + 64 * 4;                                    // [64][5] initial-sum staging
     uint32_t *cnt = reinterpret_cast<uint32_t *>(lds_i + 64 * 5);   // [kTagSlots / 4] byte counters of the shuffle's conflict detection
     int status = 0;
+#ifdef MTQ_SCAN_PROFILE
+    if (b == 0 && lane == 0) for (int q = 12; q < 16; ++q) g_scan_ticks[q] = 0;
+#endif
     unsigned long long tick = clock64();
     auto stamp = [&](int slot) {
         const unsigned long long now = clock64();
@@ -328,6 +350,11 @@ __device__ void scan_tensor(const ScanArgs &a, const Order &ord, int b, unsigned
 
     // ---- initial sums in tile order (:147-174): chains Σx, Σx², Σy, Σy², Σxy on lanes 0..4
     const int off5[5] = {0, 1, a.oy[base], a.oy2[base], a.oxy[base]};
+    // record offsets by format code, one byte each (rec <= 22): a per-lane code picks its offset with a shift, where indexing the
+    // argument arrays by a per-lane value makes every gather wait for a table load
+    const uint32_t poy = (uint32_t)a.oy[0] | ((uint32_t)a.oy[1] << 8) | ((uint32_t)a.oy[2] << 16) | ((uint32_t)a.oy[3] << 24);
+    const uint32_t poy2 = (uint32_t)a.oy2[0] | ((uint32_t)a.oy2[1] << 8) | ((uint32_t)a.oy2[2] << 16) | ((uint32_t)a.oy2[3] << 24);
+    const uint32_t poxy = (uint32_t)a.oxy[0] | ((uint32_t)a.oxy[1] << 8) | ((uint32_t)a.oxy[2] << 16) | ((uint32_t)a.oxy[3] << 24);
     double acc = 0.0;
     double nx[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
     if (lane < T) {
@@ -390,6 +417,7 @@ __device__ void scan_tensor(const ScanArgs &a, const Order &ord, int b, unsigned
     stamp(1);
     for (int p = 1; p < a.n_formats && status == 0 && !all_fixed; ++p) {
         const int f = a.fmt[p];
+        const int oy_f = (int)((poy >> (8 * f)) & 0xFFu), oy2_f = (int)((poy2 >> (8 * f)) & 0xFFu), oxy_f = (int)((poxy >> (8 * f)) & 0xFFu);
         // candidates = np.where(~fixed)[0] (:228): in tile order
         int nc = 0;
         for (int t0 = 0; t0 < T; t0 += 64) {
@@ -418,9 +446,10 @@ __device__ void scan_tensor(const ScanArgs &a, const Order &ord, int b, unsigned
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const double *rt = st + (int64_t)tt[u] * rec;
-                dd[u][0] = rt[a.oy[f]] - rt[a.oy[pv[u]]];     // :259-261
-                dd[u][1] = rt[a.oy2[f]] - rt[a.oy2[pv[u]]];
-                dd[u][2] = rt[a.oxy[f]] - rt[a.oxy[pv[u]]];
+                const int sh = 8 * pv[u];                     // the previous format's offsets out of the packed tables: no indexed load
+                dd[u][0] = rt[oy_f] - rt[(poy >> sh) & 0xFFu];   // :259-261
+                dd[u][1] = rt[oy2_f] - rt[(poy2 >> sh) & 0xFFu];
+                dd[u][2] = rt[oxy_f] - rt[(poxy >> sh) & 0xFFu];
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -508,7 +537,7 @@ __device__ void scan_tensor(const ScanArgs &a, const Order &ord, int b, unsigned
                 if (j < m) { if (lane == j) map[t] = (int8_t)f; take = j; k += j + 1; if (j == 0) accept_mode = true; }
                 else k += m;
             }
-            if (take >= 0) { Sy = shfl_f64(cy, take); Sy2 = shfl_f64(cy2, take); Sxy = shfl_f64(cxy, take); }
+            if (take >= 0) { Sy = readlane_f64(cy, take); Sy2 = readlane_f64(cy2, take); Sxy = readlane_f64(cxy, take); }   // take is wave-uniform
         }
         mem_wait();
         stamp(4 + 3 * (p - 1));
@@ -533,7 +562,7 @@ __global__ __launch_bounds__(64) void greedy_scan_pcc_lds(ScanArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int lane = threadIdx.x;
-    OrderLds ord{reinterpret_cast<volatile uint16_t *>(lds)};
+    OrderLds ord{reinterpret_cast<uint16_t *>(lds)};
     scan_tensor(a, ord, blockIdx.x, lds + 2 * ((a.tiles + 7) & ~(int64_t)7), lane);
 }
 

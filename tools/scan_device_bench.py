@@ -36,3 +36,6 @@ hb.check(hb.lib().mtq_debug_scan_ticks(tk))
 names = ["init sums", "base pass + draw-only shuffle"] + [f"pass {p}: {w}" for p in (1, 2, 3) for w in ("candidates + shuffle", "deltas", "visits")]
 tot = sum(tk[:11])
 print("phase ticks of tensor 0 (shader clock):", ", ".join(f"{nm} {tk[i]/1e3:.0f}k" for i, nm in enumerate(names)), f"| total {tot/1e3:.0f}k")
+if any(tk[12:16]):   # a library built with -DMTQ_SCAN_PROFILE: inside the shuffle batches of tensor 0
+    nb = max(int(tk[15]), 1)
+    print(f"shuffle batches of tensor 0: {nb}; per batch: draws + acceptance {tk[12]/nb:.0f}, swaps {tk[13]/nb:.0f}, hand-back {tk[14]/nb:.0f} ticks")
