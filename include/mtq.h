@@ -283,6 +283,14 @@ int mtq_greedy_scan_device(const double *stats, int64_t count, int64_t tiles, ui
                            int metric, double threshold, double elem_count, const uint64_t *seeds, int8_t *maps, int32_t *status,
                            int32_t *counts, void *scratch, size_t scratch_bytes, void *stream);
 
+/* Results home without a copy engine (no reference counterpart: the reference's arrays are host arrays).  A kernel copies `rows` rows
+ * of `width_bytes` bytes from src (pitch src_pitch) to dst (pitch dst_pitch) on `stream`; dst may be pinned host memory
+ * (hipHostMalloc / torch pin_memory: mapped into the device's address space), in which case the stores cross PCIe from the kernel
+ * and the data are on the host when an event recorded behind the call has completed.  The streamed driver brings maps, counts and
+ * column sums back this way: an asynchronous device-to-host memcpy of a few MB was seen to hold the calling thread until the stream
+ * had drained.  Pointers device-accessible, pitches >= width_bytes, rows >= 1. */
+int mtq_device_copy_2d(void *dst, size_t dst_pitch, const void *src, size_t src_pitch, size_t width_bytes, size_t rows, void *stream);
+
 /* Diagnostics (no reference counterpart).  K1's persistent waves claim their units from device counters that come from a
  * per-device ring of slots (csrc/mtq_slot_ring.hpp): a slot is handed out again only behind the event recorded after its
  * previous launch's reset, so any number of launches may be pending on any streams.  This runs that bookkeeping against

@@ -5,6 +5,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 
+#include <algorithm>
 #include <atomic>
 #include <mutex>
 
@@ -355,6 +356,40 @@ struct MockOps {
 };
 int MockOps::created = 0, MockOps::waits = 0, MockOps::last_wait_event = -1, MockOps::last_wait_stream = -1;
 } // namespace
+
+namespace {
+template <typename W>
+__global__ __launch_bounds__(256) void copy_rows(W *__restrict__ dst, size_t dst_pitch_w, const W *__restrict__ src, size_t src_pitch_w, size_t width_w, size_t total)
+{
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const size_t r = i / width_w, c = i - r * width_w;
+        dst[r * dst_pitch_w + c] = src[r * src_pitch_w + c];
+    }
+}
+template <typename W>
+void launch_copy_rows(void *dst, size_t dp, const void *src, size_t sp, size_t width, size_t rows, hipStream_t s)
+{
+    const size_t total = width / sizeof(W) * rows;
+    const unsigned blocks = (unsigned)std::min<size_t>((total + 255) / 256, 4096);
+    hipLaunchKernelGGL(copy_rows<W>, dim3(blocks), dim3(256), 0, s, static_cast<W *>(dst), dp / sizeof(W), static_cast<const W *>(src), sp / sizeof(W),
+                       width / sizeof(W), total);
+}
+} // namespace
+
+extern "C" int mtq_device_copy_2d(void *dst, size_t dst_pitch, const void *src, size_t src_pitch, size_t width_bytes, size_t rows, void *stream)
+{
+    if (!dst || !src) return fail(MTQ_ERR_INVALID, "null argument");
+    if (width_bytes == 0 || rows == 0) return fail(MTQ_ERR_INVALID, "width_bytes and rows must be positive");
+    if (dst_pitch < width_bytes || src_pitch < width_bytes) return fail(MTQ_ERR_INVALID, "a pitch is smaller than the row");
+    if (int rc = require_device()) return rc;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (rows > 1 && dst_pitch == width_bytes && src_pitch == width_bytes) { width_bytes *= rows; dst_pitch = src_pitch = width_bytes; rows = 1; }   // contiguous
+    const uintptr_t all = reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(src) | width_bytes | (rows > 1 ? (dst_pitch | src_pitch) : 0);
+    if (all % 16 == 0) launch_copy_rows<uint4>(dst, dst_pitch, src, src_pitch, width_bytes, rows, s);
+    else if (all % 8 == 0) launch_copy_rows<unsigned long long>(dst, dst_pitch, src, src_pitch, width_bytes, rows, s);
+    else launch_copy_rows<unsigned char>(dst, dst_pitch, src, src_pitch, width_bytes, rows, s);
+    return check_launch("mtq_device_copy_2d");
+}
 
 extern "C" int mtq_selftest_slot_ring(void)
 {

@@ -31,7 +31,7 @@ EXPORTS = [
     "mtq_greedy_run_chain", "mtq_greedy_run_chain_batch", "mtq_pack_chain_records", "mtq_tile_scores", "mtq_threshold_assign", "mtq_columns_from_stats", "mtq_columns_from_sums", "mtq_tile_scores_device",
     "mtq_threshold_assign_device", "mtq_columns_scratch_doubles", "mtq_column_sums_device", "mtq_column_sums_device_batched",
     "mtq_rng_create", "mtq_rng_permutation", "mtq_rng_integers", "mtq_rng_destroy", "mtq_greedy_run", "mtq_greedy_run_batch",
-    "mtq_selftest_slot_ring", "mtq_greedy_scan_scratch_bytes", "mtq_greedy_scan_device", "mtq_debug_scan_ticks",
+    "mtq_selftest_slot_ring", "mtq_device_copy_2d", "mtq_greedy_scan_scratch_bytes", "mtq_greedy_scan_device", "mtq_debug_scan_ticks",
 ]
 
 
@@ -111,6 +111,7 @@ def lib() -> ctypes.CDLL:
     L.mtq_greedy_scan_scratch_bytes.restype = ctypes.c_size_t
     L.mtq_greedy_scan_device.argtypes = [vp, i64, i64, u32, vp, ci, ci, dbl, dbl, vp, vp, vp, vp, vp, ctypes.c_size_t, vp]
     L.mtq_selftest_slot_ring.restype = ci
+    L.mtq_device_copy_2d.argtypes = [vp, ctypes.c_size_t, vp, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_size_t, vp]
     if L.mtq_version() < 123:
         raise MtqError("libmtq_hip.so is older than this package")
     _lib = L
@@ -433,6 +434,37 @@ SCAN_LDS_MAX_TILES = 32768      # csrc/mtq_scan.hip kScanMaxTilesLds: visiting o
 def device_scan_supported(formats, metric: str, tiles: int) -> bool:
     """What mtq_greedy_scan_device serves (include/mtq.h): the pcc metric, distinct formats, tiles up to SCAN_DEVICE_MAX_TILES."""
     return metric == "pcc" and len(set(formats)) == len(formats) and 0 < tiles <= SCAN_DEVICE_MAX_TILES
+
+
+def device_copy(dst, src) -> None:
+    """dst ← src by a kernel on the current stream (mtq_device_copy_2d); dst may be a pinned host tensor, src a device tensor.  Both
+    either contiguous with the same number of bytes, or 2-D / 3-D views whose rows (last dimension) are contiguous and whose leading
+    dimensions collapse to one pitch."""
+    import torch
+
+    if dst.dtype != src.dtype or dst.shape != src.shape:
+        raise ValueError("device_copy needs equal shapes and dtypes")
+    if dst.numel() == 0:
+        return
+    esz = dst.element_size()
+
+    def rows_of(t):
+        if t.is_contiguous():
+            return t.numel() * esz, 1, t.numel() * esz
+        if t.dim() < 2 or t.stride(-1) != 1:
+            raise ValueError("device_copy needs contiguous rows")
+        lead = t.reshape(-1, t.shape[-1]) if all(t.stride(i) == t.stride(i + 1) * t.shape[i + 1] for i in range(t.dim() - 2)) else None
+        if lead is None or lead.data_ptr() != t.data_ptr():
+            raise ValueError("device_copy needs one pitch over the leading dimensions")
+        return t.shape[-1] * esz, lead.shape[0], lead.stride(0) * esz
+
+    w_d, r_d, p_d = rows_of(dst)
+    w_s, r_s, p_s = rows_of(src)
+    if r_d == 1 and r_s > 1:      # contiguous on one side: its rows are the other side's rows
+        w_d, r_d, p_d = w_s, r_s, w_s
+    if r_s == 1 and r_d > 1:
+        w_s, r_s, p_s = w_d, r_d, w_d
+    check(lib().mtq_device_copy_2d(dst.data_ptr(), p_d, src.data_ptr(), p_s, w_d, r_d, _stream_ptr()))
 
 
 def greedy_scan_device(stats_dev, mask: int, formats, metric: str, threshold: float, elem_count: float, seeds_dev, maps_out=None,

@@ -448,19 +448,21 @@ class GreedyPipeline:
                 scanned.record(scan_stream)
             if trace:
                 marks.append(("scan+sums", time.perf_counter()))
-            copy_stream = self.copy_stream
-            copy_stream.wait_event(scanned)
-            with torch.cuda.stream(copy_stream):
-                b["maps_host"][first:first + n].copy_(maps, non_blocking=True)
-                b["status_host"][first:first + n].copy_(b["status_dev"][first:first + n], non_blocking=True)
-                b["counts_host"][first:first + n].copy_(b["counts_dev"][first:first + n], non_blocking=True)
-                b["sums_host"][:, first:first + n].copy_(b["sums_dev"][:, first:first + n, :7], non_blocking=True)
+            # results home by a kernel on the scan stream itself (stores into the pinned mirrors: hb.device_copy).  An asynchronous
+            # device-to-host memcpy of the batch's 2 MB of maps held this thread until its stream had drained — 7 ms, a couple of times
+            # in the first steps of a process — and needed a copy stream with two more cross-stream events per chunk
+            with torch.cuda.stream(scan_stream):
+                hb.device_copy(b["maps_host"][first:first + n], maps)
+                hb.device_copy(b["status_host"][first:first + n], b["status_dev"][first:first + n])
+                hb.device_copy(b["counts_host"][first:first + n], b["counts_dev"][first:first + n])
+                for q in range(b["sums_dev"].shape[0]):
+                    hb.device_copy(b["sums_host"][q, first:first + n], b["sums_dev"][q, first:first + n, :7])
                 done = torch.cuda.Event(blocking=True, enable_timing=trace)
-                done.record(copy_stream)
+                done.record(scan_stream)
             pending.append((done, first, n))
             if trace:
                 self._trace_rows = getattr(self, "_trace_rows", []) + [(count, tiles, e0, e1, scanned, done, time.perf_counter())]
-            b["free"].append(scanned)
+            b["free"].append(done)
         enq = {"device": True, "buf": b, "pending": pending, "tiles_hw": (th, tw), "numel": n_el, "x": x3d, "dec_mask": dec_mask,
                "seeds": sh.copy()}
         self._open.append(enq)

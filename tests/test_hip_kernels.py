@@ -557,6 +557,33 @@ def test_streamed_pipeline_mixed_routes_in_one_run():
                 assert again[k][i].pure[f] == got
 
 
+def test_device_copy_into_pinned_memory():
+    """mtq_device_copy_2d (hb.device_copy): how the streamed driver brings maps, counts and sums home — a kernel storing into pinned
+    host memory.  Contiguous (16-byte, 8-byte and byte paths), strided rows (the [:, :7] of the column-sum scratch), odd offsets."""
+    g = torch.Generator(device="cuda")
+    g.manual_seed(5)
+    for numel, off in ((1 << 20, 0), (4099, 0), (4099, 3), (17, 1)):
+        src = torch.randint(-128, 127, (numel + 8,), generator=g, device="cuda", dtype=torch.int8)[off:off + numel]
+        dst = torch.zeros((numel + 8,), dtype=torch.int8, pin_memory=True)
+        hb.device_copy(dst[off:off + numel], src)
+        torch.cuda.synchronize()
+        assert torch.equal(dst[off:off + numel], src.cpu()) and int(dst[:off].abs().sum()) == 0 and int(dst[off + numel:].abs().sum()) == 0
+    scratch = torch.randn((3, 9, 455), generator=g, device="cuda", dtype=torch.float64)
+    host = torch.zeros((3, 9, 7), dtype=torch.float64, pin_memory=True)
+    for q in range(3):
+        hb.device_copy(host[q, 2:7], scratch[q, 2:7, :7])
+    torch.cuda.synchronize()
+    assert torch.equal(host[:, 2:7], scratch[:, 2:7, :7].cpu()) and float(host[:, :2].abs().sum()) == 0.0 and float(host[:, 7:].abs().sum()) == 0.0
+    dev_dst = torch.zeros((5, 33), dtype=torch.int32, device="cuda")
+    src2 = torch.arange(5 * 40, dtype=torch.int32, device="cuda").view(5, 40)
+    hb.device_copy(dev_dst, src2[:, 3:36])       # device to device, 4-byte rows at an odd pitch: the byte path
+    assert torch.equal(dev_dst, src2[:, 3:36])
+    with pytest.raises(ValueError):
+        hb.device_copy(dev_dst, src2[:, 3:36].to(torch.int64))
+    with pytest.raises(ValueError):
+        hb.device_copy(dev_dst.t(), src2[:, 3:36].t())
+
+
 def test_chain_records_on_the_device(monkeypatch):
     """mtq_pack_chain_records against NumPy on the same records (bit for bit: one subtraction per value), for the identity-bf16
     layout (2-double side array) and stored-bf16 layouts (5 doubles); and the pipeline with chain records switched off gives the

@@ -1,12 +1,11 @@
 set -o pipefail
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r2ab; rm -rf $O; mkdir -p $O
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r2ab; rm -rf $O; mkdir -p $O/wq
 cd $R
+timeout -k 10 600 python -m pytest tests/test_hip_kernels.py tests/test_cli.py -x -q -m gpu 2>&1 | tail -2
+python tools/k1_gaps.py 128 20 3 2>&1 | grep -v amdgpu.ids | grep "steps of\|gaps"
 show() { python -c "
 import json,sys; d=json.load(open(sys.argv[1])); print(sys.argv[2], '%.1f M tiles/s' % (d['value']/1e6), '%.3f ms/step' % d['ms_per_step'], 'K1 %.3f ms' % d['roofline']['launch_ms'], 'alone %.3f' % d['roofline']['kernel_alone']['launch_ms'], 'cpu %.1f' % d['config']['host_cpu_ms_per_step'])" $1 $2; }
-run() { tag=$1; shift; env "$@" python bench.py --cpu-sample 0 > $O/b_$tag.json 2>/dev/null; show $O/b_$tag.json $tag; }
-run base_a X=1
-run v128_a MTQ_LIB=$R/quantization_analysis_amd/libmtq_hip_v128.so
-run v128w4_a MTQ_LIB=$R/quantization_analysis_amd/libmtq_hip_v128w4.so
-run base_b X=1
-run v128_b MTQ_LIB=$R/quantization_analysis_amd/libmtq_hip_v128.so
-run v128w4_b MTQ_LIB=$R/quantization_analysis_amd/libmtq_hip_v128w4.so
+python bench.py --cpu-sample 0 --steps 20 --warmup 3 > $O/b_s20.json 2>/dev/null; show $O/b_s20.json steps20
+python bench.py --cpu-sample 0 --steps 20 --warmup 3 > $O/b_s20b.json 2>/dev/null; show $O/b_s20b.json steps20
+python bench.py --cpu-sample 0 > $O/b.json 2>/dev/null; show $O/b.json default
+(cd $O/wq && python $R/wq synthetic:llama3-8b model.layers --backend hip --no-plots --compression-config $R/compression_configs/greedy_seed123.json > $O/wq.log 2>&1; echo "wq rc=$? $(grep streamed $O/wq.log | cut -c60-160)")
