@@ -790,6 +790,15 @@ class ThresholdPipeline:
         self.chunk = int(chunk)
         self.quantizer = Quantizer("hip")
         self.knife_tiles = 0
+        self._pin = {}
+
+    def _pinned(self, name: str, numel: int, dtype):
+        """Flat pinned host storage that only grows (a pinned allocation costs milliseconds)."""
+        t = self._pin.get(name)
+        if t is None or t.numel() < numel or t.dtype != dtype:
+            t = self.torch.zeros((int(numel * 1.25) + 16,), dtype=dtype, pin_memory=True)
+            self._pin[name] = t
+        return t[:numel]
 
     def _rescore_chunk(self, xc, maps: np.ndarray, near: np.ndarray, jj: np.ndarray, tt: np.ndarray, tiles_w: int) -> None:
         """The knife-edge tiles of a whole chunk at once: one indexed gather on the device, then per format K2 and the
@@ -827,40 +836,55 @@ class ThresholdPipeline:
         k1_mask = self.mask & 0xE if identity else self.mask
         dec_mask = k1_mask | hb.MASK_BF16_IDENTITY if identity else self.mask
         scratch_n = int(hb.lib().mtq_columns_scratch_doubles())
+        P = 1 + len(self.pure_formats)
+        nf = len(MIXED_TILE_FORMATS)
+        # pinned mirrors of what comes back (2 B per tile, then 7 sums and 4 counts per tensor): kernels store into them (hb.device_copy),
+        # the driver waits twice per batch — a pageable `.to("cpu")` per chunk blocked until the chunk's kernels had run, with the GPU idle
+        # until the next chunk was launched
+        both_host = self._pinned("both", 2 * count * tiles, torch.int8)
+        sums_host = self._pinned("sums", P * count * 7, torch.float64).view(P, count, 7)
+        counts_host = self._pinned("counts", count * nf, torch.int64).view(count, nf)
         results: list[TensorResult] = []
-        launched = []  # (first, n, records, map+flags on the device, their host copy in flight)
+        launched = []  # (first, n, records, map + flags on the device, their pinned mirror)
         for first in range(0, count, self.chunk):
             n = min(self.chunk, count - first)
             recs = hb.tile_stats_batched(x3d[first:first + n], k1_mask)                       # [n, tiles, rec] on the device
             both = hb.threshold_assign_device_raw(recs.view(n * tiles, -1), dec_mask, self.tile_formats, self.metric, self.threshold, self.band)
-            launched.append((first, n, recs, both, both.to("cpu", non_blocking=True)))
+            mirror = both_host[2 * first * tiles:2 * (first + n) * tiles].view(2, n * tiles)
+            hb.device_copy(mirror, both)
+            launched.append((first, n, recs, both, mirror))
         torch.cuda.current_stream().synchronize()
-        codes = torch.arange(len(MIXED_TILE_FORMATS), dtype=torch.int8, device=x3d.device)
-        summed = []  # (first, n, host maps, column sums and per-format tile counts on the device)
-        for first, n, recs, both, host in launched:
-            maps = host[0].numpy().reshape(n, tiles).copy()
-            near = host[1].numpy().reshape(n, tiles)                                           # per tile: mask of format codes inside the band
+        codes = torch.arange(nf, dtype=torch.int8, device=x3d.device)
+        all_maps = []
+        for first, n, recs, both, mirror in launched:
+            host = mirror.numpy()
+            maps = host[0].reshape(n, tiles).copy()                                            # the mirror is reused by the next batch
+            near = host[1].reshape(n, tiles)                                                   # per tile: mask of format codes inside the band
             jj, tt = np.divmod(np.flatnonzero(near.view(np.bool_)), tiles)                     # knife-edge (tensor, tile) pairs of the chunk (few)
             dirty = jj.size > 0
             if dirty:
                 self._rescore_chunk(x3d[first:first + n], maps, near, jj, tt, tw)
                 self.knife_tiles += int(jj.size)
             dmaps = (torch.from_numpy(maps).to(x3d.device) if dirty else both[0].view(n, tiles)).contiguous()
-            scratch = torch.empty((1 + len(self.pure_formats), n, scratch_n), dtype=torch.float64, device=x3d.device)
+            scratch = torch.empty((P, n, scratch_n), dtype=torch.float64, device=x3d.device)
             hb.check(hb.lib().mtq_column_sums_device_batched(recs.data_ptr(), n, tiles, dec_mask, dmaps.data_ptr(), scratch[0].data_ptr(), hb._stream_ptr()))
             for k, f in enumerate(self.pure_formats):   # wq's `none` rows from the same records
                 pm = torch.full((n, tiles), MIXED_TILE_FORMATS.index(f), dtype=torch.int8, device=x3d.device)
                 hb.check(hb.lib().mtq_column_sums_device_batched(recs.data_ptr(), n, tiles, dec_mask, pm.data_ptr(), scratch[1 + k].data_ptr(), hb._stream_ptr()))
-            summed.append((first, n, maps, scratch, (dmaps.unsqueeze(-1) == codes).sum(dim=1)))   # counts ≡ np.bincount per tensor
+            for q in range(P):
+                hb.device_copy(sums_host[q, first:first + n], scratch[q, :, :7])
+            hb.device_copy(counts_host[first:first + n], (dmaps.unsqueeze(-1) == codes).sum(dim=1))   # counts ≡ np.bincount per tensor
+            all_maps.append(maps)
+        torch.cuda.current_stream().synchronize()                                              # one wait for all chunks' sums and counts
         k = {"pcc": 0, "mae": 1, "atol": 2}[self.metric]
-        for first, n, maps, scratch, counts_dev in summed:                                      # one wait for all chunks' sums
-            sums = scratch[:, :, :7].cpu().numpy()
-            cols = columns_from_sums_batch(sums[0], float(numel))
-            pure_cols = [columns_from_sums_batch(sums[1 + i], float(numel)) for i in range(len(self.pure_formats))]
-            bc = counts_dev.cpu().numpy()
-            for j in range(n):
-                counts = {f: int(bc[j, i]) for i, f in enumerate(MIXED_TILE_FORMATS)}
-                pure = {f: tuple(float(v) for v in pure_cols[i][j]) for i, f in enumerate(self.pure_formats)} or None
-                results.append(TensorResult(first + j, maps[j].reshape(th, tw), counts, mixed_tile_total_bytes(counts), float(cols[j, 0]),
-                                            float(cols[j, 1]), float(cols[j, 2]), float(cols[j, k]), pure))
+        sums = sums_host.numpy()
+        cols = columns_from_sums_batch(sums[0], float(numel))
+        pure_cols = [columns_from_sums_batch(sums[1 + i], float(numel)) for i in range(len(self.pure_formats))]
+        bc = counts_host.numpy()
+        maps_all = np.concatenate(all_maps, axis=0) if all_maps else np.zeros((0, tiles), dtype=np.int8)
+        for j in range(count):
+            counts = {f: int(bc[j, i]) for i, f in enumerate(MIXED_TILE_FORMATS)}
+            pure = {f: tuple(float(v) for v in pure_cols[i][j]) for i, f in enumerate(self.pure_formats)} or None
+            results.append(TensorResult(j, maps_all[j].reshape(th, tw), counts, mixed_tile_total_bytes(counts), float(cols[j, 0]),
+                                        float(cols[j, 1]), float(cols[j, 2]), float(cols[j, k]), pure))
         return results
