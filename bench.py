@@ -230,16 +230,17 @@ def main() -> None:
     k1_alone_ms = sorted(alone)[len(alone) // 2]
     del alone_out
     pipe.reserve(batch)  # record buffers of both slots + scan threads: allocations, not steps
-    res = pipe.run_steps(batch for _ in range(args.warmup))
-    pipe.timing.drain()
-    pipe.timing.__init__()
-
     # a generation-2 collection of the interpreter's heap (torch's module graph: ~40 ms here) would land inside a 7 ms
-    # step every few dozen steps: collect now and move what exists to the permanent generation
+    # step every few dozen steps: collect now and move what exists to the permanent generation.  BEFORE the warm-up steps, not
+    # between them and the timed ones: the GPU idles while the collector runs, its clocks fall, and the first six launches of the
+    # timed region then ran 5-12 % slower (2.7-2.9 ms against 2.5: visible in a 20-step run)
     import gc
 
     gc.collect()
     gc.freeze()
+    res = pipe.run_steps(batch for _ in range(args.warmup))
+    pipe.timing.drain()
+    pipe.timing.__init__()
     barrier()
     cpu0 = time.process_time()
     t0 = time.perf_counter()

@@ -130,7 +130,7 @@ class GreedyPipeline:
     SLOTS = int(os.environ.get("MTQ_PIPE_SLOTS", "3"))   # record slots = batches in flight: one on the GPU, one queued behind it, one being scanned (see run_steps)
 
     def __init__(self, tile_formats=None, metric: str = "pcc", threshold: float = 0.999, seed: int = 123,
-                 chunk: int = 8, workers: int = 8, pure_formats=(), scan: str = "auto"):
+                 chunk: int = 8, workers: int = 8, pure_formats=(), scan: str = "auto", scan_streams: int | None = None):
         """scan: "device" — the sequential scan runs on the GPU where K1 wrote the records (csrc/mtq_scan.hip: only maps, counts and
         seven sums per tensor cross PCIe, the host does not scan); "host" — records over PCIe, scans on host threads; "auto" —
         "device" where mtq_greedy_scan_device serves the search (pcc metric, distinct formats), else "host".  MTQ_DEVICE_SCAN=0
@@ -167,8 +167,12 @@ class GreedyPipeline:
         self.host_chunk_tiles = None             # host route: tiles per K1 launch / records copy / scan task (None: self.chunk tensors)
         # device scans + column sums: behind their chunk's K1, beside the next chunks' K1.  A scan is one wave per tensor for a few
         # milliseconds (latency-bound), so consecutive chunks' scans must overlap each other: a ring of streams
+        # How many: as many as scans of consecutive batches overlap.  Steps of one shape (bench.py: a 2.0 ms scan launch per 2.5 ms step)
+        # overlap two — three streams; with eight, K1's launch measured 2.5 % longer and the step 3 % (806 against 829 M tiles/s:
+        # more hardware queues in play).  A model's shape groups (streamed.py) keep every batch of a window in flight and ask for eight.
+        n_scan = int(os.environ.get("MTQ_SCAN_STREAMS", str(3 if scan_streams is None else scan_streams)))
         self.scan_streams = [torch.cuda.Stream(priority=int(os.environ.get("MTQ_SCAN_PRIORITY", "-1")))
-                             for _ in range(int(os.environ.get("MTQ_SCAN_STREAMS", "8")))]   # priority -1: ahead of K1's blocks when a slot opens
+                             for _ in range(max(1, n_scan))]   # priority -1: ahead of K1's blocks when a slot opens
         self._scan_rr = 0
         self.host_fallbacks = 0                  # tensors the device scan handed back (zero denominator)
         self.host_seconds = {"enqueue": 0.0, "wait": 0.0, "wrap": 0.0}   # driver-thread time: launching, waiting for results, wrapping them

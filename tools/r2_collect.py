@@ -41,6 +41,7 @@ def slim_counter_csv(src, dst):
 
 shutil.copy(O / "bench.json", P / "r2_b_bench.json")
 shutil.copy(O / "bench_host_scan.json", P / "r2_b_bench_host_scan.json")
+shutil.copy(O / "bench_steps20.json", P / "r2_b_bench_steps20.json")
 shutil.copy(O / "bench_under_rocprof.json", P / "r2_b_bench_under_rocprofv3.json")
 shutil.copy(newest("prof_bench/*/*_kernel_stats.csv"), P / "r2_b_bench_kernel_stats.csv")
 shutil.copy(newest("prof_k1/*/*_kernel_stats.csv"), P / "r2_b_k1_only_kernel_stats.csv")

@@ -5,6 +5,7 @@ cd $R
 timeout -k 10 1000 python -m pytest tests -q -m gpu > $O/gpu_tests.log 2>&1; echo "gpu tests rc=$?"; tail -2 $O/gpu_tests.log
 python __graft_entry__.py smoke > $O/smoke.log 2>&1; echo "smoke rc=$?"
 python bench.py > $O/bench.json 2> $O/bench.err; echo "bench rc=$?"
+python bench.py --cpu-sample 0 --steps 20 --warmup 3 > $O/bench_steps20.json 2> $O/bench_steps20.err; echo "bench 20 steps rc=$?"
 python bench.py --scan host --cpu-sample 0 > $O/bench_host_scan.json 2> $O/bench_host_scan.err; echo "bench host-scan rc=$?"
 python tools/scan_device_bench.py 128 3 > $O/scan_device_bench.txt 2>&1; echo "scan bench rc=$?"
 mkdir -p $O/wq && ( cd $O/wq && python $R/wq synthetic:llama3-8b model.layers --backend hip --no-plots --compression-config $R/compression_configs/greedy_seed123.json > $O/wq_llama.log 2>&1; echo "wq llama rc=$?" ); grep streamed $O/wq_llama.log
