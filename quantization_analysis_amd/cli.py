@@ -367,17 +367,24 @@ def _evaluate_shard(shard, tensor_names, index, algorithms, selected_algo, forma
                 deferred.append((idx, tensor_names[idx], assignment))
         finally:
             ev.close()
+        streamed_note = None
         if ev.compute_tiles:
             k1 = f", K1 {ev.k1_tiles / max(ev.k1_ms, 1e-9) / 1e3:.1f} M tiles/s" if ev.k1_ms else ""
-            notes.append(f"[rank {rank}] streamed {len(deferred)} tensors in {len(groups)} shape groups: {ev.compute_tiles} tiles in {ev.compute_seconds:.3f} s "
-                         f"of GPU pipeline = {ev.compute_tiles / max(ev.compute_seconds, 1e-9) / 1e6:.1f} M tiles/s (loader and artifacts excluded{k1})")
+            streamed_note = (f"[rank {rank}] streamed {len(deferred)} tensors in {len(groups)} shape groups: {ev.compute_tiles} tiles in {ev.compute_seconds:.3f} s "
+                             f"of GPU pipeline = {ev.compute_tiles / max(ev.compute_seconds, 1e-9) / 1e6:.1f} M tiles/s (loader and artifacts excluded{k1})")
+            load_s = ev.load_seconds
+    else:
+        streamed_note = None
     for i in per_tensor:
         rows_by_idx[i] = _evaluate_tensor(i, tensor_names[i], index, algorithms, formats, quantizer, args, run_tag, processed_root, results_dir)
     algo_dir = selected_algo.name.replace("-", "_")
+    t_art = time.perf_counter()
     for idx, name, assignment in deferred:   # wq:696-750, after the GPU work
         write_assignment_outputs(results_dir, name, assignment, algo_dir, not args.no_plots)
         if not args.no_plots:
             write_size_plot(results_dir, name, selected_algo.params.get("metric", "pcc"), rows_by_idx[idx], formats, selected_algo.name)
+    if streamed_note:   # where the wall time of the streamed part went: the path itself is the middle number
+        notes.append(streamed_note + f"; wall: loader {load_s:.1f} s, pipeline {ev.compute_seconds:.3f} s, maps and plots to disk {time.perf_counter() - t_art:.1f} s")
     ordered = [rows_by_idx[i] for i in sorted(rows_by_idx)]
     return (np.concatenate(ordered) if ordered else np.zeros((0, ROW_W))), notes
 

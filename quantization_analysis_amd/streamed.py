@@ -10,12 +10,13 @@ Vectors and scalars (their 2-D image is zero-filled: tile_utils.py:96-102) keep 
 """
 from __future__ import annotations
 
+import concurrent.futures as cf
 import time
 
 import numpy as np
 
 from .compression_algorithms.tile_utils import MIXED_TILE_FORMATS
-from .pipeline import GreedyPipeline, ThresholdPipeline, default_workers
+from .pipeline import GreedyPipeline, ThresholdPipeline, cpu_budget, default_workers
 from .quantization_formats import SUPPORTED_FORMATS
 
 STREAMED_ALGOS = {"mixed-tile-greedy", "mixed-tile-threshold"}
@@ -59,6 +60,7 @@ class ShardEvaluator:
         self.pure = [f for f in formats if f in MIXED_TILE_FORMATS]
         self.compute_seconds = 0.0
         self.compute_tiles = 0
+        self.load_seconds = 0.0      # tensors to HBM (synthetic presets: drawn on the CPU; safetensors: read + H2D) and their min / mean / max
         self.k1_ms = 0.0
         self.k1_tiles = 0
         self._pipe = None
@@ -80,7 +82,15 @@ class ShardEvaluator:
         """→ (x3d on the device, per-tensor (min, mean, max, mean|x|, max|x|)) — the loader; not part of the timed pipeline."""
         import torch
 
-        xs = [self.index.load(n, device=self.device) for _i, n in part]
+        # tensors are independent (a synthetic preset draws each from its own seeded CPU generator, a checkpoint reads each from its
+        # file): loaded by a few threads — the draw and the file read release the interpreter lock — in the order of `part`
+        names = [n for _i, n in part]
+        workers = max(1, min(8, cpu_budget(), len(names)))
+        if workers > 1:
+            with cf.ThreadPoolExecutor(max_workers=workers) as pool:
+                xs = list(pool.map(lambda n: self.index.load(n, device=self.device), names))
+        else:
+            xs = [self.index.load(n, device=self.device) for n in names]
         metas = []
         for x in xs:
             xf = x.float()
@@ -129,8 +139,10 @@ class ShardEvaluator:
                 nbytes += self._batch_bytes(batches[w1])
                 w1 += 1
             window = batches[w0:w1]
+            t_load = time.perf_counter()
             loaded = [self._load_batch(k[0], k[1], part) for k, part, _t in window]
             torch.cuda.synchronize()
+            self.load_seconds += time.perf_counter() - t_load
             greedy = self.algo.name == "mixed-tile-greedy"
             pipe = self._pipeline(1)
             # a generation-2 collection of the interpreter's heap (torch's module graph: tens of ms) would land inside the window's few
