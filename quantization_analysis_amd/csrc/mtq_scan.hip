@@ -286,6 +286,8 @@ struct ScanArgs {
     int n_formats;
     int fmt[MTQ_NUM_TILE_FORMATS];       // format codes in search order
     int oy[MTQ_NUM_TILE_FORMATS], oy2[MTQ_NUM_TILE_FORMATS], oxy[MTQ_NUM_TILE_FORMATS];   // record offsets of Σy, Σy², Σxy BY FORMAT CODE (identity bf16: 0, 1, 1)
+    int oab[MTQ_NUM_TILE_FORMATS];       // … of Σ|x−y| (mae metric); kNoOffset for the identity bf16, whose Σ|x−y| is 0
+    int metric;                          // MTQ_METRIC_PCC or MTQ_METRIC_MAE
     double thr, n;
     const uint64_t *seeds;    // [count]
     int8_t *maps;             // [count][tiles] out
@@ -295,6 +297,9 @@ struct ScanArgs {
     double *delta;            // [count][tiles][4] scratch: Δ(Σy, Σy², Σxy) of the visit and the tile's previous code
     const U128 *jump_a, *jump_g;   // [kJump]
 };
+
+constexpr int kNoOffset = 0xFF;
+__device__ inline double rec_at(const double *rt, uint32_t off) { return off == (uint32_t)kNoOffset ? 0.0 : rt[off]; }
 
 // pcc_hoisted of csrc/mtq_host.cpp (mixed_tile_greedy.py:176-190 with the x-only terms hoisted): the same operations in the
 // same order.  special: zero denominator.
@@ -309,7 +314,7 @@ __device__ inline bool pcc_good(double n, double mean_x, double am2, double thr,
     return val >= thr;
 }
 
-template <typename Order>
+template <bool kMae, typename Order>
 __device__ void scan_tensor(const ScanArgs &a, const Order &ord, int b, unsigned char *lds, int lane)
 {
     const int T = (int)a.tiles;
@@ -349,10 +354,12 @@ __device__ void scan_tensor(const ScanArgs &a, const Order &ord, int b, unsigned
     }
 
     // ---- initial sums in tile order (:147-174): chains Σx, Σx², Σy, Σy², Σxy on lanes 0..4
-    const int off5[5] = {0, 1, a.oy[base], a.oy2[base], a.oxy[base]};
+    constexpr bool mae = kMae;   // compiled per metric (a run-time flag cost the pcc scan 9 %): one running sum, Σ|x−y| (:280-301), carried where the pcc search carries Σy; Σy², Σxy idle
+    const int off5[5] = {0, 1, mae ? a.oab[base] : a.oy[base], a.oy2[base], a.oxy[base]};
     // record offsets by format code, one byte each (rec <= 22): a per-lane code picks its offset with a shift, where indexing the
     // argument arrays by a per-lane value makes every gather wait for a table load
-    const uint32_t poy = (uint32_t)a.oy[0] | ((uint32_t)a.oy[1] << 8) | ((uint32_t)a.oy[2] << 16) | ((uint32_t)a.oy[3] << 24);
+    const int *o1 = mae ? a.oab : a.oy;
+    const uint32_t poy = (uint32_t)o1[0] | ((uint32_t)o1[1] << 8) | ((uint32_t)o1[2] << 16) | ((uint32_t)o1[3] << 24);
     const uint32_t poy2 = (uint32_t)a.oy2[0] | ((uint32_t)a.oy2[1] << 8) | ((uint32_t)a.oy2[2] << 16) | ((uint32_t)a.oy2[3] << 24);
     const uint32_t poxy = (uint32_t)a.oxy[0] | ((uint32_t)a.oxy[1] << 8) | ((uint32_t)a.oxy[2] << 16) | ((uint32_t)a.oxy[3] << 24);
     double acc = 0.0;
@@ -360,7 +367,7 @@ __device__ void scan_tensor(const ScanArgs &a, const Order &ord, int b, unsigned
     if (lane < T) {
         const double *rt = st + (int64_t)lane * rec;
 #pragma unroll
-        for (int c = 0; c < 5; ++c) nx[c] = rt[off5[c]];
+        for (int c = 0; c < 5; ++c) nx[c] = rec_at(rt, (uint32_t)off5[c]);
     }
     for (int t0 = 0; t0 < T; t0 += 64) {
         const int m = min(64, T - t0);
@@ -371,7 +378,7 @@ __device__ void scan_tensor(const ScanArgs &a, const Order &ord, int b, unsigned
         if (t0 + 64 + lane < T) {   // the next block's records are on their way while this block's chain runs
             const double *rt = st + (int64_t)(t0 + 64 + lane) * rec;
 #pragma unroll
-            for (int c = 0; c < 5; ++c) nx[c] = rt[off5[c]];
+            for (int c = 0; c < 5; ++c) nx[c] = rec_at(rt, (uint32_t)off5[c]);
         }
         __syncthreads();
         if (lane < 5) {
@@ -408,7 +415,7 @@ __device__ void scan_tensor(const ScanArgs &a, const Order &ord, int b, unsigned
     bool all_fixed = false;
     {
         bool special = false;
-        const bool good = pcc_good(n, mean_x, am2, thr, Sy, Sy2, Sxy, special);
+        const bool good = mae ? Sy / n <= thr : pcc_good(n, mean_x, am2, thr, Sy, Sy2, Sxy, special);   // mae: is_good(sum_abs / N) (:280-284)
         if (special) status = 1;
         all_fixed = !good;
         if (!wave_shuffle<false>(r, ord, T, cnt, lane)) status = 2;   // the generator advances as the permutation would have
@@ -447,9 +454,14 @@ __device__ void scan_tensor(const ScanArgs &a, const Order &ord, int b, unsigned
             for (int u = 0; u < 4; ++u) {
                 const double *rt = st + (int64_t)tt[u] * rec;
                 const int sh = 8 * pv[u];                     // the previous format's offsets out of the packed tables: no indexed load
-                dd[u][0] = rt[oy_f] - rt[(poy >> sh) & 0xFFu];   // :259-261
-                dd[u][1] = rt[oy2_f] - rt[(poy2 >> sh) & 0xFFu];
-                dd[u][2] = rt[oxy_f] - rt[(poxy >> sh) & 0xFFu];
+                if (mae) {                                       // :293 — the candidate's Σ|x−y| minus the tile's current one
+                    dd[u][0] = rec_at(rt, (uint32_t)oy_f) - rec_at(rt, (poy >> sh) & 0xFFu);
+                    dd[u][1] = dd[u][2] = 0.0;
+                } else {
+                    dd[u][0] = rt[oy_f] - rt[(poy >> sh) & 0xFFu];   // :259-261
+                    dd[u][1] = rt[oy2_f] - rt[(poy2 >> sh) & 0xFFu];
+                    dd[u][2] = rt[oxy_f] - rt[(poxy >> sh) & 0xFFu];
+                }
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -518,7 +530,7 @@ __device__ void scan_tensor(const ScanArgs &a, const Order &ord, int b, unsigned
                 cy = Sy + dy; cy2 = Sy2 + dy2; cxy = Sxy + dxy;
             }
             bool special = false;
-            const bool good = pcc_good(n, mean_x, am2, thr, cy, cy2, cxy, special);
+            const bool good = mae ? cy / n <= thr : pcc_good(n, mean_x, am2, thr, cy, cy2, cxy, special);   // mae: is_good(cab / N) (:293-294)
             const uint64_t act = below(m);
             const uint64_t okm = __ballot(good && active) & act, spm = __ballot(special && active) & act;
             int j, take = -1;
@@ -563,7 +575,8 @@ __global__ __launch_bounds__(64) void greedy_scan_pcc_lds(ScanArgs a)
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int lane = threadIdx.x;
     OrderLds ord{reinterpret_cast<uint16_t *>(lds)};
-    scan_tensor(a, ord, blockIdx.x, lds + 2 * ((a.tiles + 7) & ~(int64_t)7), lane);
+    if (a.metric == MTQ_METRIC_MAE) scan_tensor<true>(a, ord, blockIdx.x, lds + 2 * ((a.tiles + 7) & ~(int64_t)7), lane);
+    else scan_tensor<false>(a, ord, blockIdx.x, lds + 2 * ((a.tiles + 7) & ~(int64_t)7), lane);
 }
 
 __global__ __launch_bounds__(64) void greedy_scan_pcc_global(ScanArgs a)
@@ -571,7 +584,8 @@ __global__ __launch_bounds__(64) void greedy_scan_pcc_global(ScanArgs a)
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int lane = threadIdx.x;
     OrderGlobal ord{a.order_g + (int64_t)blockIdx.x * a.tiles};
-    scan_tensor(a, ord, blockIdx.x, lds, lane);
+    if (a.metric == MTQ_METRIC_MAE) scan_tensor<true>(a, ord, blockIdx.x, lds, lane);
+    else scan_tensor<false>(a, ord, blockIdx.x, lds, lane);
 }
 
 constexpr size_t kFixedLds = (64 * 4 + 64 * 4 + 64 * 5) * sizeof(double) + kTagSlots;
@@ -629,7 +643,7 @@ extern "C" int mtq_greedy_scan_device(const double *stats, int64_t count, int64_
     if (!stats || !formats || !seeds || !maps || !status || !scratch) return fail(MTQ_ERR_INVALID, "null argument");
     if (count <= 0 || count > (1 << 20) || tiles <= 0) return fail(MTQ_ERR_INVALID, "count and tiles must be positive");
     if (tiles > MTQ_SCAN_DEVICE_MAX_TILES) return fail(MTQ_ERR_UNSUPPORTED, "more tiles than the device scan takes: use the host scan");
-    if (metric != MTQ_METRIC_PCC) return fail(MTQ_ERR_UNSUPPORTED, "the device scan serves the pcc metric: use the host scan");
+    if (metric != MTQ_METRIC_PCC && metric != MTQ_METRIC_MAE) return fail(MTQ_ERR_UNSUPPORTED, "the device scan serves the pcc and mae metrics: use the host scan");
     if (n_formats <= 0 || n_formats > MTQ_NUM_TILE_FORMATS) return fail(MTQ_ERR_INVALID, "n_formats must be 1..4");
     if (fmt_mask & MTQ_MASK_SLIM) return fail(MTQ_ERR_INVALID, "the device scan reads full records");
     if (!(elem_count > 0.0)) return fail(MTQ_ERR_INVALID, "elem_count must be positive");
@@ -644,7 +658,9 @@ extern "C" int mtq_greedy_scan_device(const double *stats, int64_t count, int64_
         a.oy[f] = s >= 0 ? 2 + 5 * s : 0;
         a.oy2[f] = s >= 0 ? 3 + 5 * s : 1;
         a.oxy[f] = s >= 0 ? 4 + 5 * s : 1;
+        a.oab[f] = s >= 0 ? 5 + 5 * s : kNoOffset;
     }
+    a.metric = metric;
     for (int i = 0; i < n_formats; ++i) {
         if (!slot_ok(slot_of(fmt_mask, formats[i]))) return fail(MTQ_ERR_INVALID, "a format is not available under fmt_mask");
         for (int j = 0; j < i; ++j) if (formats[j] == formats[i]) return fail(MTQ_ERR_UNSUPPORTED, "the device scan needs distinct formats: use the host scan");

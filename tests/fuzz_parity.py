@@ -90,6 +90,11 @@ def run(cases: int, seed: int) -> int:
                 if int(ds.cpu()[0]) == 0:   # status 1 (zero denominator met) hands the tensor to the host scan
                     ok_g &= np.array_equal(dm.cpu().numpy().reshape(a.shape), a)
                     ok_g &= cnt.cpu().numpy()[0].tolist() == [int(np.sum(a == k)) for k in range(4)]
+                # the mae search on the device against the host scan on the same records
+                thr_m = float(rng.choice([1e-5, 1e-4, 1e-3])) * max(float(np.abs(x).mean()) / 0.016, 1e-6)
+                gm, _cm, _om = hb.greedy_run(full, 0xF, ALL, "mae", thr_m, float(x.size), 7)
+                dm, ds = hb.greedy_scan_device(recs_d, 0xF, ALL, "mae", thr_m, float(x.size), sd)
+                ok_g &= int(ds.cpu()[0]) == 0 and np.array_equal(dm.cpu().numpy()[0], gm)
                 order = [ALL[k] for k in rng.permutation(4)[: int(rng.integers(1, 5))]]
                 s2 = int(rng.integers(1, 2**31))
                 gh, _ch, _oh = hb.greedy_run(full, 0xF, order, "pcc", thr, float(x.size), s2)

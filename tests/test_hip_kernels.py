@@ -492,8 +492,9 @@ def test_streamed_pipeline_matches_oracle(scan):
     for i, r in enumerate(res):
         a, counts, _st = orc.greedy(xs[i], ALL, "pcc", 0.998, 123)
         assert np.array_equal(r.assignment, a) and r.counts == counts, i
-    # the mae metric keeps the full records (Σ|d| decides)
-    pipe = GreedyPipeline(ALL, "mae", 3e-4, 123, chunk=2, workers=2)
+    # the mae metric (Σ|d| decides): on the device too, or over PCIe with the full records
+    pipe = GreedyPipeline(ALL, "mae", 3e-4, 123, chunk=2, workers=2, scan=scan)
+    assert pipe.device_scan == (scan == "device")
     try:
         res = pipe.run(dev(xs[[0, 2]], bf16=True))
     finally:
@@ -646,7 +647,7 @@ def test_fast_kernel_strided_view_and_batch_stride():
 # ------------------------------------------------------------------------------------------------------------------
 # H1 on the device (csrc/mtq_scan.hip): the whole greedy search where K1 wrote the records
 # ------------------------------------------------------------------------------------------------------------------
-def _device_scan_vs_host(xs, formats, thr, seeds, mask=None):
+def _device_scan_vs_host(xs, formats, thr, seeds, mask=None, metric="pcc"):
     """xs: (count, rows, cols) device tensor.  Device scan maps == host scan maps (same records), status 0."""
     import torch
 
@@ -657,9 +658,9 @@ def _device_scan_vs_host(xs, formats, thr, seeds, mask=None):
     numel = xs.shape[1] * xs.shape[2]
     sd = torch.tensor(seeds, dtype=torch.int64, device=xs.device)
     cnt = torch.zeros((xs.shape[0], 4), dtype=torch.int32, device=xs.device)
-    maps, status = hb.greedy_scan_device(recs, dec, formats, "pcc", thr, float(numel), sd, counts_out=cnt)
+    maps, status = hb.greedy_scan_device(recs, dec, formats, metric, thr, float(numel), sd, counts_out=cnt)
     torch.cuda.synchronize()
-    want, counts, _outs = hb.greedy_run_batch(recs.cpu().numpy(), dec, formats, "pcc", thr, float(numel), seeds, 4)
+    want, counts, _outs = hb.greedy_run_batch(recs.cpu().numpy(), dec, formats, metric, thr, float(numel), seeds, 4)
     assert status.cpu().tolist() == [0] * xs.shape[0]
     assert np.array_equal(cnt.cpu().numpy(), counts)
     got = maps.cpu().numpy()
@@ -670,7 +671,7 @@ def _device_scan_vs_host(xs, formats, thr, seeds, mask=None):
 
 @pytest.mark.gpu
 def test_device_scan_golden_greedy_cases(golden_dir):
-    """Every pcc case of golden F4 (the reference's maps) through K1 + the device scan."""
+    """Every pcc and mae case of golden F4 (the reference's maps) through K1 + the device scan."""
     import json
 
     import torch
@@ -679,17 +680,25 @@ def test_device_scan_golden_greedy_cases(golden_dir):
     d = np.load(golden_dir / "f4_greedy.npz")
     n = 0
     for name, m in meta.items():
-        if m["metric"] != "pcc":
+        if m["metric"] not in ("pcc", "mae"):
             continue
         x = gen(m["kind"], m["seed"], tuple(m["shape"]))
         x2d, info = hb.to_device_2d(torch.from_numpy(x).to(torch.bfloat16) if m["kind"].endswith("bf16") else x)
         if x2d.shape[0] * x2d.shape[1] != x.size:
             continue   # vectors with a ragged last row: their element count is not rows*cols (covered by the host scan)
-        got = _device_scan_vs_host(x2d[None].contiguous(), m["formats"], m["threshold"], [m["algo_seed"]])
+        got = _device_scan_vs_host(x2d[None].contiguous(), m["formats"], m["threshold"], [m["algo_seed"]], metric=m["metric"])
         th, tw = hb.tiles_hw(*x2d.shape)
         assert np.array_equal(got[0].reshape(th, tw), d[f"{name}_assign"]), name
         n += 1
-    assert n >= 7
+    assert n >= 8
+    # mae on batches: thresholds around the formats' typical per-tile errors, bf16 storage (identity records) and float32, other orders
+    for kind, bf16 in (("normal_bf16", True), ("heavy_f32", False)):
+        xs = np.stack([gen(kind, 500 + i, (192, 256)) for i in range(6)])
+        xd = dev(xs, bf16=bf16)
+        for thr in (5e-5, 2e-4, 1e-3, 1e-2):
+            _device_scan_vs_host(xd, ALL, thr, [31 + i for i in range(6)], metric="mae")
+        _device_scan_vs_host(xd, ["bfp8", "bfp2"], 3e-4, [5] * 6, metric="mae")
+        _device_scan_vs_host(xd, ["bfp4", "bfp8", "bf16"], 3e-4, [9] * 6, metric="mae")
 
 
 @pytest.mark.gpu
@@ -743,7 +752,9 @@ def test_device_scan_refusals_and_zero_variance():
     sd = torch.tensor([5, 6], dtype=torch.int64, device="cuda")
     _maps, status = hb.greedy_scan_device(recs, 0xE | hb.MASK_BF16_IDENTITY, ALL, "pcc", 0.999, 64.0 * 128, sd)
     assert status.cpu().tolist() == [1, 1]
+    maps_m, status_m = hb.greedy_scan_device(recs, 0xE | hb.MASK_BF16_IDENTITY, ALL, "mae", 1e-3, 64.0 * 128, sd)   # mae has no denominator: all zeros → every format exact
+    assert status_m.cpu().tolist() == [0, 0] and np.array_equal(maps_m.cpu().numpy(), hb.greedy_run_batch(recs.cpu().numpy(), 0xE | hb.MASK_BF16_IDENTITY, ALL, "mae", 1e-3, 64.0 * 128, [5, 6], 1)[0])
     with pytest.raises(hb.MtqError):
-        hb.greedy_scan_device(recs, 0xE | hb.MASK_BF16_IDENTITY, ALL, "mae", 1e-3, 64.0 * 128, sd)
+        hb.greedy_scan_device(recs, 0xE | hb.MASK_BF16_IDENTITY, ALL, "atol", 1e-3, 64.0 * 128, sd)
     with pytest.raises(hb.MtqError):
         hb.greedy_scan_device(recs, 0xE | hb.MASK_BF16_IDENTITY, ["bfp8", "bfp8"], "pcc", 0.9, 64.0 * 128, sd)
