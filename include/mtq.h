@@ -273,9 +273,10 @@ int mtq_column_sums_device_batched(const double *stats, int64_t count, int64_t t
  * and the sequential accept / reject scan with the host scan's IEEE operations in the host scan's order, so maps[count][tiles]
  * (device, int8 codes) are the host's maps.  status[count] (device): 0 = done; 1 = a zero denominator turned up (the decision
  * needs Σ|x−y|: run mtq_greedy_run on that tensor's records); 2 = internal budget exhausted (same remedy).  Serves the pcc
- * metric and the mae metric (one running sum, Σ|x−y|: mixed_tile_greedy.py:280-301), distinct formats (fmt_mask may carry
- * MTQ_MASK_BF16_IDENTITY), tiles <= MTQ_SCAN_DEVICE_MAX_TILES; anything else (the atol metric, repeated formats)
- * returns MTQ_ERR_UNSUPPORTED and the caller uses the host scan.  seeds[count]: device array of non-zero seeds.  counts
+ * metric, the mae metric (one running sum, Σ|x−y|: mixed_tile_greedy.py:280-301) and the atol metric (:305-344 — order-independent for
+ * finite maxima, a per-tile walk down the format list: csrc/mtq_scan.hip greedy_atol; status 1 when a maximum is NaN), distinct
+ * formats (fmt_mask may carry MTQ_MASK_BF16_IDENTITY), tiles <= MTQ_SCAN_DEVICE_MAX_TILES; anything else (repeated formats, more
+ * tiles) returns MTQ_ERR_UNSUPPORTED and the caller uses the host scan.  seeds[count]: device array of non-zero seeds.  counts
  * [count][4] (device, may be NULL): tiles per format code of every finished map (np.bincount of the map).  scratch:
  * device memory of mtq_greedy_scan_scratch_bytes(count, tiles) bytes.  Asynchronous on `stream`. */
 #define MTQ_SCAN_DEVICE_MAX_TILES (1 << 22)

@@ -287,7 +287,8 @@ struct ScanArgs {
     int fmt[MTQ_NUM_TILE_FORMATS];       // format codes in search order
     int oy[MTQ_NUM_TILE_FORMATS], oy2[MTQ_NUM_TILE_FORMATS], oxy[MTQ_NUM_TILE_FORMATS];   // record offsets of Σy, Σy², Σxy BY FORMAT CODE (identity bf16: 0, 1, 1)
     int oab[MTQ_NUM_TILE_FORMATS];       // … of Σ|x−y| (mae metric); kNoOffset for the identity bf16, whose Σ|x−y| is 0
-    int metric;                          // MTQ_METRIC_PCC or MTQ_METRIC_MAE
+    int omx[MTQ_NUM_TILE_FORMATS];       // … of max|x−y| (atol metric); kNoOffset for the identity bf16
+    int metric;                          // MTQ_METRIC_PCC, MTQ_METRIC_MAE (scan kernels) or MTQ_METRIC_ATOL (greedy_atol)
     double thr, n;
     const uint64_t *seeds;    // [count]
     int8_t *maps;             // [count][tiles] out
@@ -570,6 +571,57 @@ __device__ void scan_tensor(const ScanArgs &a, const Order &ord, int b, unsigned
     }
 }
 
+// The atol search needs no scan.  Its global metric is max over tiles of max|x−y|, so a replacement is accepted iff the new tile maximum
+// and every OTHER tile's current maximum are within the threshold (mixed_tile_greedy.py:305-344 keeps that maximum with a multiplicity and
+// an occasional recount; for finite values the candidate it forms IS max(new, others)).  If any tile's maximum under the first format
+// exceeds the threshold, the first format's own pass fixes every tile (:305-309) and the map stays at the first format; otherwise every
+// other tile is always within the threshold and tile t walks down the format list while its own maximum stays within it — whatever the
+// visiting order, so no generator either (checked against the reference's three atol maps of F4 and, seed after seed, against the
+// host scan).  A NaN among the maxima leaves that equivalence: status 1, the host scan takes the tensor.
+__global__ __launch_bounds__(256) void greedy_atol(ScanArgs a)
+{
+    __shared__ int s_bad, s_nan, s_cnt[MTQ_NUM_TILE_FORMATS];
+    const int b = blockIdx.x;
+    const int64_t T = a.tiles;
+    const double *st = a.stats + (int64_t)b * T * a.rec;
+    int8_t *map = a.maps + (int64_t)b * T;
+    if (threadIdx.x == 0) { s_bad = 0; s_nan = 0; }
+    if (threadIdx.x < MTQ_NUM_TILE_FORMATS) s_cnt[threadIdx.x] = 0;
+    __syncthreads();
+    const int base = a.fmt[0];
+    bool bad = false, nan = false;
+    for (int64_t t = threadIdx.x; t < T; t += 256) {
+        const double *rt = st + t * a.rec;
+        bad |= !(rec_at(rt, (uint32_t)a.omx[base]) <= a.thr);
+        for (int p = 0; p < a.n_formats; ++p) { const double v = rec_at(rt, (uint32_t)a.omx[a.fmt[p]]); nan |= v != v; }
+    }
+    if (bad) s_bad = 1;
+    if (nan) s_nan = 1;
+    __syncthreads();
+    const bool all_base = s_bad != 0;
+    int mine[MTQ_NUM_TILE_FORMATS] = {0, 0, 0, 0};
+    for (int64_t t = threadIdx.x; t < T; t += 256) {
+        const double *rt = st + t * a.rec;
+        int code = base;
+        if (!all_base)
+            for (int p = 1; p < a.n_formats; ++p) {
+                if (!(rec_at(rt, (uint32_t)a.omx[a.fmt[p]]) <= a.thr)) break;   // rejected: fixed at the format it has (:277-278)
+                code = a.fmt[p];
+            }
+        map[t] = (int8_t)code;
+#pragma unroll
+        for (int c = 0; c < MTQ_NUM_TILE_FORMATS; ++c) mine[c] += code == c;
+    }
+#pragma unroll
+    for (int c = 0; c < MTQ_NUM_TILE_FORMATS; ++c) if (mine[c]) atomicAdd(&s_cnt[c], mine[c]);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        a.status[b] = s_nan ? 1 : 0;
+        if (a.counts)
+            for (int c = 0; c < MTQ_NUM_TILE_FORMATS; ++c) a.counts[b * MTQ_NUM_TILE_FORMATS + c] = s_cnt[c];
+    }
+}
+
 __global__ __launch_bounds__(64) void greedy_scan_pcc_lds(ScanArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -643,7 +695,7 @@ extern "C" int mtq_greedy_scan_device(const double *stats, int64_t count, int64_
     if (!stats || !formats || !seeds || !maps || !status || !scratch) return fail(MTQ_ERR_INVALID, "null argument");
     if (count <= 0 || count > (1 << 20) || tiles <= 0) return fail(MTQ_ERR_INVALID, "count and tiles must be positive");
     if (tiles > MTQ_SCAN_DEVICE_MAX_TILES) return fail(MTQ_ERR_UNSUPPORTED, "more tiles than the device scan takes: use the host scan");
-    if (metric != MTQ_METRIC_PCC && metric != MTQ_METRIC_MAE) return fail(MTQ_ERR_UNSUPPORTED, "the device scan serves the pcc and mae metrics: use the host scan");
+    if (metric != MTQ_METRIC_PCC && metric != MTQ_METRIC_MAE && metric != MTQ_METRIC_ATOL) return fail(MTQ_ERR_INVALID, "unknown metric");
     if (n_formats <= 0 || n_formats > MTQ_NUM_TILE_FORMATS) return fail(MTQ_ERR_INVALID, "n_formats must be 1..4");
     if (fmt_mask & MTQ_MASK_SLIM) return fail(MTQ_ERR_INVALID, "the device scan reads full records");
     if (!(elem_count > 0.0)) return fail(MTQ_ERR_INVALID, "elem_count must be positive");
@@ -659,6 +711,7 @@ extern "C" int mtq_greedy_scan_device(const double *stats, int64_t count, int64_
         a.oy2[f] = s >= 0 ? 3 + 5 * s : 1;
         a.oxy[f] = s >= 0 ? 4 + 5 * s : 1;
         a.oab[f] = s >= 0 ? 5 + 5 * s : kNoOffset;
+        a.omx[f] = s >= 0 ? 6 + 5 * s : kNoOffset;
     }
     a.metric = metric;
     for (int i = 0; i < n_formats; ++i) {
@@ -683,6 +736,10 @@ extern "C" int mtq_greedy_scan_device(const double *stats, int64_t count, int64_
     a.delta = static_cast<double *>(scratch);
     a.order_g = reinterpret_cast<uint32_t *>(static_cast<unsigned char *>(scratch) + (size_t)count * (size_t)tiles * 4 * sizeof(double));
     hipStream_t st = static_cast<hipStream_t>(stream);
+    if (metric == MTQ_METRIC_ATOL) {
+        hipLaunchKernelGGL(greedy_atol, dim3((unsigned)count), dim3(256), 0, st, a);
+        return check_launch("mtq_greedy_scan_device");
+    }
     if (tiles <= kScanMaxTilesLds) {
         const size_t lds = 2 * (size_t)((tiles + 7) & ~(int64_t)7) + kFixedLds;
         static std::atomic<bool> raised[64];   // per device: the attribute belongs to the function's code object on the current device

@@ -432,8 +432,8 @@ SCAN_LDS_MAX_TILES = 32768      # csrc/mtq_scan.hip kScanMaxTilesLds: visiting o
 
 
 def device_scan_supported(formats, metric: str, tiles: int) -> bool:
-    """What mtq_greedy_scan_device serves (include/mtq.h): the pcc and mae metrics, distinct formats, tiles up to SCAN_DEVICE_MAX_TILES."""
-    return metric in ("pcc", "mae") and len(set(formats)) == len(formats) and 0 < tiles <= SCAN_DEVICE_MAX_TILES
+    """What mtq_greedy_scan_device serves (include/mtq.h): the three metrics, distinct formats, tiles up to SCAN_DEVICE_MAX_TILES."""
+    return metric in ("pcc", "mae", "atol") and len(set(formats)) == len(formats) and 0 < tiles <= SCAN_DEVICE_MAX_TILES
 
 
 def device_copy(dst, src) -> None:

@@ -133,7 +133,7 @@ class GreedyPipeline:
                  chunk: int = 8, workers: int = 8, pure_formats=(), scan: str = "auto", scan_streams: int | None = None):
         """scan: "device" — the sequential scan runs on the GPU where K1 wrote the records (csrc/mtq_scan.hip: only maps, counts and
         seven sums per tensor cross PCIe, the host does not scan); "host" — records over PCIe, scans on host threads; "auto" —
-        "device" where mtq_greedy_scan_device serves the search (pcc or mae metric, distinct formats), else "host".  MTQ_DEVICE_SCAN=0
+        "device" where mtq_greedy_scan_device serves the search (distinct formats), else "host".  MTQ_DEVICE_SCAN=0
         forces "host"."""
         import torch
 
@@ -158,7 +158,7 @@ class GreedyPipeline:
             raise ValueError("scan must be 'auto', 'host' or 'device'")
         can = hb.device_scan_supported(self.tile_formats, self.metric, 1)
         if scan == "device" and not can:
-            raise ValueError("the device scan serves the pcc and mae metrics with distinct formats")
+            raise ValueError("the device scan needs distinct formats")
         self.device_scan = can and scan != "host" and os.environ.get("MTQ_DEVICE_SCAN", "1") != "0"
         # A device scan is ONE wave per tensor (≈ 0.14–0.19 µs per tile, three passes): right when a batch holds many tensors, a long
         # pole when a batch is a few very large ones — a host core scans a tile in ≈ 0.025 µs.  Callers whose batches are latency-bound

@@ -95,6 +95,10 @@ def run(cases: int, seed: int) -> int:
                 gm, _cm, _om = hb.greedy_run(full, 0xF, ALL, "mae", thr_m, float(x.size), 7)
                 dm, ds = hb.greedy_scan_device(recs_d, 0xF, ALL, "mae", thr_m, float(x.size), sd)
                 ok_g &= int(ds.cpu()[0]) == 0 and np.array_equal(dm.cpu().numpy()[0], gm)
+                thr_a = float(rng.choice([1e-3, 1e-2, 0.1])) * max(float(np.abs(x).max()), 1e-30)
+                ga, _ca, _oa = hb.greedy_run(full, 0xF, ALL, "atol", thr_a, float(x.size), 7)
+                dm, ds = hb.greedy_scan_device(recs_d, 0xF, ALL, "atol", thr_a, float(x.size), sd)
+                ok_g &= int(ds.cpu()[0]) == 0 and np.array_equal(dm.cpu().numpy()[0], ga)
                 order = [ALL[k] for k in rng.permutation(4)[: int(rng.integers(1, 5))]]
                 s2 = int(rng.integers(1, 2**31))
                 gh, _ch, _oh = hb.greedy_run(full, 0xF, order, "pcc", thr, float(x.size), s2)
@@ -127,6 +131,11 @@ def run(cases: int, seed: int) -> int:
                 dm, ds = hb.greedy_scan_device(torch.from_numpy(full).cuda()[None], 0xF, ALL, "pcc", thr, float(x.size), sd)
                 if int(ds.cpu()[0]) == 0:
                     ok_g = np.array_equal(dm.cpu().numpy()[0], gh)
+                for met, th2 in (("mae", 1e-4), ("atol", 1e-2)):   # status 0 must mean the host scan's map, whatever the input holds
+                    gh2, _c2h, _o2h = hb.greedy_run(full, 0xF, ALL, met, th2, float(x.size), 7)
+                    dm2, ds2 = hb.greedy_scan_device(torch.from_numpy(full).cuda()[None], 0xF, ALL, met, th2, float(x.size), sd)
+                    if int(ds2.cpu()[0]) == 0:
+                        ok_g &= np.array_equal(dm2.cpu().numpy()[0], gh2)
         if not (ok and ok_q and ok_a and ok_g and ok_t):
             bad += 1
             print(f"MISMATCH case {c}: shape {(rows, cols)} bf16 {bf16} mask {mask:#x} fmt {fmt}: stats {ok} quantize {ok_q} apply {ok_a} greedy {ok_g}", flush=True)

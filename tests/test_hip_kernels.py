@@ -502,6 +502,15 @@ def test_streamed_pipeline_matches_oracle(scan):
     for i, r in zip((0, 2), res):
         a, counts, _st = orc.greedy(xs[i], ALL, "mae", 3e-4, 123)
         assert np.array_equal(r.assignment, a) and r.counts == counts, i
+    # the atol metric through the pipeline (device: the closed-form walk; host: the sequential scan with its multiplicity bookkeeping)
+    pipe = GreedyPipeline(ALL, "atol", 4e-3, 123, chunk=2, workers=2, scan=scan)
+    try:
+        res = pipe.run(dev(xs[[0, 2]], bf16=True))
+    finally:
+        pipe.close()
+    for i, r in zip((0, 2), res):
+        a, counts, _st = orc.greedy(xs[i], ALL, "atol", 4e-3, 123)
+        assert np.array_equal(r.assignment, a) and r.counts == counts, i
     # overlapped batches (three record slots): the last batch's results, each batch its own tensors
     b1 = dev(np.stack([gen("normal_bf16", 70 + i, (128, 256)) for i in range(4)]), bf16=True)
     b2x = np.stack([gen("heavy_bf16", 80 + i, (128, 256)) for i in range(4)])
@@ -671,7 +680,7 @@ def _device_scan_vs_host(xs, formats, thr, seeds, mask=None, metric="pcc"):
 
 @pytest.mark.gpu
 def test_device_scan_golden_greedy_cases(golden_dir):
-    """Every pcc and mae case of golden F4 (the reference's maps) through K1 + the device scan."""
+    """Every case of golden F4 (the reference's maps: pcc, mae, atol) through K1 + the device scan."""
     import json
 
     import torch
@@ -680,8 +689,6 @@ def test_device_scan_golden_greedy_cases(golden_dir):
     d = np.load(golden_dir / "f4_greedy.npz")
     n = 0
     for name, m in meta.items():
-        if m["metric"] not in ("pcc", "mae"):
-            continue
         x = gen(m["kind"], m["seed"], tuple(m["shape"]))
         x2d, info = hb.to_device_2d(torch.from_numpy(x).to(torch.bfloat16) if m["kind"].endswith("bf16") else x)
         if x2d.shape[0] * x2d.shape[1] != x.size:
@@ -690,7 +697,7 @@ def test_device_scan_golden_greedy_cases(golden_dir):
         th, tw = hb.tiles_hw(*x2d.shape)
         assert np.array_equal(got[0].reshape(th, tw), d[f"{name}_assign"]), name
         n += 1
-    assert n >= 8
+    assert n >= 10
     # mae on batches: thresholds around the formats' typical per-tile errors, bf16 storage (identity records) and float32, other orders
     for kind, bf16 in (("normal_bf16", True), ("heavy_f32", False)):
         xs = np.stack([gen(kind, 500 + i, (192, 256)) for i in range(6)])
@@ -699,6 +706,11 @@ def test_device_scan_golden_greedy_cases(golden_dir):
             _device_scan_vs_host(xd, ALL, thr, [31 + i for i in range(6)], metric="mae")
         _device_scan_vs_host(xd, ["bfp8", "bfp2"], 3e-4, [5] * 6, metric="mae")
         _device_scan_vs_host(xd, ["bfp4", "bfp8", "bf16"], 3e-4, [9] * 6, metric="mae")
+        # atol: order-independent on the device (greedy_atol), sequential with a generator on the host — the same maps, seed after seed
+        for thr in (1e-4, 1e-3, 4e-3, 2e-2, 0.2, 10.0):
+            _device_scan_vs_host(xd, ALL, thr, [71 + 13 * i for i in range(6)], metric="atol")
+        _device_scan_vs_host(xd, ["bfp8", "bfp2"], 2e-2, [5] * 6, metric="atol")
+        _device_scan_vs_host(xd, ["bfp4", "bfp8", "bf16"], 2e-2, [9] * 6, metric="atol")
 
 
 @pytest.mark.gpu
@@ -754,7 +766,11 @@ def test_device_scan_refusals_and_zero_variance():
     assert status.cpu().tolist() == [1, 1]
     maps_m, status_m = hb.greedy_scan_device(recs, 0xE | hb.MASK_BF16_IDENTITY, ALL, "mae", 1e-3, 64.0 * 128, sd)   # mae has no denominator: all zeros → every format exact
     assert status_m.cpu().tolist() == [0, 0] and np.array_equal(maps_m.cpu().numpy(), hb.greedy_run_batch(recs.cpu().numpy(), 0xE | hb.MASK_BF16_IDENTITY, ALL, "mae", 1e-3, 64.0 * 128, [5, 6], 1)[0])
+    xn = torch.full((1, 64, 128), 0.01, dtype=torch.float32, device="cuda")
+    xn[0, 3, 5] = float("nan")                                                    # a NaN maximum: the atol walk hands the tensor to the host scan
+    _m, status_n = hb.greedy_scan_device(hb.tile_stats_batched(xn, 0xF), 0xF, ALL, "atol", 1e-3, 64.0 * 128, sd[:1])
+    assert status_n.cpu().tolist() == [1]
     with pytest.raises(hb.MtqError):
-        hb.greedy_scan_device(recs, 0xE | hb.MASK_BF16_IDENTITY, ALL, "atol", 1e-3, 64.0 * 128, sd)
+        hb.greedy_scan_device(recs, 0xE | hb.MASK_BF16_IDENTITY | hb.MASK_SLIM, ALL, "pcc", 0.9, 64.0 * 128, sd)   # full records only
     with pytest.raises(hb.MtqError):
         hb.greedy_scan_device(recs, 0xE | hb.MASK_BF16_IDENTITY, ["bfp8", "bfp8"], "pcc", 0.9, 64.0 * 128, sd)
