@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define MTQ_VERSION 123 /* 0.1.2.3: + mtq_rng_integers, identity-bf16 / slim masks, device-side decisions, knife-edge format masks, chain records */
+#define MTQ_VERSION 130 /* 0.1.3.0: + the greedy search on the device (mtq_greedy_scan_device: pcc, mae, atol), mtq_device_copy_2d, the slot-ring self-test */
 
 typedef enum {
     MTQ_OK = 0,

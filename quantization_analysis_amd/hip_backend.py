@@ -112,7 +112,7 @@ def lib() -> ctypes.CDLL:
     L.mtq_greedy_scan_device.argtypes = [vp, i64, i64, u32, vp, ci, ci, dbl, dbl, vp, vp, vp, vp, vp, ctypes.c_size_t, vp]
     L.mtq_selftest_slot_ring.restype = ci
     L.mtq_device_copy_2d.argtypes = [vp, ctypes.c_size_t, vp, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_size_t, vp]
-    if L.mtq_version() < 123:
+    if L.mtq_version() < 130:
         raise MtqError("libmtq_hip.so is older than this package")
     _lib = L
     return L
