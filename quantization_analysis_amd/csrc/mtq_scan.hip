@@ -302,6 +302,27 @@ struct ScanArgs {
 constexpr int kNoOffset = 0xFF;
 __device__ inline double rec_at(const double *rt, uint32_t off) { return off == (uint32_t)kNoOffset ? 0.0 : rt[off]; }
 
+// Lanes 0..2: the running sum `s` plus the staged deltas of visits 0..kN−1, added one after the other as the sequential scan adds them;
+// prefix i → lds_p[i][lane].  Sixteen staged values are read ahead of the additions, which stay one dependent chain.
+template <int kN>
+__device__ inline void prefix_chain(const double *lds_d, double *lds_p, int lane, double s)
+{
+    double v[16], w[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) v[u] = lds_d[u * 4 + lane];
+#pragma unroll
+    for (int i0 = 0; i0 < kN; i0 += 16) {
+        if (i0 + 16 < kN) {
+#pragma unroll
+            for (int u = 0; u < 16; ++u) w[u] = lds_d[(i0 + 16 + u) * 4 + lane];
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) { s = s + v[u]; lds_p[(i0 + u) * 4 + lane] = s; }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) v[u] = w[u];
+    }
+}
+
 // pcc_hoisted of csrc/mtq_host.cpp (mixed_tile_greedy.py:176-190 with the x-only terms hoisted): the same operations in the
 // same order.  special: zero denominator.
 __device__ inline bool pcc_good(double n, double mean_x, double am2, double thr, double sy, double sy2, double sxy, bool &special)
@@ -481,8 +502,10 @@ __device__ void scan_tensor(const ScanArgs &a, const Order &ord, int b, unsigned
         int pprev = 0;
         uint32_t pt = 0;
         bool accept_mode = true;
+        int span = 16;   // visits an accept-mode round stages: its three serial chains cost per visit staged, and a run of acceptances is short
+                         // where rejections are frequent — 16 after a rejection, 64 after a round that accepted all of its visits
         while (k < nc) {
-            const int m = min(64, nc - k);
+            const int m = min(accept_mode ? span : 64, nc - k);
             const bool active = lane < m;
             double dy = 0.0, dy2 = 0.0, dxy = 0.0;
             int prev = 0;
@@ -508,21 +531,9 @@ __device__ void scan_tensor(const ScanArgs &a, const Order &ord, int b, unsigned
                 lds_d[lane * 4 + 0] = dy; lds_d[lane * 4 + 1] = dy2; lds_d[lane * 4 + 2] = dxy;
                 __syncthreads();
                 if (lane < 3) {   // inactive visits staged +0 deltas: their prefixes are never read
-                    double s = lane == 0 ? Sy : (lane == 1 ? Sy2 : Sxy);
-                    double v[16], w[16];
-#pragma unroll
-                    for (int u = 0; u < 16; ++u) v[u] = lds_d[u * 4 + lane];
-#pragma unroll
-                    for (int i0 = 0; i0 < 64; i0 += 16) {   // the next sixteen deltas are on their way while these sixteen are added, one after the other
-                        if (i0 + 16 < 64) {
-#pragma unroll
-                            for (int u = 0; u < 16; ++u) w[u] = lds_d[(i0 + 16 + u) * 4 + lane];
-                        }
-#pragma unroll
-                        for (int u = 0; u < 16; ++u) { s = s + v[u]; lds_p[(i0 + u) * 4 + lane] = s; }
-#pragma unroll
-                        for (int u = 0; u < 16; ++u) v[u] = w[u];
-                    }
+                    const double s0 = lane == 0 ? Sy : (lane == 1 ? Sy2 : Sxy);
+                    if (span == 16) prefix_chain<16>(lds_d, lds_p, lane, s0);   // both fully unrolled: a run-time bound cost more than the short chain saves
+                    else prefix_chain<64>(lds_d, lds_p, lane, s0);
                 }
                 __syncthreads();
                 cy = lds_p[lane * 4 + 0]; cy2 = lds_p[lane * 4 + 1]; cxy = lds_p[lane * 4 + 2];
@@ -541,13 +552,13 @@ __device__ void scan_tensor(const ScanArgs &a, const Order &ord, int b, unsigned
                 if (spm & below(min(j + 1, 64))) { status = 1; break; }   // a zero denominator among the visits this round settles
                 if (lane < j) map[t] = (int8_t)f;              // accepted (:264-276)
                 if (j > 0) take = j - 1;
-                if (j < m) { if (lane == j) map[t] = (int8_t)(prev | 0x80); k += j + 1; if (j == 0) accept_mode = false; }   // fixed (:277-278)
-                else k += m;
+                if (j < m) { if (lane == j) map[t] = (int8_t)(prev | 0x80); k += j + 1; span = 16; if (j == 0) accept_mode = false; }   // fixed (:277-278)
+                else { k += m; span = 64; }
             } else {
                 j = okm ? __builtin_ctzll(okm) : m;            // first accepted visit
                 if (spm & below(min(j + 1, 64))) { status = 1; break; }
                 if (lane < j) map[t] = (int8_t)(prev | 0x80);
-                if (j < m) { if (lane == j) map[t] = (int8_t)f; take = j; k += j + 1; if (j == 0) accept_mode = true; }
+                if (j < m) { if (lane == j) map[t] = (int8_t)f; take = j; k += j + 1; if (j == 0) { accept_mode = true; span = 16; } }
                 else k += m;
             }
             if (take >= 0) { Sy = readlane_f64(cy, take); Sy2 = readlane_f64(cy2, take); Sxy = readlane_f64(cxy, take); }   // take is wave-uniform
