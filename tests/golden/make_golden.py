@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Generate tests/golden/*.npz by IMPORTING the reference (johanna-rock/quantization_analysis).
 
-Run in the build container only:  python tests/golden/make_golden.py [r1|r2|all]   (r1 = the round-1 files, r2 = F3, F7, F11–F13)
+Run in the build container only:  python tests/golden/make_golden.py [r1|r2|r2b|all]   (r1 = the round-1 files, r2 = F3, F7, F11–F13, r2b = F14)
 The reference lives at /root/reference and never travels; only the arrays written here are
 committed.  Fixture list follows SURVEY.md §8(c) F1–F8.  Inputs ≤ 64 K elements are stored;
 larger inputs are stored as a (generator, seed, shape) recipe plus a SHA-256 of their bytes.
@@ -513,8 +513,31 @@ def main_r2() -> None:
     print("wrote f3_tile_sums.npz, f7_wq/, f13_large_magnitude.npz, golden_meta_r2.json (f11, f12, f13)")
 
 
+def main_r2b() -> None:
+    """F14 (end of round 2): the reference's mixed-tile-greedy under the mae and atol metrics at a mid size, two seeds each — the pin of
+    the device-side search for those metrics (csrc/mtq_scan.hip: the mae instantiation of the scan, the order-free atol walk).  Maps
+    and y by SHA-256, counts and columns as numbers."""
+    import tempfile
+
+    q = Quantizer("emulation")
+    f14 = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        for tag, kind, seed, shape in (("bf16_1024x768", "normal_bf16", 141, (1024, 768)), ("f32_512x640", "heavy_f32", 142, (512, 640))):
+            xi = gen(kind, seed, shape)
+            for metric, thrs in (("mae", (3e-4, 2e-3)), ("atol", (4e-3, 3e-2))):
+                for thr in thrs:
+                    for algo_seed in (123, 7):
+                        f14[f"{tag}|{metric}|{thr}|{algo_seed}"] = dict(
+                            run_algo("mixed-tile-greedy", {"metric": metric, "threshold": thr, "seed": algo_seed, "formats": ALL}, xi, ALL, q, tmp)["summary"],
+                            kind=kind, seed=seed, shape=list(shape), metric=metric, threshold=thr, algo_seed=algo_seed)
+    (OUT / "golden_meta_r2b.json").write_text(json.dumps({"numpy": np.__version__, "f14": f14}, indent=1, sort_keys=True))
+    print(f"wrote golden_meta_r2b.json (f14: {len(f14)} cases)")
+
+
 if __name__ == "__main__":
     which = sys.argv[1] if len(sys.argv) > 1 else "all"
+    if which in ("r2b", "all"):
+        main_r2b()
     if which in ("r1", "all"):
         main_r1()
     if which in ("r2", "all"):

@@ -3,7 +3,8 @@
   F7  the reference's `wq` run end to end on the synthetic:tiny tensors: table.txt, compression_config.used.json, maps,
   F11 the headline size (BASELINE configs[1]: 4096x4096 bf16, greedy pcc>=0.999 seed 123; threshold 0.94 / 0.999) by SHA-256,
   F12 BASELINE configs[2]/[3] tensor shapes (DeepSeek-R1 layer-0 vectors + kv_a_proj_with_mqa, Llama-3-8B k_proj) by SHA-256,
-  F13 large-magnitude mae thresholds (knife-edge band must scale with the score).
+  F13 large-magnitude mae thresholds (knife-edge band must scale with the score),
+  F14 (make_golden.py r2b) mixed-tile-greedy under the mae and atol metrics at 1024x768 bf16 / 512x640 float32, two seeds each.
 The GPU side of the same fixtures is tests/test_configs_gpu.py."""
 import json
 
@@ -145,3 +146,20 @@ def test_f13_large_magnitude_mae_host_backend(golden_dir, meta2):
     """The package's threshold rule (float64 moments + literal re-score inside a band that scales with the threshold) and
     greedy scan reproduce the reference's maps where mae scores are ~1e3 (an absolute 2e-6 band would miss the knife edge)."""
     check_f13_backend(golden_dir, meta2, "emulation")
+
+
+def test_f14_greedy_mae_atol_oracle(golden_dir):
+    """The reference's mae / atol greedy maps (by SHA-256), counts and columns from the oracle; and what the device-side atol walk
+    rests on: the reference's own atol map does not depend on the seed."""
+    from tests.inputs import gen
+
+    f14 = json.loads((golden_dir / "golden_meta_r2b.json").read_text())["f14"]
+    assert len(f14) == 16
+    for key, w in f14.items():
+        x = gen(w["kind"], w["seed"], tuple(w["shape"]))
+        assert sha(x) == w["x_sha256"], key
+        a, counts, st = orc.greedy(x, ALL, w["metric"], w["threshold"], w["algo_seed"])
+        check_summary(w, x, a, counts, st["stats"])
+    for key, w in f14.items():
+        if w["metric"] == "atol" and w["algo_seed"] == 123:
+            assert f14[key.rsplit("|", 1)[0] + "|7"]["assign_sha256"] == w["assign_sha256"], key

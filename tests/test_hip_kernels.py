@@ -714,6 +714,32 @@ def test_device_scan_golden_greedy_cases(golden_dir):
 
 
 @pytest.mark.gpu
+def test_device_search_mae_atol_against_reference_f14(golden_dir):
+    """F14: the reference's mixed-tile-greedy maps under mae and atol (1024x768 bf16, 512x640 float32; two seeds each) from K1 + the
+    device-side search — the mae instantiation of the scan and the order-free atol walk — by SHA-256, with the counts."""
+    import hashlib
+    import json
+
+    import torch
+
+    f14 = json.loads((golden_dir / "golden_meta_r2b.json").read_text())["f14"]
+    for key, w in f14.items():
+        x = gen(w["kind"], w["seed"], tuple(w["shape"]))
+        bf16 = w["kind"].endswith("bf16")
+        xd = dev(x, bf16=bf16)[None]
+        k1 = 0xE if bf16 else 0xF
+        dec = k1 | hb.MASK_BF16_IDENTITY if bf16 else k1
+        recs = hb.tile_stats_batched(xd, k1)
+        sd = torch.tensor([w["algo_seed"]], dtype=torch.int64, device="cuda")
+        cnt = torch.zeros((1, 4), dtype=torch.int32, device="cuda")
+        maps, status = hb.greedy_scan_device(recs, dec, ALL, w["metric"], w["threshold"], float(x.size), sd, counts_out=cnt)
+        assert int(status.cpu()[0]) == 0, key
+        a = maps.cpu().numpy()[0].reshape(w["assign_shape"])
+        assert hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest() == w["assign_sha256"], key
+        assert cnt.cpu().numpy()[0].tolist() == w["counts"], key
+
+
+@pytest.mark.gpu
 def test_device_scan_headline_tensor_and_batches(golden_dir):
     """The 4096x4096 headline tensor against the reference's map (golden F11) and a batch of tensors with different seeds."""
     import hashlib
