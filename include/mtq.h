@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define MTQ_VERSION 130 /* 0.1.3.0: + the greedy search on the device (mtq_greedy_scan_device: pcc, mae, atol), mtq_device_copy_2d, the slot-ring self-test */
+#define MTQ_VERSION 140 /* 0.1.4.0: + partial / listed K1 (mtq_tile_stats_partial, mtq_tile_stats_listed), the search in phases with shared visiting orders, mtq_shutdown */
 
 typedef enum {
     MTQ_OK = 0,
@@ -69,6 +69,10 @@ int mtq_version(void);
 const char *mtq_last_error(void);
 /* Number of visible HIP devices; MTQ_ERR_NO_DEVICE if the runtime reports none. */
 int mtq_device_count(int *count);
+/* Releases what the library keeps between calls: joins the scan threads, drains the devices it used and frees its device tables and
+ * events.  Idempotent; the library sets itself up again on the next call that needs any of it.  Nothing of this is ever done from a
+ * static destructor: call it before the process tears the HIP runtime down (the Python binding registers it with atexit). */
+int mtq_shutdown(void);
 
 /* ------------------------------------------------------------------ DEVICE: kernels */
 
@@ -99,6 +103,30 @@ int mtq_tile_stats(const void *x, int in_dtype, int64_t rows, int64_t cols, int6
 int mtq_tile_stats_batched(const void *x, int in_dtype, int64_t count, int64_t stride_elems,
                            int64_t rows, int64_t cols, int64_t ld,
                            uint32_t fmt_mask, double *stats, void *stream);
+
+/*
+ * K1 with part of the record left for later (round 3) — same records, same layout (`layout_mask` names the slots that exist), but only
+ * the five statistics of the formats in `full_mask` and Σy, Σy², Σxy of the formats in `sums_mask` are promised; every other statistic of
+ * the layout is UNSPECIFIED afterwards (the exact-integer bf16 kernel leaves NaN there, the other routes write the whole record).
+ * Σx, Σx² are always written.  What the greedy search needs of a format before any tile has ended up in it is Σy, Σy², Σxy
+ * (mixed_tile_greedy.py:245-261), and it only looks at format p for the tiles that accepted every earlier format (:227-231): the
+ * streamed driver evaluates the last format of the list — and Σ|x−y|, max|x−y| of the one before it — for those tiles alone
+ * (mtq_tile_stats_listed) between the search's last two passes.  full_mask and sums_mask are disjoint subsets of layout_mask.
+ */
+int mtq_tile_stats_partial(const void *x, int in_dtype, int64_t count, int64_t stride_elems,
+                           int64_t rows, int64_t cols, int64_t ld,
+                           uint32_t layout_mask, uint32_t full_mask, uint32_t sums_mask, double *stats, void *stream);
+
+/*
+ * K1 for a list of tiles: what mtq_tile_stats_partial left out, for the tiles that turn out to need it.  listed[0 .. *n_listed) (device;
+ * at most `capacity` entries are read) names tiles as tensor * tiles + tile; for each of them the five statistics of the formats in
+ * full_mask and Σ|x−y|, max|x−y| of those in err_mask are written into the tile's record (layout `layout_mask`), bit for bit what
+ * mtq_tile_stats writes there; nothing else of the record is touched.  BFP formats only.  The list comes from phase 1 of a split search
+ * (mtq_greedy_scan_device_ex), which is the only reader of these statistics before the map is final.
+ */
+int mtq_tile_stats_listed(const void *x, int in_dtype, int64_t count, int64_t stride_elems, int64_t rows, int64_t cols, int64_t ld,
+                          uint32_t layout_mask, uint32_t full_mask, uint32_t err_mask, const uint32_t *listed, const uint32_t *n_listed,
+                          int64_t capacity, double *stats, void *stream);
 
 /*
  * K2 quantize — materialise y = quantize→dequantize(x) for one format as float32.
@@ -284,6 +312,31 @@ size_t mtq_greedy_scan_scratch_bytes(int64_t count, int64_t tiles);
 int mtq_greedy_scan_device(const double *stats, int64_t count, int64_t tiles, uint32_t fmt_mask, const int *formats, int n_formats,
                            int metric, double threshold, double elem_count, const uint64_t *seeds, int8_t *maps, int32_t *status,
                            int32_t *counts, void *scratch, size_t scratch_bytes, void *stream);
+
+/* The same search with what round 3 added (mtq_greedy_scan_device is this with orders = NULL, phase = 0):
+ *   orders  — NULL, or the buffer mtq_scan_orders_device filled for the seed that ALL `count` tensors share (seeds[] must hold that
+ *             seed): every tensor of a model run is searched with one seed (mixed_tile_greedy.py:222-226), and a pass's permutation
+ *             depends only on the generator state and the number of candidates, so the base pass's draws and the permutations of
+ *             range(tiles) of passes 1 and 2 are computed once per launch; a tensor whose pass 1 rejects a tile shuffles its own
+ *             candidates from the shared state, as before.  With orders the kernel runs two waves per tensor: the second gathers the
+ *             passes' deltas ahead of the first.
+ *   phase   — 0: the whole search.  1: every pass but the last, then the last pass's candidates (np.where(~fixed), :228) of every
+ *             tensor are appended to listed[] as tensor * tiles + tile (n_listed: device counter, zeroed by the caller) and the
+ *             search's state goes to carry (mtq_scan_carry_bytes(count) bytes); maps hold work-in-progress codes.  2: the last pass
+ *             from carry, then the finished maps, status and counts.  Between 1 and 2 the caller fills in the statistics of the
+ *             last format for the listed tiles (mtq_tile_stats_listed) — the search never reads them for any other tile.  Phases need
+ *             n_formats >= 2 and the pcc or mae metric.
+ */
+size_t mtq_scan_carry_bytes(int64_t count);
+int mtq_greedy_scan_device_ex(const double *stats, int64_t count, int64_t tiles, uint32_t fmt_mask, const int *formats, int n_formats,
+                              int metric, double threshold, double elem_count, const uint64_t *seeds, int8_t *maps, int32_t *status,
+                              int32_t *counts, void *scratch, size_t scratch_bytes, const void *orders, int phase, uint32_t *listed,
+                              uint32_t *n_listed, void *carry, void *stream);
+/* The visiting orders a launch's tensors share: the generator (SeedSequence(seed) → PCG64) after the base pass's draws, then
+ * Generator.permutation(tiles) for pass 1 and — n_orders == 2 — once more for pass 2, with the generator states in between, into
+ * `orders` (mtq_scan_orders_bytes(tiles) bytes, device).  Depends on nothing but seed and tiles: it can run beside K1. */
+size_t mtq_scan_orders_bytes(int64_t tiles);
+int mtq_scan_orders_device(uint64_t seed, int64_t tiles, int n_orders, void *orders, size_t orders_bytes, void *stream);
 
 /* Results home without a copy engine (no reference counterpart: the reference's arrays are host arrays).  A kernel copies `rows` rows
  * of `width_bytes` bytes from src (pitch src_pitch) to dst (pitch dst_pitch) on `stream`; dst may be pinned host memory

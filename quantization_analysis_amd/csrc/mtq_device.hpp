@@ -179,4 +179,32 @@ __device__ __forceinline__ void group_terms_literal(const uint32_t u[kGroup], ui
     }
 }
 
+// One tile by the literal route, complete in every lane: lane ℓ holds the group (row ℓ>>1, half ℓ&1) in u; the 4 groups of a row
+// pair (lanes 4j..4j+3) are added sequentially, the 16 row pairs by a balanced tree (the order include/mtq.h documents).  acc is indexed by
+// FORMAT (static); formats outside fmt_mask are left as group_terms_literal left them.
+__device__ __forceinline__ void tile_terms_literal(const uint32_t u[kGroup], uint32_t fmt_mask, double acc[2 + 5 * kNumFmt])
+{
+    const int lane = threadIdx.x & 63;
+    group_terms_literal(u, fmt_mask, acc);
+#pragma unroll
+    for (int k = 0; k < 2 + 5 * kNumFmt; ++k) {
+        const bool live = k < 2 || (fmt_mask & (1u << ((k - 2) / 5))); // wave-uniform
+        if (live) {
+            const bool is_max = k >= 2 && ((k - 2) % 5) == 4;
+            double v = acc[k];
+            {   // the 4 groups of a row pair (lanes 4j..4j+3) sequentially, identically in every lane of the quad
+                const int q0 = lane & ~3;
+                const double a = __shfl(v, q0, 64), b = __shfl(v, q0 + 1, 64), c = __shfl(v, q0 + 2, 64), d = __shfl(v, q0 + 3, 64);
+                v = is_max ? nanmax(nanmax(nanmax(a, b), c), d) : ((a + b) + c) + d;
+            }
+#pragma unroll
+            for (int s = 4; s < 64; s <<= 1) { // 16 row pairs: balanced tree
+                const double o = __shfl_xor(v, s, 64);
+                v = is_max ? nanmax(v, o) : v + o;
+            }
+            acc[k] = v;
+        }
+    }
+}
+
 } // namespace mtq

@@ -273,6 +273,120 @@ __global__ __launch_bounds__(kDirectWaves * 64, MTQ_DIRECT_WAVES_PER_SIMD) void 
     }
 }
 
+// K1 for a LIST of tiles (mtq_tile_stats_listed): the same per-tile arithmetic and summation order, the tile taken from a device list
+// (tensor * tiles + tile) whose length is a device counter — the candidates the split greedy search hands over before its last pass
+// (csrc/mtq_scan.hip, phase 1).  Of every evaluated format j (ascending code) only the statistics named in its byte of `wmask` (bit k =
+// statistic k of Σy, Σy², Σxy, Σ|x−y|, max|x−y|) are written, at the format's slot offset in the record layout (its byte of `obase`);
+// Σx, Σx² and every other slot of the record are left as they are.  A tile the exact route cannot take (a group outside its exponent
+// range) is evaluated on the spot by the literal route: no follow-up kernel.
+template <typename T, uint32_t FM>
+__global__ __launch_bounds__(kDirectWaves * 64, MTQ_DIRECT_WAVES_PER_SIMD) void tile_stats_listed(
+    const T *__restrict__ x, int64_t stride, int64_t rows, int64_t cols, int64_t ld, uint32_t tiles_w, uint32_t tiles,
+    const uint32_t *__restrict__ list, const uint32_t *__restrict__ n_list, uint32_t cap, double *__restrict__ stats, int vec_ok, int rec,
+    uint32_t obase, uint32_t wmask)
+{
+    constexpr int nf = popc4(FM), nsum = 2 + 4 * nf, pad = direct_pad(FM);
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    double *part = reinterpret_cast<double *>(lds) + wave * (64 * pad);          // [64 groups][pad]
+    const uint32_t n = min(*n_list, cap);
+    const uint32_t step = gridDim.x * kDirectWaves;
+
+    auto fetch = [&](uint32_t gt, uint32_t (&u)[kGroup]) {
+        const uint32_t b = gt / tiles, t = gt - b * tiles;
+        const uint32_t tr = t / tiles_w, tc = t - tr * tiles_w;
+        Loader<T>::group(x + (int64_t)b * stride, (int64_t)tr * kTile + (lane >> 1), (int64_t)tc * kTile + (lane & 1) * kGroup, rows,
+                         cols, ld, vec_ok != 0, u);
+    };
+
+    uint32_t k = blockIdx.x * kDirectWaves + wave;
+    uint32_t gt = k < n ? list[k] : 0u;
+    uint32_t nxt[kGroup];
+    if (k < n) fetch(gt, nxt);
+    while (k < n) {
+        uint32_t u[kGroup];
+#pragma unroll
+        for (int i = 0; i < kGroup; ++i) u[i] = nxt[i];
+        const uint32_t k_next = k + step;
+        const uint32_t gt_next = k_next < n ? list[k_next] : 0u;
+        if (k_next < n) fetch(gt_next, nxt);                                     // in flight while this tile is processed
+
+        double s[kMaxSums];
+        float mx[kNumFmt];
+        bool bad;
+        direct_group<FM, sizeof(T) == 2>(u, s, mx, bad);
+        double *out = stats + (int64_t)gt * rec;
+        if (__ballot(bad) != 0ull) {                                             // wave-uniform, rare: the literal route, here and now
+            double acc[2 + 5 * kNumFmt];
+            tile_terms_literal(u, FM, acc);
+            if (lane == 0) {
+                int j = 0;
+#pragma unroll
+                for (int f = 0; f < kNumFmt; ++f) {
+                    if (!(FM & (1u << f))) continue;
+                    const uint32_t o = (obase >> (8 * j)) & 0xFFu, w = (wmask >> (8 * j)) & 0xFFu;
+#pragma unroll
+                    for (int q = 0; q < 5; ++q) if (w & (1u << q)) out[o + q] = acc[2 + 5 * f + q];
+                    ++j;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < nsum; ++q) part[lane * pad + q] = s[q];
+#pragma unroll
+            for (int j = 0; j < nf; ++j) {
+#pragma unroll
+                for (int sft = 1; sft < 64; sft <<= 1) mx[j] = fmaxf(mx[j], __shfl_xor(mx[j], sft, 64));
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                    // every lane's group sums are in the table
+            const int kk = lane & 31, h = lane >> 5;                              // statistic kk over row pairs 8h .. 8h+7
+            double r = 0.0;
+            if (kk < nsum) {
+                const double *col = part + (32 * h) * pad + kk;
+                double q[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j)                                       // the 4 groups of a row pair, sequentially
+                    q[j] = ((col[(4 * j) * pad] + col[(4 * j + 1) * pad]) + col[(4 * j + 2) * pad]) + col[(4 * j + 3) * pad];
+                r = ((q[0] + q[1]) + (q[2] + q[3])) + ((q[4] + q[5]) + (q[6] + q[7])); // balanced tree over the row pairs
+            }
+            r = r + __shfl_xor(r, 32, 64);                                        // the two halves of the tile (top tree level)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                    // table consumed: the next tile may overwrite it
+            if (lane >= 2 && lane < nsum) {
+                const int j = (lane - 2) >> 2, q = (lane - 2) & 3;
+                const uint32_t o = (obase >> (8 * j)) & 0xFFu, w = (wmask >> (8 * j)) & 0xFFu;
+                if (w & (1u << q)) out[o + q] = r;
+            } else if (lane >= 32 && lane < 32 + nf) {
+                const int j = lane - 32;
+                float v = mx[0];
+#pragma unroll
+                for (int jj = 1; jj < nf; ++jj) v = (j == jj) ? mx[jj] : v;
+                const uint32_t o = (obase >> (8 * j)) & 0xFFu, w = (wmask >> (8 * j)) & 0xFFu;
+                if (w & 16u) out[o + 4] = (double)v;
+            }
+        }
+        k = k_next;
+        gt = gt_next;
+    }
+}
+
+template <typename T>
+static void launch_listed(uint32_t fm, dim3 grid, hipStream_t st, const T *x, int64_t stride, int64_t rows, int64_t cols, int64_t ld,
+                          uint32_t tiles_w, uint32_t tiles, const uint32_t *list, const uint32_t *n_list, uint32_t cap, double *stats, int vec_ok,
+                          int rec, uint32_t obase, uint32_t wmask)
+{
+    const dim3 block(kDirectWaves * 64);
+#define MTQ_LAUNCH_LISTED(M) \
+    case M: hipLaunchKernelGGL((tile_stats_listed<T, M>), grid, block, (size_t)kDirectWaves * 64 * direct_pad(M) * sizeof(double), st, x, \
+                               stride, rows, cols, ld, tiles_w, tiles, list, n_list, cap, stats, vec_ok, rec, obase, wmask); break;
+    switch (fm) { // BFP subsets only: the bf16 slot has no use for a late evaluation
+        MTQ_LAUNCH_LISTED(2u) MTQ_LAUNCH_LISTED(4u) MTQ_LAUNCH_LISTED(6u) MTQ_LAUNCH_LISTED(8u) MTQ_LAUNCH_LISTED(10u)
+        MTQ_LAUNCH_LISTED(12u) MTQ_LAUNCH_LISTED(14u)
+    default: break;
+    }
+#undef MTQ_LAUNCH_LISTED
+}
+
 template <typename T>
 static void launch_direct(uint32_t fm, dim3 grid, hipStream_t st, const T *x, int64_t stride, int64_t rows, int64_t cols, int64_t ld,
                           uint32_t tiles_w, uint32_t tiles, uint32_t total, double *stats, int vec_ok, unsigned *work, unsigned launch_id, int tiles_per_wave)
@@ -333,4 +447,52 @@ extern "C" int mtq_launch_tile_stats_direct(const void *x, int in_dtype, int64_t
         launch_direct<float>(fmt_mask & MTQ_MASK_ALL, grid, st, static_cast<const float *>(x), stride_elems, rows, cols, ld, (uint32_t)tw,
                              (uint32_t)tiles, (uint32_t)total, stats, vec_ok, work, launch_id, quota);
     return check_launch("mtq_tile_stats (direct)");
+}
+
+// mtq_tile_stats_listed (include/mtq.h): argument checks here, the kernel above.
+extern "C" int mtq_tile_stats_listed(const void *x, int in_dtype, int64_t count, int64_t stride_elems, int64_t rows, int64_t cols, int64_t ld,
+                                     uint32_t layout_mask, uint32_t full_mask, uint32_t err_mask, const uint32_t *listed, const uint32_t *n_listed,
+                                     int64_t capacity, double *stats, void *stream)
+{
+    if (!x || !listed || !n_listed || !stats) return fail(MTQ_ERR_INVALID, "null argument");
+    if (in_dtype != MTQ_DTYPE_BF16 && in_dtype != MTQ_DTYPE_F32) return fail(MTQ_ERR_INVALID, "unknown input dtype");
+    if (count <= 0 || rows <= 0 || cols <= 0 || ld < cols || capacity <= 0) return fail(MTQ_ERR_INVALID, "shapes must be positive and ld >= cols");
+    if ((layout_mask & ~MTQ_MASK_ALL) != 0 || ((full_mask | err_mask) & ~layout_mask) != 0 || (full_mask & err_mask) != 0)
+        return fail(MTQ_ERR_INVALID, "full_mask and err_mask must be disjoint subsets of layout_mask");
+    const uint32_t fm = full_mask | err_mask;
+    if (fm == 0u || (fm & 1u)) return fail(MTQ_ERR_INVALID, "the listed evaluation takes BFP formats (and at least one)");
+    const int64_t th = (rows + kTile - 1) / kTile, tw = (cols + kTile - 1) / kTile, tiles = th * tw;
+    if (count * tiles >= ((int64_t)1 << 32) || tw > INT32_MAX) return fail(MTQ_ERR_INVALID, "too many tiles for a listed launch");
+    if (int rc = require_device()) return rc;
+    const int rec = 2 + 5 * popc4(layout_mask);
+    uint32_t obase = 0u, wmask = 0u;
+    int j = 0;
+    for (int f = 1; f < kNumFmt; ++f) {
+        if (!(fm & (1u << f))) continue;
+        obase |= (uint32_t)(2 + 5 * popc4(layout_mask & ((1u << f) - 1u))) << (8 * j);
+        wmask |= ((full_mask & (1u << f)) ? 0x1Fu : 0x18u) << (8 * j);   // all five, or Σ|x−y| and max|x−y|
+        ++j;
+    }
+    const int64_t esz = in_dtype == MTQ_DTYPE_BF16 ? 2 : 4;
+    const int vec_ok = (reinterpret_cast<uintptr_t>(x) & 15u) == 0 && (ld * esz) % 16 == 0 && (stride_elems * esz) % 16 == 0;
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0;
+        hipDeviceProp_t p;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess) return fail(MTQ_ERR_HIP, "hipGetDeviceProperties failed");
+        cus = p.multiProcessorCount;
+    }
+    // the list's length is only known on the device: a grid that fills the chip once, every wave striding through the list
+    const int64_t need = (capacity + kDirectWaves - 1) / kDirectWaves;
+    const int64_t max_blocks = (int64_t)cus * MTQ_DIRECT_WAVES_PER_SIMD * 4 / kDirectWaves;
+    const dim3 grid((unsigned)(need < max_blocks ? need : max_blocks));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const uint32_t cap = (uint32_t)(capacity < (int64_t)UINT32_MAX ? capacity : (int64_t)UINT32_MAX);
+    if (in_dtype == MTQ_DTYPE_BF16)
+        launch_listed<uint16_t>(fm, grid, st, static_cast<const uint16_t *>(x), stride_elems, rows, cols, ld, (uint32_t)tw, (uint32_t)tiles, listed,
+                                n_listed, cap, stats, vec_ok, rec, obase, wmask);
+    else
+        launch_listed<float>(fm, grid, st, static_cast<const float *>(x), stride_elems, rows, cols, ld, (uint32_t)tw, (uint32_t)tiles, listed, n_listed,
+                             cap, stats, vec_ok, rec, obase, wmask);
+    return check_launch("mtq_tile_stats_listed");
 }

@@ -23,6 +23,11 @@ struct WorkSlot { unsigned *counters = nullptr; int index = -1, device = -1; };
 int work_counter_acquire(void *stream, WorkSlot *out);
 // Records the slot's event on `stream` (behind the follow-up kernel) and gives the slot back.
 void work_counter_release(const WorkSlot &slot, void *stream);
+// The launch the slot was acquired for could not be enqueued: the slot goes back without a new event.
+void work_counter_abandon(const WorkSlot &slot);
 // hipGetLastError() → MTQ_OK / MTQ_ERR_HIP with the kernel name in the message.
 int check_launch(const char *what);
+// mtq_shutdown's parts (each translation unit releases what it owns; none of them runs from a static destructor)
+void scan_shutdown();       // mtq_scan.hip: the device jump-ahead tables
+void host_shutdown();       // mtq_host.cpp: the scan thread pool
 } // namespace mtq

@@ -32,9 +32,6 @@
 #include "mtq_device.hpp"
 #include "mtq_error.hpp"
 
-#ifndef MTQ_ROLLED_WAVES_PER_SIMD
-#define MTQ_ROLLED_WAVES_PER_SIMD 3
-#endif
 namespace mtq {
 
 typedef unsigned short us2 __attribute__((ext_vector_type(2)));
@@ -78,7 +75,7 @@ struct FmtAcc {           // integer group sums of one BFP format
     uint32_t dmax, dmin;  // packed running max / min of (a − y) + 0x8000 (unsigned halves)
 };
 
-template <typename F>
+template <typename F, bool kErr>
 __device__ __forceinline__ void fmt_step(uint32_t a, uint32_t abias, uint32_t sgn, FmtAcc &A)
 {
     // RNE of `a` to a multiple of G = 2^sh, saturating at (2^mb − 1)·G (quantization_formats.py:133-141)
@@ -90,15 +87,17 @@ __device__ __forceinline__ void fmt_step(uint32_t a, uint32_t abias, uint32_t sg
     if constexpr (F::onebit) A.sq2 += q;   // q ∈ {0,1}: Σq² = Σq, kept as two packed 16-bit counters (≤ 8 each), folded at the end
     else A.sq2 = __builtin_amdgcn_udot2(as_us2(q), as_us2(q), A.sq2, false);
     A.saq = __builtin_amdgcn_udot2(as_us2(a), as_us2(q), A.saq, false);
-    A.sad = __builtin_amdgcn_sad_u16(a, y, A.sad);
-    // a − y per half, biased by 0x8000 so that one 32-bit subtract serves both halves (no borrow: a|0x8000 ≥ y)
-    const uint32_t db = abias - y;
     if constexpr (F::d2) { // δ = a − y ∈ [−128, 128] as signed halves
         const s2 dl = as_s2(a) - as_s2(y);
         A.sd2 = __builtin_amdgcn_sdot2(dl, dl, A.sd2, false);
     }
-    A.dmax = as_u32(__builtin_elementwise_max(as_us2(A.dmax), as_us2(db)));
-    A.dmin = as_u32(__builtin_elementwise_min(as_us2(A.dmin), as_us2(db)));
+    if constexpr (kErr) {  // Σ|x−y| and max|x−y|: left out for a format whose record slot only carries Σy, Σy², Σxy (PART)
+        A.sad = __builtin_amdgcn_sad_u16(a, y, A.sad);
+        // a − y per half, biased by 0x8000 so that one 32-bit subtract serves both halves (no borrow: a|0x8000 ≥ y)
+        const uint32_t db = abias - y;
+        A.dmax = as_u32(__builtin_elementwise_max(as_us2(A.dmax), as_us2(db)));
+        A.dmin = as_u32(__builtin_elementwise_min(as_us2(A.dmin), as_us2(db)));
+    }
 }
 
 __device__ __forceinline__ uint32_t fmt_maxabs(const FmtAcc &A)
@@ -109,13 +108,9 @@ __device__ __forceinline__ uint32_t fmt_maxabs(const FmtAcc &A)
     return max(up, dn);
 }
 
-// v_pk_lshrrev_b16: per-half logical right shift, shift amount = low 4 bits (defined by the ISA for any d)
-__device__ __forceinline__ uint32_t pk_lshr(uint32_t v, uint32_t sh)
-{
-    uint32_t r;
-    asm("v_pk_lshrrev_b16 %0, %1, %2" : "=v"(r) : "v"(sh), "v"(v));
-    return r;
-}
+// v_pk_lshrrev_b16: per-half logical right shift; every caller keeps the shift amounts at 15 or below.  (Round 2 had this as inline
+// asm; the compiler then put an `s_nop 0` — four issue cycles — behind each of the three per element pair.)
+__device__ __forceinline__ uint32_t pk_lshr(uint32_t v, uint32_t sh) { return as_u32(as_us2(v) >> as_us2(sh)); }
 
 __device__ __forceinline__ double pow2_f64(uint32_t biased_hi) { return __hiloint2double((int)biased_hi, 0); }
 
@@ -126,7 +121,9 @@ struct GroupOut {
     bool bad;   // outside the exact route's preconditions: the tile is redone by the literal fix-up kernel
 };
 
-template <uint32_t BFP, typename Reload>
+// BFP: the BFP formats evaluated (bit 0 bfp8, 1 bfp4, 2 bfp2); PART ⊂ BFP: those of them whose slot only gets Σy, Σy², Σxy
+// (mtq_tile_stats_partial: the greedy search needs nothing else of a format until a tile ends up in it).
+template <uint32_t BFP, uint32_t PART, typename Reload>
 __device__ __forceinline__ void fast_group(const uint32_t w[8], GroupOut &G, Reload reload)
 {
     uint32_t ab[8];
@@ -157,9 +154,9 @@ __device__ __forceinline__ void fast_group(const uint32_t w[8], GroupOut &G, Rel
         bmaxp = as_u32(__builtin_elementwise_max(as_us2(bmaxp), as_us2(b)));
         const uint32_t abias = a | 0x80008000u;
         // bfp8 also carries Σa² (see below), so it is evaluated for every mask; bfp4 / bfp2 only when requested
-        fmt_step<Fmt8>(a, abias, sgn, A8);
-        if constexpr (BFP & 2u) fmt_step<Fmt4>(a, abias, sgn, A4);
-        if constexpr (BFP & 4u) fmt_step<Fmt2>(a, abias, sgn, A2);
+        fmt_step<Fmt8, (BFP & 1u) != 0 && !(PART & 1u)>(a, abias, sgn, A8);
+        if constexpr (BFP & 2u) fmt_step<Fmt4, !(PART & 2u)>(a, abias, sgn, A4);
+        if constexpr (BFP & 4u) fmt_step<Fmt2, !(PART & 4u)>(a, abias, sgn, A2);
     }
     // exact route needs every float32 term normal and finite: E in [80, 180]; anything else marks the tile — except an
     // all-zero group (pruned weights, padding), which contributes nothing: its (garbage) integers are scaled by
@@ -187,6 +184,7 @@ __device__ __forceinline__ void fast_group(const uint32_t w[8], GroupOut &G, Rel
         const uint32_t sq2 = f == 2 ? (A[f]->sq2 & 0xFFFFu) + (A[f]->sq2 >> 16) : A[f]->sq2;
         G.term[3 + 4 * f] = __builtin_ldexp((double)sq2, 2 * (Ei - 126 - mbs[f]));            // Σq² · 2^(2(E−126−mb))
         G.term[4 + 4 * f] = __builtin_ldexp((double)A[f]->saq, 2 * Ei - 267 - mbs[f]);        // Σa·q · 2^(2E−267−mb)
+        if (PART & (1u << f)) { G.term[5 + 4 * f] = 0.0; G.mx[f] = 0.0f; continue; }
         G.term[5 + 4 * f] = __builtin_ldexp((double)((A[f]->sad << 7) + sbs), e1);            // (128·Σ|a−y| + Σb) · 2^(E−148)
         G.mx[f] = (float)max(fmt_maxabs(*A[f]) << 7, bmax) * sf; // integer < 2^23: exact
     }
@@ -213,9 +211,37 @@ __device__ __forceinline__ void fast_group(const uint32_t w[8], GroupOut &G, Rel
         G.term[0] += tx;
         G.term[1] += tx2;
 #pragma unroll
-        for (int f = 0; f < 3; ++f) { G.term[5 + 4 * f] += tab; G.mx[f] = fmaxf(G.mx[f], tmx); }
+        for (int f = 0; f < 3; ++f) {
+            if (!(BFP & (1u << f)) || (PART & (1u << f))) continue;
+            G.term[5 + 4 * f] += tab; G.mx[f] = fmaxf(G.mx[f], tmx);
+        }
     }
 }
+
+// Which of the 14 group terms an instantiation produces, in ascending order (compile-time): Σx, Σx², then per evaluated
+// format Σy, Σy², Σxy and — unless the format is partial — Σ|x−y|.
+__host__ __device__ constexpr bool term_needed(uint32_t bfp, uint32_t part, int s)
+{
+    return s < 2 || (((bfp >> ((s - 2) >> 2)) & 1u) && (((s - 2) & 3) < 3 || !((part >> ((s - 2) >> 2)) & 1u)));
+}
+__host__ __device__ constexpr int terms_needed(uint32_t bfp, uint32_t part)
+{
+    int n = 0;
+    for (int s = 0; s < kSums; ++s) n += term_needed(bfp, part, s) ? 1 : 0;
+    return n;
+}
+__host__ __device__ constexpr int term_at(uint32_t bfp, uint32_t part, int i)
+{
+    int n = 0;
+    for (int s = 0; s < kSums; ++s) {
+        if (!term_needed(bfp, part, s)) continue;
+        if (n == i) return s;
+        ++n;
+    }
+    return 0;
+}
+// One reduce pass takes up to 13 statistics (4 tiles × n × 17 doubles of scratch + the record image inside the 8 KiB input image)
+constexpr int kOnePassMax = 13;
 
 // ---------------------------------------------------------------------------------------------
 // The kernel.  The 4 groups of a lane run in a ROLLED loop that reads each group from the LDS image just
@@ -233,17 +259,35 @@ __device__ __forceinline__ void glds16(const void *sbase, uint32_t voff, uint32_
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_addr) : "memory");
 }
 
-template <uint32_t BFP>
-__global__ __launch_bounds__(kFastWaves * 64, MTQ_ROLLED_WAVES_PER_SIMD) void tile_stats_bf16_rolled(
-    const uint16_t *__restrict__ x, int64_t stride, int64_t ld, int tiles_w, int64_t tiles, int units_w, int units_per_tensor,
-    int total_units, uint32_t fmt_mask, int rec, double *__restrict__ stats, unsigned *__restrict__ work, unsigned launch_id, int units_per_wave)
+// waves per SIMD an instantiation is compiled and launched for: the three-format kernel needs 146 VGPRs (3 waves); every smaller subset
+// fits 128 (4 waves: 8 KiB of LDS per wave allows 5).  -DMTQ_ROLLED_WAVES_PER_SIMD_FORCE=n overrides both.
+__host__ __device__ constexpr int rolled_waves(uint32_t bfp)
 {
+#ifdef MTQ_ROLLED_WAVES_PER_SIMD_FORCE
+    return MTQ_ROLLED_WAVES_PER_SIMD_FORCE;
+#else
+    return bfp == 7u ? 3 : 4;
+#endif
+}
+
+template <uint32_t BFP, uint32_t PART>
+__global__ __launch_bounds__(kFastWaves * 64, rolled_waves(BFP)) void tile_stats_bf16_rolled(
+    const uint16_t *__restrict__ x, int64_t stride, int64_t ld, int tiles_w, int64_t tiles, int units_w, int units_per_tensor,
+    int total_units, uint32_t fmt_mask, uint32_t eval_mask, uint32_t part_mask, int rec, double *__restrict__ stats, unsigned *__restrict__ work,
+    unsigned launch_id, int units_per_wave)
+{
+    // fmt_mask: the record LAYOUT (which slots exist); eval_mask ⊂ fmt_mask: the slots this launch writes; part_mask ⊂ eval_mask: those
+    // of them that only get Σy, Σy², Σxy.  Slots of the layout that are not written hold NaN afterwards (mtq_tile_stats_partial).
+    constexpr int nsum = terms_needed(BFP, PART);
+    constexpr bool one_pass = nsum <= kOnePassMax;
+    constexpr int scratch_doubles = one_pass ? kUnitTiles * nsum * kScratchStride : kScratchDoubles;
+    static_assert((scratch_doubles + kRecDoubles) * 8 <= kInBytes, "reduce scratch + record image must fit in the input image");
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     unsigned char *in = lds + wave * kRolledWaveLds;
     double *scratch = reinterpret_cast<double *>(in);                       // overlays the image after the reads
-    double *recbuf = scratch + kScratchDoubles;
+    double *recbuf = scratch + scratch_doubles;
     const uint32_t in_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)in;
     const uint32_t t = lane >> 4, j = lane & 15;
 
@@ -272,6 +316,7 @@ __global__ __launch_bounds__(kFastWaves * 64, MTQ_ROLLED_WAVES_PER_SIMD) void ti
     };
     const int o_bf16 = 2, o8 = 2 + 5 * __builtin_popcount(fmt_mask & 1u), o4 = 2 + 5 * __builtin_popcount(fmt_mask & 3u),
               o2 = 2 + 5 * __builtin_popcount(fmt_mask & 7u);
+    const bool holes = (eval_mask & ~part_mask & MTQ_MASK_ALL) != (fmt_mask & MTQ_MASK_ALL);   // some slot (or part of one) is not written
 
     auto unit_base = [&](int u, int &b, int &tr, int &uc) {
         b = u / units_per_tensor;
@@ -285,6 +330,33 @@ __global__ __launch_bounds__(kFastWaves * 64, MTQ_ROLLED_WAVES_PER_SIMD) void ti
         const unsigned char *base = reinterpret_cast<const unsigned char *>(x + (int64_t)b * stride + ((int64_t)tr * kTile) * ld + (int64_t)uc * kUnitCols);
 #pragma unroll
         for (int i = 0; i < 8; ++i) glds16(base, dma_off[i], in_addr + i * 1024);
+    };
+    // lane j of a tile's 16 lanes reduces one statistic and puts it where the record wants it
+    auto place = [&](double *rec_t, int sidx, double r) {
+        if (sidx == 0) {
+            rec_t[0] = r;
+            if (eval_mask & 1u) {
+                const double z = __builtin_fabs(r) * 0.0;
+                rec_t[o_bf16] = r; rec_t[o_bf16 + 3] = z; rec_t[o_bf16 + 4] = z;
+            }
+        } else if (sidx == 1) {
+            rec_t[1] = r;
+            if (eval_mask & 1u) { rec_t[o_bf16 + 1] = r; rec_t[o_bf16 + 2] = r; }
+        } else {
+            const int f = (sidx - 2) >> 2, k = (sidx - 2) & 3;
+            const int o = f == 0 ? o8 : (f == 1 ? o4 : o2);
+            if (eval_mask & (2u << f)) rec_t[o + k] = r;
+        }
+    };
+    auto tree16 = [&](const double *row) -> double {
+        double v[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v[k] = row[k];
+#pragma unroll
+        for (int stp = 1; stp < 16; stp <<= 1)
+#pragma unroll
+            for (int k = 0; k < 16; k += 2 * stp) v[k] = v[k] + v[k + stp];
+        return v[0];
     };
 
     // A wave retires after units_per_wave units (0: never — a fully persistent grid): the launch then consists of more blocks than
@@ -312,19 +384,21 @@ __global__ __launch_bounds__(kFastWaves * 64, MTQ_ROLLED_WAVES_PER_SIMD) void ti
             const uint4 hi = *reinterpret_cast<const uint4 *>(rowp + ((c0 ^ (kl | 1u)) << 4));
             const uint32_t w[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
             GroupOut G;
-            fast_group<BFP>(w, G, [&](uint32_t w2[8]) {
+            fast_group<BFP, PART>(w, G, [&](uint32_t w2[8]) {
                 const uint4 l2 = *reinterpret_cast<const uint4 *>(rowp + ((c0 ^ kl) << 4));
                 const uint4 h2 = *reinterpret_cast<const uint4 *>(rowp + ((c0 ^ (kl | 1u)) << 4));
                 w2[0] = l2.x; w2[1] = l2.y; w2[2] = l2.z; w2[3] = l2.w; w2[4] = h2.x; w2[5] = h2.y; w2[6] = h2.z; w2[7] = h2.w;
             });
 #pragma unroll
-            for (int s = 0; s < kSums; ++s) acc[s] = acc[s] + G.term[s];   // 0.0 + t = t exactly: sequential ((g0+g1)+g2)+g3
+            for (int s = 0; s < kSums; ++s)
+                if (term_needed(BFP, PART, s)) acc[s] = acc[s] + G.term[s];   // 0.0 + t = t exactly: sequential ((g0+g1)+g2)+g3
             mx[0] = fmaxf(mx[0], G.mx[0]); mx[1] = fmaxf(mx[1], G.mx[1]); mx[2] = fmaxf(mx[2], G.mx[2]);
             bad |= G.bad;
         }
 
 #pragma unroll
         for (int f = 0; f < 3; ++f) {
+            if (!(BFP & (1u << f)) || (PART & (1u << f))) continue;
 #pragma unroll
             for (int sft = 1; sft < 16; sft <<= 1) mx[f] = fmaxf(mx[f], __shfl_xor(mx[f], sft, 16));
         }
@@ -333,43 +407,39 @@ __global__ __launch_bounds__(kFastWaves * 64, MTQ_ROLLED_WAVES_PER_SIMD) void ti
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                   // every lane's image reads are done: overlay may begin
 
         double *rec_t = recbuf + t * rec;
-#pragma unroll
-        for (int pass = 0; pass < 2; ++pass) {
-#pragma unroll
-            for (int s = 0; s < 7; ++s) scratch[(t * 7 + s) * kScratchStride + j] = acc[7 * pass + s];
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if (j < 7) {
-                const double *row = scratch + (t * 7 + j) * kScratchStride;
-                double v[16];
-#pragma unroll
-                for (int k = 0; k < 16; ++k) v[k] = row[k];
-#pragma unroll
-                for (int stp = 1; stp < 16; stp <<= 1)
-#pragma unroll
-                    for (int k = 0; k < 16; k += 2 * stp) v[k] = v[k] + v[k + stp];
-                const double r = v[0];
-                const int sidx = 7 * pass + (int)j;
-                if (sidx == 0) {
-                    rec_t[0] = r;
-                    if (fmt_mask & 1u) {
-                        const double z = __builtin_fabs(r) * 0.0;
-                        rec_t[o_bf16] = r; rec_t[o_bf16 + 3] = z; rec_t[o_bf16 + 4] = z;
-                    }
-                } else if (sidx == 1) {
-                    rec_t[1] = r;
-                    if (fmt_mask & 1u) { rec_t[o_bf16 + 1] = r; rec_t[o_bf16 + 2] = r; }
-                } else {
-                    const int f = (sidx - 2) >> 2, k = (sidx - 2) & 3;
-                    const int o = f == 0 ? o8 : (f == 1 ? o4 : o2);
-                    if (fmt_mask & (2u << f)) rec_t[o + k] = r;
-                }
-            }
+        const int nrec = kUnitTiles * rec;
+        if (holes) {   // slots of the layout this launch does not write: NaN, so that a reader of an unwritten statistic cannot go unnoticed
+            const double poison = __longlong_as_double(0x7FF8000000000BADll);
+            if (lane < nrec) recbuf[lane] = poison;
+            if (lane + 64 < nrec) recbuf[lane + 64] = poison;
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
+        if constexpr (one_pass) {
+#pragma unroll
+            for (int i = 0; i < nsum; ++i) scratch[(t * nsum + i) * kScratchStride + j] = acc[term_at(BFP, PART, i)];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if ((int)j < nsum) {
+                const double r = tree16(scratch + (t * nsum + j) * kScratchStride);
+                int sidx = 0;
+#pragma unroll
+                for (int i = 0; i < nsum; ++i) sidx = (int)j == i ? term_at(BFP, PART, i) : sidx;
+                place(rec_t, sidx, r);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        } else {
+#pragma unroll
+            for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+                for (int s = 0; s < 7; ++s) scratch[(t * 7 + s) * kScratchStride + j] = acc[7 * pass + s];
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (j < 7) place(rec_t, 7 * pass + (int)j, tree16(scratch + (t * 7 + j) * kScratchStride));
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
+        }
         if (j == 15) {
-            if (fmt_mask & 2u) rec_t[o8 + 4] = (double)mx[0];
-            if (fmt_mask & 4u) rec_t[o4 + 4] = (double)mx[1];
-            if (fmt_mask & 8u) rec_t[o2 + 4] = (double)mx[2];
+            if (eval_mask & ~part_mask & 2u) rec_t[o8 + 4] = (double)mx[0];
+            if (eval_mask & ~part_mask & 4u) rec_t[o4 + 4] = (double)mx[1];
+            if (eval_mask & ~part_mask & 8u) rec_t[o2 + 4] = (double)mx[2];
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (tile_bad && j == 0) {
@@ -381,7 +451,6 @@ __global__ __launch_bounds__(kFastWaves * 64, MTQ_ROLLED_WAVES_PER_SIMD) void ti
         int b, tr, uc;
         unit_base(u, b, tr, uc);
         double *out = stats + ((int64_t)b * tiles + (int64_t)tr * tiles_w + uc * kUnitTiles) * rec;
-        const int nrec = kUnitTiles * rec;
         double r0 = 0.0, r1 = 0.0;
         if (lane < nrec) r0 = recbuf[lane];
         if (lane + 64 < nrec) r1 = recbuf[lane + 64];
@@ -397,9 +466,12 @@ __global__ __launch_bounds__(kFastWaves * 64, MTQ_ROLLED_WAVES_PER_SIMD) void ti
 
 using namespace mtq;
 
-// Launcher used by mtq_tile_stats_batched when the input qualifies (mtq_kernels.hip decides).
+// Launcher used by mtq_tile_stats_batched / mtq_tile_stats_partial when the input qualifies (mtq_kernels.hip decides).
+// fmt_mask: record layout; eval_mask ⊂ fmt_mask: slots to write; part_mask ⊂ eval_mask: slots that only get Σy, Σy², Σxy
+// (served for the combinations instantiated below; any other part_mask is widened to full slots, which is always allowed).
 extern "C" int mtq_launch_tile_stats_bf16_fast(const void *x, int64_t count, int64_t stride_elems, int64_t rows, int64_t cols,
-                                               int64_t ld, uint32_t fmt_mask, double *stats, void *stream, mtq::WorkSlot *work_out, unsigned launch_id)
+                                               int64_t ld, uint32_t fmt_mask, uint32_t eval_mask, uint32_t part_mask, double *stats, void *stream,
+                                               mtq::WorkSlot *work_out, unsigned launch_id)
 {
     const int64_t th = rows / kTile, tw = cols / kTile, tiles = th * tw;
     const int64_t units_w = cols / kUnitCols, upt = th * units_w, total = count * upt;
@@ -413,7 +485,10 @@ extern "C" int mtq_launch_tile_stats_bf16_fast(const void *x, int64_t count, int
         cus = p.multiProcessorCount;
     }
     const int64_t need = (total + kFastWaves - 1) / kFastWaves;
-    const int64_t max_blocks = (int64_t)cus * MTQ_ROLLED_WAVES_PER_SIMD * 4 / kFastWaves; // resident blocks: MTQ_ROLLED_WAVES_PER_SIMD waves on each of a CU's 4 SIMDs
+    eval_mask &= fmt_mask & MTQ_MASK_ALL;
+    part_mask &= eval_mask & 0xEu;
+    const uint32_t bfp = (eval_mask >> 1) & 7u;
+    const int64_t max_blocks = (int64_t)cus * rolled_waves(bfp) * 4 / kFastWaves; // resident blocks: that many waves on each of a CU's 4 SIMDs
     // MTQ_K1_UNITS_PER_WAVE (default 8; 0 = persistent waves): with a bound, the grid is what the units need at that many per wave,
     // rounded up to whole counter groups plus one spare block per group (a block that finds its group's queue empty exits at once)
     static int upw = -1;
@@ -429,18 +504,26 @@ extern "C" int mtq_launch_tile_stats_bf16_fast(const void *x, int64_t count, int
     const size_t lds_bytes = kFastWaves * kRolledWaveLds;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const uint16_t *xp = static_cast<const uint16_t *>(x);
+    uint32_t part = (part_mask >> 1) & 7u;
+    if (!((bfp == 3u && part == 2u) || (bfp == 1u && part == 1u) || (bfp == 2u && part == 2u))) { part = 0u; part_mask = 0u; }
     if (int rc = work_counter_acquire(stream, work_out)) return rc;   // `st` now waits for the slot's previous launch to have reset it
     unsigned *work = work_out->counters;
-#define MTQ_LAUNCH_FAST(B) \
-    hipLaunchKernelGGL(tile_stats_bf16_rolled<B>, grid, block, lds_bytes, st, xp, stride_elems, ld, (int)tw, tiles, (int)units_w, (int)upt, (int)total, fmt_mask, rec, stats, work, launch_id, (need > max_blocks ? upw : 0))
-    switch ((fmt_mask >> 1) & 7u) { // one instantiation per requested BFP subset: unrequested formats cost nothing
-    case 1: MTQ_LAUNCH_FAST(1u); break;
-    case 2: MTQ_LAUNCH_FAST(2u); break;
-    case 3: MTQ_LAUNCH_FAST(3u); break;
-    case 4: MTQ_LAUNCH_FAST(4u); break;
-    case 5: MTQ_LAUNCH_FAST(5u); break;
-    case 6: MTQ_LAUNCH_FAST(6u); break;
-    default: MTQ_LAUNCH_FAST(7u); break;
+#define MTQ_LAUNCH_FAST(B, P) \
+    hipLaunchKernelGGL((tile_stats_bf16_rolled<B, P>), grid, block, lds_bytes, st, xp, stride_elems, ld, (int)tw, tiles, (int)units_w, (int)upt, (int)total, fmt_mask, eval_mask, part_mask, rec, stats, work, launch_id, (need > max_blocks ? upw : 0))
+    switch (bfp | (part << 4)) { // one instantiation per evaluated BFP subset: unrequested formats cost nothing
+    case 0x01: MTQ_LAUNCH_FAST(1u, 0u); break;
+    case 0x02: MTQ_LAUNCH_FAST(2u, 0u); break;
+    case 0x03: MTQ_LAUNCH_FAST(3u, 0u); break;
+    case 0x04: MTQ_LAUNCH_FAST(4u, 0u); break;
+    case 0x05: MTQ_LAUNCH_FAST(5u, 0u); break;
+    case 0x06: MTQ_LAUNCH_FAST(6u, 0u); break;
+    case 0x07: MTQ_LAUNCH_FAST(7u, 0u); break;
+    case 0x11: MTQ_LAUNCH_FAST(1u, 1u); break;
+    case 0x22: MTQ_LAUNCH_FAST(2u, 2u); break;
+    case 0x23: MTQ_LAUNCH_FAST(3u, 2u); break;
+    default:                                             // no BFP format evaluated: the launcher's callers never ask for that
+        work_counter_release(*work_out, stream);
+        return fail(MTQ_ERR_INVALID, "the bf16 fast kernel needs at least one BFP format to evaluate");
     }
 #undef MTQ_LAUNCH_FAST
     return check_launch("mtq_tile_stats (bf16 fast)");

@@ -881,8 +881,10 @@ extern "C" int mtq_greedy_run_chain(const double *chain, const double *base, int
 
 // Process-wide pool of scan threads.  The streamed driver calls mtq_greedy_run_batch once per chunk of tensors, a few
 // calls in flight at a time; spawning and joining a thread per worker per call cost about as much as scanning a tensor
-// (≈ 0.35 ms per call with 8–16 workers), so the threads are created once, sleep on a condition variable between
-// batches and are never joined (the singleton is leaked on purpose: no destructor runs at process exit).
+// (≈ 0.35 ms per call with 8–16 workers), so the threads are created once and sleep on a condition variable between
+// batches.  The singleton itself is never destroyed (no destructor of ours runs at process exit); its threads are
+// joined by mtq_shutdown (host_shutdown below), which the Python binding calls from an atexit hook, and started
+// again by the next batch if there is one.
 namespace {
 class ScanPool {
 public:
@@ -890,12 +892,24 @@ public:
     void ensure(int n)
     {
         std::lock_guard<std::mutex> lock(mu_);
-        while ((int)threads_ < n) { std::thread([this] { loop(); }).detach(); ++threads_; }
+        stop_ = false;
+        while ((int)threads_.size() < n) threads_.emplace_back([this] { loop(); });
     }
     void submit(std::function<void()> fn)
     {
         { std::lock_guard<std::mutex> lock(mu_); queue_.push_back(std::move(fn)); }
         cv_.notify_one();
+    }
+    void shutdown()   // the queue is drained first: a batch in flight on another thread completes
+    {
+        std::vector<std::thread> mine;
+        {
+            std::lock_guard<std::mutex> lock(mu_);
+            stop_ = true;
+            mine.swap(threads_);
+        }
+        cv_.notify_all();
+        for (auto &t : mine) if (t.joinable()) t.join();
     }
 private:
     void loop()
@@ -904,7 +918,8 @@ private:
             std::function<void()> fn;
             {
                 std::unique_lock<std::mutex> lock(mu_);
-                cv_.wait(lock, [this] { return !queue_.empty(); });
+                cv_.wait(lock, [this] { return stop_ || !queue_.empty(); });
+                if (queue_.empty()) return;              // stop_ and nothing left to do
                 fn = std::move(queue_.front());
                 queue_.pop_front();
             }
@@ -914,7 +929,8 @@ private:
     std::mutex mu_;
     std::condition_variable cv_;
     std::deque<std::function<void()>> queue_;
-    size_t threads_ = 0;
+    std::vector<std::thread> threads_;
+    bool stop_ = false;
 };
 
 struct BatchState {
@@ -1002,3 +1018,6 @@ extern "C" int mtq_greedy_run_chain_batch(const double *chain, const double *bas
                                     elem_count, seeds[i], maps + i * tiles, counts ? counts + 4 * i : nullptr);
     });
 }
+
+// mtq_shutdown's part of this file (mtq_error.hpp): the scan threads are joined; a later batch starts them again.
+void mtq::host_shutdown() { ScanPool::instance().shutdown(); }

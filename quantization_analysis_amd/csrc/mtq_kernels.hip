@@ -37,27 +37,7 @@ __device__ __forceinline__ void tile_stats_one(const T *__restrict__ x, int64_t 
     uint32_t u[kGroup];
     Loader<T>::group(xb, tr * kTile + (lane >> 1), tc * kTile + (lane & 1) * kGroup, rows, cols, ld, vec_ok != 0, u);
     double acc[2 + 5 * kNumFmt]; // registers are indexed by FORMAT (static); the record is compacted when written
-    group_terms_literal(u, fmt_mask, acc);
-
-#pragma unroll
-    for (int k = 0; k < 2 + 5 * kNumFmt; ++k) {
-        const bool live = k < 2 || (fmt_mask & (1u << ((k - 2) / 5))); // wave-uniform
-        if (live) {
-            const bool is_max = k >= 2 && ((k - 2) % 5) == 4;
-            double v = acc[k];
-            {   // the 4 groups of a row pair (lanes 4j..4j+3) sequentially, identically in every lane of the quad
-                const int q0 = lane & ~3;
-                const double a = __shfl(v, q0, 64), b = __shfl(v, q0 + 1, 64), c = __shfl(v, q0 + 2, 64), d = __shfl(v, q0 + 3, 64);
-                v = is_max ? nanmax(nanmax(nanmax(a, b), c), d) : ((a + b) + c) + d;
-            }
-#pragma unroll
-            for (int s = 4; s < 64; s <<= 1) { // 16 row pairs: balanced tree
-                const double o = __shfl_xor(v, s, 64);
-                v = is_max ? nanmax(v, o) : v + o;
-            }
-            acc[k] = v;
-        }
-    }
+    tile_terms_literal(u, fmt_mask, acc);
     if (lane == 0) {
         double *out = stats + gt * rec;
         out[0] = acc[0];
@@ -277,7 +257,8 @@ static int check_matrix(const void *x, int in_dtype, int64_t rows, int64_t cols,
 using namespace mtq;
 
 extern "C" int mtq_launch_tile_stats_bf16_fast(const void *x, int64_t count, int64_t stride_elems, int64_t rows, int64_t cols,
-                                               int64_t ld, uint32_t fmt_mask, double *stats, void *stream, mtq::WorkSlot *work_out, unsigned launch_id);
+                                               int64_t ld, uint32_t fmt_mask, uint32_t eval_mask, uint32_t part_mask, double *stats, void *stream,
+                                               mtq::WorkSlot *work_out, unsigned launch_id);
 extern "C" int mtq_launch_tile_stats_direct(const void *x, int in_dtype, int64_t count, int64_t stride_elems, int64_t rows, int64_t cols,
                                             int64_t ld, uint32_t fmt_mask, double *stats, int vec_ok, void *stream, mtq::WorkSlot *work_out, unsigned launch_id);
 
@@ -298,6 +279,7 @@ struct HipEventOps {
     static bool create(event &e) { return hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess; }
     static bool record(event &e, stream s) { return hipEventRecord(e, s) == hipSuccess; }
     static bool wait(stream s, event &e) { return hipStreamWaitEvent(s, e, 0) == hipSuccess; }
+    static void destroy(event &e) { (void)hipEventDestroy(e); }
 };
 constexpr int kMaxDev = 64;
 constexpr size_t kSlotUnsigned = (size_t)kWorkGroups * kWorkStride;
@@ -343,6 +325,39 @@ void mtq::work_counter_release(const WorkSlot &slot, void *stream)
     (void)g_rings[slot.device].slots.release(slot.index, static_cast<hipStream_t>(stream));
 }
 
+void mtq::work_counter_abandon(const WorkSlot &slot)
+{
+    if (slot.index < 0 || slot.device < 0) return;
+    g_rings[slot.device].slots.abandon(slot.index);
+}
+
+// Everything the library holds on to between calls is released here, on request — never from a static destructor, where the HIP
+// runtime may already be gone (a run under rocprofv3 ended in a SIGSEGV inside __cxa_finalize in round 2).  The Python binding
+// registers it with atexit when it loads the library, i.e. after torch has registered its own exit hooks: it runs before them.
+extern "C" int mtq_shutdown(void)
+{
+    host_shutdown();                                   // scan threads joined
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess) n_dev = 0;   // no runtime left: nothing device-side can be released, and nothing needs to be
+    int cur = 0;
+    const bool have_cur = n_dev > 0 && hipGetDevice(&cur) == hipSuccess;
+    {
+        std::lock_guard<std::mutex> lock(g_ring_mu);
+        for (int d = 0; d < kMaxDev && d < n_dev; ++d) {
+            unsigned *base = g_rings[d].base.exchange(nullptr, std::memory_order_acq_rel);
+            if (!base) continue;
+            if (hipSetDevice(d) == hipSuccess) {
+                (void)hipDeviceSynchronize();          // no launch still counts units in the slots, no event is still pending
+                g_rings[d].slots.reset();
+                (void)hipFree(base);
+            }
+        }
+    }
+    if (n_dev > 0) scan_shutdown();                    // device jump-ahead tables
+    if (have_cur) (void)hipSetDevice(cur);
+    return MTQ_OK;
+}
+
 // The bookkeeping above against mock event operations (no GPU): 0 when every property holds, else the number of the
 // first failed check.  Exported for tests/test_capi_host.py.
 namespace {
@@ -352,8 +367,11 @@ struct MockOps {
     static int created, waits, last_wait_event, last_wait_stream;
     static bool create(event &e) { e.id = created++; return true; }
     static bool record(event &e, stream s) { e.recorded_on = s; return true; }
-    static bool wait(stream s, event &e) { ++waits; last_wait_event = e.id; last_wait_stream = s; return e.recorded_on >= 0; }
+    static bool wait(stream s, event &e) { ++waits; last_wait_event = e.id; last_wait_stream = s; if (fail_next > 0) { --fail_next; return false; } return e.recorded_on >= 0; }
+    static void destroy(event &e) { e.id = -1; e.recorded_on = -1; ++destroyed; }
+    static int fail_next, destroyed;
 };
+int MockOps::fail_next = 0, MockOps::destroyed = 0;
 int MockOps::created = 0, MockOps::waits = 0, MockOps::last_wait_event = -1, MockOps::last_wait_stream = -1;
 } // namespace
 
@@ -394,6 +412,7 @@ extern "C" int mtq_device_copy_2d(void *dst, size_t dst_pitch, const void *src, 
 extern "C" int mtq_selftest_slot_ring(void)
 {
     MockOps::created = MockOps::waits = 0;
+    MockOps::destroyed = 0;
     static SlotRing<MockOps, 4> ring;                    // static: the mutexes are not movable; the test runs once per process
     int a[4];
     for (int k = 0; k < 4; ++k) a[k] = ring.acquire(10 + k);
@@ -413,6 +432,26 @@ extern "C" int mtq_selftest_slot_ring(void)
         if (!ring.release(i, 40 + k)) return 10;
     }
     if (MockOps::waits != before + 8) return 11;
+    // a launch that could not be enqueued gives its slot back without a new event: the slot is free again, its old event still orders the next user
+    const int c = ring.acquire(60);
+    if (c < 0) return 12;
+    ring.abandon(c);
+    bool seen = false;
+    for (int k = 0; k < 4 && !seen; ++k) {
+        const int i = ring.acquire(70 + k);
+        if (i < 0) return 13;
+        seen = i == c;
+        if (!ring.release(i, 70 + k)) return 14;
+    }
+    if (!seen) return 15;
+    // a slot whose event cannot be waited for is passed over, not fatal
+    const int w0 = MockOps::waits;
+    MockOps::fail_next = 1;                               // the first slot tried cannot be waited for …
+    const int got = ring.acquire(81);
+    if (got < 0 || MockOps::fail_next != 0 || MockOps::waits != w0 + 2) return 17;   // … and the next one is handed out
+    if (!ring.release(got, 81)) return 18;
+    ring.reset();
+    if (MockOps::destroyed != 4) return 19;
     return 0;
 }
 
@@ -464,8 +503,9 @@ extern "C" int mtq_pack_slim_records(const double *stats, int64_t tiles, uint32_
     return check_launch("mtq_pack_slim_records");
 }
 
-extern "C" int mtq_tile_stats_batched(const void *x, int in_dtype, int64_t count, int64_t stride_elems, int64_t rows,
-                                      int64_t cols, int64_t ld, uint32_t fmt_mask, double *stats, void *stream)
+// K1 over a batch.  eval_mask / part_mask: mtq_tile_stats_partial (the whole layout, no partial slot, for mtq_tile_stats[_batched]).
+static int tile_stats_launch(const void *x, int in_dtype, int64_t count, int64_t stride_elems, int64_t rows, int64_t cols, int64_t ld,
+                             uint32_t fmt_mask, uint32_t eval_mask, uint32_t part_mask, double *stats, void *stream)
 {
     if (int rc = check_matrix(x, in_dtype, rows, cols, ld)) return rc;
     if (!stats) return fail(MTQ_ERR_INVALID, "stats is null");
@@ -481,7 +521,12 @@ extern "C" int mtq_tile_stats_batched(const void *x, int in_dtype, int64_t count
     if (in_dtype == MTQ_DTYPE_BF16 && vec_ok && rows % kTile == 0 && cols % 128 == 0 && (fmt_mask & 0xEu) != 0 && !force_generic()) {
         WorkSlot work;
         const unsigned launch_id = next_launch_id();
-        if (int rc = mtq_launch_tile_stats_bf16_fast(x, count, stride_elems, rows, cols, ld, fmt_mask, stats, stream, &work, launch_id)) return rc;
+        // the exact-integer kernel serves partial evaluation; every other route below writes the whole layout (always allowed)
+        const uint32_t ev = (eval_mask & 0xEu) ? eval_mask : fmt_mask;
+        if (int rc = mtq_launch_tile_stats_bf16_fast(x, count, stride_elems, rows, cols, ld, fmt_mask, ev, ev == eval_mask ? part_mask : 0u, stats, stream, &work, launch_id)) {
+            work_counter_abandon(work);                  // the launch never happened: the slot keeps its previous user's event
+            return rc;
+        }
         const int64_t waves = (count * tiles + 63) / 64;
         hipLaunchKernelGGL(tile_stats_redo_flagged<uint16_t>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, static_cast<hipStream_t>(stream),
                            static_cast<const uint16_t *>(x), count, stride_elems, rows, cols, ld, (int)tw, tiles, fmt_mask, rec, stats, vec_ok, work.counters, launch_id);
@@ -492,7 +537,10 @@ extern "C" int mtq_tile_stats_batched(const void *x, int in_dtype, int64_t count
     if ((fmt_mask & MTQ_MASK_ALL) != 0 && count * tiles < ((int64_t)1 << 31) && !force_generic()) {
         WorkSlot work;
         const unsigned launch_id = next_launch_id();
-        if (int rc = mtq_launch_tile_stats_direct(x, in_dtype, count, stride_elems, rows, cols, ld, fmt_mask, stats, vec_ok, stream, &work, launch_id)) return rc;
+        if (int rc = mtq_launch_tile_stats_direct(x, in_dtype, count, stride_elems, rows, cols, ld, fmt_mask, stats, vec_ok, stream, &work, launch_id)) {
+            work_counter_abandon(work);
+            return rc;
+        }
         const dim3 rgrid((unsigned)(((count * tiles + 63) / 64 + 3) / 4));
         if (in_dtype == MTQ_DTYPE_BF16)
             hipLaunchKernelGGL(tile_stats_redo_flagged<uint16_t>, rgrid, dim3(256), 0, s, static_cast<const uint16_t *>(x), count, stride_elems,
@@ -510,6 +558,21 @@ extern "C" int mtq_tile_stats_batched(const void *x, int in_dtype, int64_t count
         hipLaunchKernelGGL(tile_stats_generic<float>, dim3((unsigned)blocks), dim3(256), 0, s, static_cast<const float *>(x), count,
                            stride_elems, rows, cols, ld, (int)tw, tiles, fmt_mask, rec, stats, vec_ok);
     return check_launch("mtq_tile_stats");
+}
+
+extern "C" int mtq_tile_stats_batched(const void *x, int in_dtype, int64_t count, int64_t stride_elems, int64_t rows,
+                                      int64_t cols, int64_t ld, uint32_t fmt_mask, double *stats, void *stream)
+{
+    return tile_stats_launch(x, in_dtype, count, stride_elems, rows, cols, ld, fmt_mask, fmt_mask, 0u, stats, stream);
+}
+
+extern "C" int mtq_tile_stats_partial(const void *x, int in_dtype, int64_t count, int64_t stride_elems, int64_t rows, int64_t cols,
+                                      int64_t ld, uint32_t layout_mask, uint32_t full_mask, uint32_t sums_mask, double *stats, void *stream)
+{
+    if (((full_mask | sums_mask) & ~layout_mask) != 0 || (full_mask & sums_mask) != 0 || (layout_mask & ~MTQ_MASK_ALL) != 0)
+        return fail(MTQ_ERR_INVALID, "full_mask and sums_mask must be disjoint subsets of layout_mask");
+    if (sums_mask & 1u) return fail(MTQ_ERR_INVALID, "the bf16 slot has no partial form");
+    return tile_stats_launch(x, in_dtype, count, stride_elems, rows, cols, ld, layout_mask, full_mask | sums_mask, sums_mask, stats, stream);
 }
 
 extern "C" int mtq_tile_stats(const void *x, int in_dtype, int64_t rows, int64_t cols, int64_t ld, uint32_t fmt_mask,

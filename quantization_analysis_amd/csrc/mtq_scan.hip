@@ -279,6 +279,33 @@ __device__ bool wave_shuffle(Rng &r, const Order &ord, int n, uint32_t *cnt, int
     return true;
 }
 
+// Visiting orders that every tensor of a launch shares (mtq_scan_orders_device): all tensors of a model run are searched with ONE seed
+// (mixed_tile_greedy.py:222-226: default_rng(self.seed) per tensor), and a pass's permutation depends on nothing but the generator state
+// and the number of candidates — which is the tile count T as long as every earlier pass accepted every tile (the usual course of the
+// first passes: bfp8 is accepted everywhere at any threshold a user would ask for).  So the draws of the base pass, pass 1's permutation
+// of range(T) and — on the assumption that pass 1 accepts everything, checked by every tensor — pass 2's are computed once per launch
+// instead of once per tensor.  A tensor whose course differs falls back to its own shuffle from the shared generator state.
+struct alignas(16) OrdersHdr {
+    U128 state[3];            // generator state after the base pass's draws, after pass 1's permutation, after pass 2's
+    U128 inc;
+    uint32_t has32[3], u32[3];
+    uint32_t tiles, n_orders;
+    uint64_t seed;
+    uint32_t ok[2];           // written by the two blocks of the orders kernel: 1 = that order is complete
+    uint32_t pad[4];
+};
+static_assert(sizeof(OrdersHdr) == 128, "orders header layout");
+__host__ __device__ inline size_t orders_stride(int64_t tiles) { return (size_t)((tiles + 63) & ~(int64_t)63); }
+
+// What phase 1 of a split search hands to phase 2, per tensor
+struct Carry {
+    double Sy, Sy2, Sxy, sum_x, sum_x2;
+    U128 state, inc;
+    uint32_t has32, u32;
+    int32_t status, done;
+};
+static_assert(sizeof(Carry) == 88, "carry layout");
+
 struct ScanArgs {
     const double *stats;      // [count][tiles][rec]
     int64_t tiles;
@@ -296,7 +323,12 @@ struct ScanArgs {
     int32_t *counts;          // [count][4] out (may be null): tiles per format code in the finished map
     uint32_t *order_g;        // [count][tiles] scratch (tiles > kScanMaxTilesLds)
     double *delta;            // [count][tiles][4] scratch: Δ(Σy, Σy², Σxy) of the visit and the tile's previous code
+    double *delta2;           // the same for pass 2 under the shared orders (filled by the helper wave while pass 1 is visited)
     const U128 *jump_a, *jump_g;   // [kJump]
+    const unsigned char *orders;   // OrdersHdr + two index arrays, or null
+    int phase;                // 0: the whole search; 1: every pass but the last, then the last pass's candidates → listed; 2: the last pass
+    uint32_t *listed, *n_listed;
+    Carry *carry;             // [count] (phases 1 and 2)
 };
 
 constexpr int kNoOffset = 0xFF;
@@ -336,237 +368,354 @@ __device__ inline bool pcc_good(double n, double mean_x, double am2, double thr,
     return val >= thr;
 }
 
+#ifdef MTQ_SCAN_PROFILE
+#define MTQ_SCAN_STAMP(slot) do { const unsigned long long now_ = clock64(); if (b == 0 && lane == 0 && (slot) < 16) g_scan_ticks[slot] = now_ - tick_s; tick_s = now_; } while (0)
+#else
+#define MTQ_SCAN_STAMP(slot) do { } while (0)
+#endif
+
+struct Offsets3 { uint32_t y, y2, xy; };   // packed by format code, one byte each (rec <= 22): a per-lane code picks its offset with a shift
+
+// Deltas of every visit of a pass in visiting order (mixed_tile_greedy.py:259-261; mae :293): the candidate format's sums minus those of
+// the format the tile holds.  Four rounds of 64 gathers in flight (latency-bound).  tile_at(k) → tile of visit k; prev_of(tile) → its code.
+template <bool kMae, typename TileAt, typename PrevOf>
+__device__ inline void gather_deltas(const double *st, int rec, Offsets3 po, int f, int nc, double *delta, int lane, TileAt tile_at, PrevOf prev_of)
+{
+    const uint32_t oy_f = (po.y >> (8 * f)) & 0xFFu, oy2_f = (po.y2 >> (8 * f)) & 0xFFu, oxy_f = (po.xy >> (8 * f)) & 0xFFu;
+    for (int k0 = 0; k0 < nc; k0 += 256) {
+        uint32_t tt[4];
+        int pv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int k = k0 + 64 * u + lane;
+            tt[u] = k < nc ? tile_at((uint32_t)k) : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) pv[u] = prev_of(tt[u]);
+        double dd[4][3];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const double *rt = st + (int64_t)tt[u] * rec;
+            const int sh = 8 * pv[u];                     // the previous format's offsets out of the packed tables: no indexed load
+            if (kMae) {                                      // :293 — the candidate's Σ|x−y| minus the tile's current one
+                dd[u][0] = rec_at(rt, oy_f) - rec_at(rt, (po.y >> sh) & 0xFFu);
+                dd[u][1] = dd[u][2] = 0.0;
+            } else {
+                dd[u][0] = rt[oy_f] - rt[(po.y >> sh) & 0xFFu];   // :259-261
+                dd[u][1] = rt[oy2_f] - rt[(po.y2 >> sh) & 0xFFu];
+                dd[u][2] = rt[oxy_f] - rt[(po.xy >> sh) & 0xFFu];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int k = k0 + 64 * u + lane;
+            if (k < nc) {
+                double *d = delta + (int64_t)k * 4;
+                d[0] = dd[u][0]; d[1] = dd[u][1]; d[2] = dd[u][2]; d[3] = __longlong_as_double((long long)pv[u]);
+            }
+        }
+    }
+    mem_wait();
+}
+
+// The visits of one pass (:234-278), 64 per round under a speculation on their outcome (file header).  → 0, or 1 when a zero
+// denominator turned up.  any_rej: some visit of the pass was rejected (its tile is fixed).
+template <bool kMae, typename TileAt>
+__device__ inline int visit_pass(TileAt tile_at, const double *delta, int nc, int f, int8_t *map, double *lds_d, double *lds_p, int lane, double n,
+                                 double mean_x, double am2, double thr, double &Sy, double &Sy2, double &Sxy, bool &any_rej)
+{
+    constexpr bool mae = kMae;
+    int k = 0, pk = -1;
+    double pdy = 0.0, pdy2 = 0.0, pdxy = 0.0;
+    int pprev = 0;
+    uint32_t pt = 0;
+    bool accept_mode = true;
+    int span = 16;   // visits an accept-mode round stages: its three serial chains cost per visit staged, and a run of acceptances is short
+                     // where rejections are frequent — 16 after a rejection, 64 after a round that accepted all of its visits
+    while (k < nc) {
+        const int m = min(accept_mode ? span : 64, nc - k);
+        const bool active = lane < m;
+        double dy = 0.0, dy2 = 0.0, dxy = 0.0;
+        int prev = 0;
+        uint32_t t = 0;
+        if (pk == k) {   // the window fetched ahead (the previous round consumed all of its visits)
+            dy = pdy; dy2 = pdy2; dxy = pdxy; prev = pprev; t = pt;
+        } else if (active) {
+            const double *d = delta + (int64_t)(k + lane) * 4;
+            dy = ld_l2(d); dy2 = ld_l2(d + 1); dxy = ld_l2(d + 2);
+            prev = (int)__double_as_longlong(ld_l2(d + 3));
+            t = tile_at((uint32_t)(k + lane));
+        }
+        pk = k + m;      // fetch the window after this one while this one is decided (useless only when the speculation fails)
+        pdy = pdy2 = pdxy = 0.0; pprev = 0; pt = 0;
+        if (pk + lane < nc) {
+            const double *d = delta + (int64_t)(pk + lane) * 4;
+            pdy = ld_l2(d); pdy2 = ld_l2(d + 1); pdxy = ld_l2(d + 2);
+            pprev = (int)__double_as_longlong(ld_l2(d + 3));
+            pt = tile_at((uint32_t)(pk + lane));
+        }
+        double cy, cy2, cxy;
+        if (accept_mode) {   // lane i: the running sums after visits 0..i, added one after the other as the sequential scan adds them
+            lds_d[lane * 4 + 0] = dy; lds_d[lane * 4 + 1] = dy2; lds_d[lane * 4 + 2] = dxy;
+            compiler_fence();   // one wave: its LDS operations execute in program order
+            if (lane < 3) {   // inactive visits staged +0 deltas: their prefixes are never read
+                const double s0 = lane == 0 ? Sy : (lane == 1 ? Sy2 : Sxy);
+                if (span == 16) prefix_chain<16>(lds_d, lds_p, lane, s0);   // both fully unrolled: a run-time bound cost more than the short chain saves
+                else prefix_chain<64>(lds_d, lds_p, lane, s0);
+            }
+            compiler_fence();
+            cy = lds_p[lane * 4 + 0]; cy2 = lds_p[lane * 4 + 1]; cxy = lds_p[lane * 4 + 2];
+            compiler_fence();
+        } else {             // lane i: the running sums plus its own delta
+            cy = Sy + dy; cy2 = Sy2 + dy2; cxy = Sxy + dxy;
+        }
+        bool special = false;
+        const bool good = mae ? cy / n <= thr : pcc_good(n, mean_x, am2, thr, cy, cy2, cxy, special);   // mae: is_good(cab / N) (:293-294)
+        const uint64_t act = below(m);
+        const uint64_t okm = __ballot(good && active) & act, spm = __ballot(special && active) & act;
+        int j, take = -1;
+        if (accept_mode) {
+            const uint64_t rej = ~okm & act;
+            j = rej ? __builtin_ctzll(rej) : m;            // first rejected visit
+            if (spm & below(min(j + 1, 64))) return 1;      // a zero denominator among the visits this round settles
+            if (lane < j) map[t] = (int8_t)f;              // accepted (:264-276)
+            if (j > 0) take = j - 1;
+            if (j < m) { if (lane == j) map[t] = (int8_t)(prev | 0x80); any_rej = true; k += j + 1; span = 16; if (j == 0) accept_mode = false; }   // fixed (:277-278)
+            else { k += m; span = 64; }
+        } else {
+            j = okm ? __builtin_ctzll(okm) : m;            // first accepted visit
+            if (spm & below(min(j + 1, 64))) return 1;
+            if (lane < j) map[t] = (int8_t)(prev | 0x80);
+            if (j > 0) any_rej = true;
+            if (j < m) { if (lane == j) map[t] = (int8_t)f; take = j; k += j + 1; if (j == 0) { accept_mode = true; span = 16; } }
+            else k += m;
+        }
+        if (take >= 0) { Sy = readlane_f64(cy, take); Sy2 = readlane_f64(cy2, take); Sxy = readlane_f64(cxy, take); }   // take is wave-uniform
+    }
+    mem_wait();
+    return 0;
+}
+
 template <bool kMae, typename Order>
-__device__ void scan_tensor(const ScanArgs &a, const Order &ord, int b, unsigned char *lds, int lane)
+__device__ void scan_tensor(const ScanArgs &a, const Order &ord, int b, unsigned char *lds, int lane, int wave, bool two_waves)
 {
     const int T = (int)a.tiles;
     const int rec = a.rec;
     const double *st = a.stats + (int64_t)b * a.tiles * rec;
     int8_t *map = a.maps + (int64_t)b * a.tiles;
     double *delta = a.delta + (int64_t)b * a.tiles * 4;
+    double *delta2 = a.delta2 + (int64_t)b * a.tiles * 4;
     double *lds_d = reinterpret_cast<double *>(lds);                 // [64][4] deltas / staging
     double *lds_p = lds_d + 64 * 4;                                    // [64][4] prefixes
     double *lds_i = lds_p + 64 * 4;                                    // [64][5] initial-sum staging
     uint32_t *cnt = reinterpret_cast<uint32_t *>(lds_i + 64 * 5);   // [kTagSlots / 4] byte counters of the shuffle's conflict detection
-    int status = 0;
-#ifdef MTQ_SCAN_PROFILE
-    if (b == 0 && lane == 0) for (int q = 12; q < 16; ++q) g_scan_ticks[q] = 0;
-#endif
-    unsigned long long tick = clock64();
-    auto stamp = [&](int slot) {
-        const unsigned long long now = clock64();
-        if (b == 0 && lane == 0 && slot < 16) g_scan_ticks[slot] = now - tick;
-        tick = now;
-    };
-
-    for (int i = lane; i < kTagSlots / 4; i += 64) cnt[i] = 0u;
-    const int base = a.fmt[0];
-    for (int t = lane; t < T; t += 64) map[t] = (int8_t)base;        // :99
-
-    // ---- generator
-    Rng r;
-    {
-        U128 inc;
-        seed_pcg(a.seeds[b], r.state, inc);
-        r.has32 = false;
-        r.u32 = 0u;
-        const int q0 = (lane >> 1) + 1, q1 = lane >= 1 ? ((lane - 1) >> 1) + 1 : 1;
-        r.a0 = a.jump_a[q0]; r.c0 = mul128(a.jump_g[q0], inc);
-        r.a1 = a.jump_a[q1]; r.c1 = mul128(a.jump_g[q1], inc);
-    }
-
-    // ---- initial sums in tile order (:147-174): chains Σx, Σx², Σy, Σy², Σxy on lanes 0..4
     constexpr bool mae = kMae;   // compiled per metric (a run-time flag cost the pcc scan 9 %): one running sum, Σ|x−y| (:280-301), carried where the pcc search carries Σy; Σy², Σxy idle
-    const int off5[5] = {0, 1, mae ? a.oab[base] : a.oy[base], a.oy2[base], a.oxy[base]};
+    const int base = a.fmt[0];
     // record offsets by format code, one byte each (rec <= 22): a per-lane code picks its offset with a shift, where indexing the
     // argument arrays by a per-lane value makes every gather wait for a table load
     const int *o1 = mae ? a.oab : a.oy;
-    const uint32_t poy = (uint32_t)o1[0] | ((uint32_t)o1[1] << 8) | ((uint32_t)o1[2] << 16) | ((uint32_t)o1[3] << 24);
-    const uint32_t poy2 = (uint32_t)a.oy2[0] | ((uint32_t)a.oy2[1] << 8) | ((uint32_t)a.oy2[2] << 16) | ((uint32_t)a.oy2[3] << 24);
-    const uint32_t poxy = (uint32_t)a.oxy[0] | ((uint32_t)a.oxy[1] << 8) | ((uint32_t)a.oxy[2] << 16) | ((uint32_t)a.oxy[3] << 24);
-    double acc = 0.0;
-    double nx[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
-    if (lane < T) {
-        const double *rt = st + (int64_t)lane * rec;
-#pragma unroll
-        for (int c = 0; c < 5; ++c) nx[c] = rec_at(rt, (uint32_t)off5[c]);
-    }
-    for (int t0 = 0; t0 < T; t0 += 64) {
-        const int m = min(64, T - t0);
-        if (lane < m) {
-#pragma unroll
-            for (int c = 0; c < 5; ++c) lds_i[lane * 5 + c] = nx[c];
+    Offsets3 po;
+    po.y = (uint32_t)o1[0] | ((uint32_t)o1[1] << 8) | ((uint32_t)o1[2] << 16) | ((uint32_t)o1[3] << 24);
+    po.y2 = (uint32_t)a.oy2[0] | ((uint32_t)a.oy2[1] << 8) | ((uint32_t)a.oy2[2] << 16) | ((uint32_t)a.oy2[3] << 24);
+    po.xy = (uint32_t)a.oxy[0] | ((uint32_t)a.oxy[1] << 8) | ((uint32_t)a.oxy[2] << 16) | ((uint32_t)a.oxy[3] << 24);
+
+    // passes p_begin .. p_end−1 run in this launch; passes 1 .. n_sh may take their visiting order from the launch's shared orders
+    const int p_end = a.phase == 1 ? a.n_formats - 1 : a.n_formats;
+    const OrdersHdr *hdr = reinterpret_cast<const OrdersHdr *>(a.orders);
+    int n_sh = 0;
+    if (hdr && a.phase != 2 && hdr->tiles == (uint32_t)T && hdr->ok[0]) n_sh = (hdr->n_orders >= 2 && hdr->ok[1]) ? 2 : 1;
+    n_sh = min(n_sh, p_end - 1);
+    const uint32_t *P1 = reinterpret_cast<const uint32_t *>(a.orders + sizeof(OrdersHdr)), *P2 = P1 + orders_stride(T);
+
+    // tile of visit k: out of the launch's shared order Pg, or out of this tensor's own order
+    const uint32_t *Pg = nullptr;
+    auto tile_at = [&](uint32_t k) -> uint32_t { return Pg ? Pg[k] : ord.get(k); };
+    // code a tile holds when a pass comes to it: a known format (prev_code >= 0: the helper wave's speculation) or what the map says
+    int prev_code = -1;
+    auto prev_of = [&](uint32_t t) -> int { return prev_code >= 0 ? prev_code : (int)((uint8_t)ld_l2(map + t) & 0x7Fu); };
+
+    if (wave == 1) {
+        // Helper wave: the deltas of the passes that use the shared orders, speculating that pass p finds every tile in format fmt[p−1]
+        // (true while every earlier pass accepted every tile — the visiting wave checks, and gathers its own deltas otherwise).  Pass 1's
+        // are gathered while the visiting wave forms the initial sums, pass 2's while it visits pass 1.
+#pragma nounroll
+        for (int p = 1; p <= 2; ++p) {
+            if (p <= n_sh) {
+                Pg = p == 1 ? P1 : P2;
+                prev_code = a.fmt[p - 1];
+                gather_deltas<kMae>(st, rec, po, a.fmt[p], T, p == 1 ? delta : delta2, lane, tile_at, prev_of);
+            }
+            __syncthreads();
         }
-        if (t0 + 64 + lane < T) {   // the next block's records are on their way while this block's chain runs
-            const double *rt = st + (int64_t)(t0 + 64 + lane) * rec;
+        return;
+    }
+
+    int status = 0;
+    bool done = false;            // the search is over before the launch's last pass: nothing but the finish is left
+#ifdef MTQ_SCAN_PROFILE
+    if (b == 0 && lane == 0) for (int q = 12; q < 16; ++q) g_scan_ticks[q] = 0;
+    unsigned long long tick_s = clock64();
+#endif
+    for (int i = lane; i < kTagSlots / 4; i += 64) cnt[i] = 0u;
+    compiler_fence();
+
+    Rng r;
+    U128 inc;
+    double sum_x = 0.0, sum_x2 = 0.0, Sy = 0.0, Sy2 = 0.0, Sxy = 0.0;
+    const double n = a.n, thr = a.thr;
+    auto set_jumps = [&]() {
+        const int q0 = (lane >> 1) + 1, q1 = lane >= 1 ? ((lane - 1) >> 1) + 1 : 1;
+        r.a0 = a.jump_a[q0]; r.c0 = mul128(a.jump_g[q0], inc);
+        r.a1 = a.jump_a[q1]; r.c1 = mul128(a.jump_g[q1], inc);
+    };
+    int p_begin = 1;
+
+    if (a.phase != 2) {
+        for (int t = lane; t < T; t += 64) map[t] = (int8_t)base;        // :99
+        // ---- generator
+        if (n_sh >= 1) { inc = hdr->inc; r.state = hdr->state[0]; r.has32 = hdr->has32[0] != 0u; r.u32 = hdr->u32[0]; }   // as it stands after the base pass's draws
+        else { seed_pcg(a.seeds[b], r.state, inc); r.has32 = false; r.u32 = 0u; }
+        set_jumps();
+
+        // ---- initial sums in tile order (:147-174): chains Σx, Σx², Σy, Σy², Σxy on lanes 0..4
+        const int off5[5] = {0, 1, mae ? a.oab[base] : a.oy[base], a.oy2[base], a.oxy[base]};
+        double acc = 0.0;
+        double nx[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+        if (lane < T) {
+            const double *rt = st + (int64_t)lane * rec;
 #pragma unroll
             for (int c = 0; c < 5; ++c) nx[c] = rec_at(rt, (uint32_t)off5[c]);
         }
-        __syncthreads();
-        if (lane < 5) {
-            if (m == 64) {   // sixteen staged values ahead: the additions stay one dependent chain in tile order, the LDS reads do not wait for it
-                double v[16], w[16];
+        for (int t0 = 0; t0 < T; t0 += 64) {
+            const int m = min(64, T - t0);
+            if (lane < m) {
 #pragma unroll
-                for (int u = 0; u < 16; ++u) v[u] = lds_i[u * 5 + lane];
-#pragma unroll
-                for (int i0 = 0; i0 < 64; i0 += 16) {
-                    if (i0 + 16 < 64) {
-#pragma unroll
-                        for (int u = 0; u < 16; ++u) w[u] = lds_i[(i0 + 16 + u) * 5 + lane];
-                    }
-#pragma unroll
-                    for (int u = 0; u < 16; ++u) acc = acc + v[u];
-#pragma unroll
-                    for (int u = 0; u < 16; ++u) v[u] = w[u];
-                }
-            } else {
-                for (int i = 0; i < m; ++i) acc = acc + lds_i[i * 5 + lane];
+                for (int c = 0; c < 5; ++c) lds_i[lane * 5 + c] = nx[c];
             }
+            if (t0 + 64 + lane < T) {   // the next block's records are on their way while this block's chain runs
+                const double *rt = st + (int64_t)(t0 + 64 + lane) * rec;
+#pragma unroll
+                for (int c = 0; c < 5; ++c) nx[c] = rec_at(rt, (uint32_t)off5[c]);
+            }
+            compiler_fence();
+            if (lane < 5) {
+                if (m == 64) {   // sixteen staged values ahead: the additions stay one dependent chain in tile order, the LDS reads do not wait for it
+                    double v[16], w[16];
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) v[u] = lds_i[u * 5 + lane];
+#pragma unroll
+                    for (int i0 = 0; i0 < 64; i0 += 16) {
+                        if (i0 + 16 < 64) {
+#pragma unroll
+                            for (int u = 0; u < 16; ++u) w[u] = lds_i[(i0 + 16 + u) * 5 + lane];
+                        }
+#pragma unroll
+                        for (int u = 0; u < 16; ++u) acc = acc + v[u];
+#pragma unroll
+                        for (int u = 0; u < 16; ++u) v[u] = w[u];
+                    }
+                } else {
+                    for (int i = 0; i < m; ++i) acc = acc + lds_i[i * 5 + lane];
+                }
+            }
+            compiler_fence();
         }
-        __syncthreads();
+        sum_x = shfl_f64(acc, 0); sum_x2 = shfl_f64(acc, 1);
+        Sy = shfl_f64(acc, 2); Sy2 = shfl_f64(acc, 3); Sxy = shfl_f64(acc, 4);
+    } else {
+        const Carry &c = a.carry[b];
+        Sy = c.Sy; Sy2 = c.Sy2; Sxy = c.Sxy; sum_x = c.sum_x; sum_x2 = c.sum_x2;
+        r.state = c.state; inc = c.inc; r.has32 = c.has32 != 0u; r.u32 = c.u32;
+        status = c.status; done = c.done != 0;
+        set_jumps();
+        p_begin = a.n_formats - 1;
     }
-    const double sum_x = shfl_f64(acc, 0), sum_x2 = shfl_f64(acc, 1);
-    double Sy = shfl_f64(acc, 2), Sy2 = shfl_f64(acc, 3), Sxy = shfl_f64(acc, 4);
-    const double n = a.n, thr = a.thr;
     const double mean_x = sum_x / n;
     double am2 = sum_x2 - n * mean_x * mean_x;
     if (am2 < 0.0) am2 = 0.0;
+    MTQ_SCAN_STAMP(0);
 
-    stamp(0);
-    // ---- pass of the base format: every tile already has it, one question for all of them (:237-241)
-    bool all_fixed = false;
-    {
+    if (a.phase != 2) {
+        // ---- pass of the base format: every tile already has it, one question for all of them (:237-241)
         bool special = false;
         const bool good = mae ? Sy / n <= thr : pcc_good(n, mean_x, am2, thr, Sy, Sy2, Sxy, special);   // mae: is_good(sum_abs / N) (:280-284)
         if (special) status = 1;
-        all_fixed = !good;
-        if (!wave_shuffle<false>(r, ord, T, cnt, lane)) status = 2;   // the generator advances as the permutation would have
+        done = !good;                                                  // every tile is fixed at once: no later pass has a candidate
+        if (n_sh == 0 && !wave_shuffle<false>(r, ord, T, cnt, lane)) status = 2;   // the generator advances as the permutation would have
+        if (two_waves) __syncthreads();                                // the helper wave's deltas of pass 1 are in memory
+    }
+    MTQ_SCAN_STAMP(1);
+
+    bool pristine = a.phase != 2;     // every pass so far accepted every tile: the next pass's candidates are all T tiles, in tile order
+    bool b2_pending = two_waves && a.phase != 2;
+    for (int p = p_begin; p < p_end && status == 0 && !done; ++p) {
+        const int f = a.fmt[p];
+        if (p == 2 && b2_pending) { __syncthreads(); b2_pending = false; }   // the helper wave's deltas of pass 2 are in memory
+        bool any_rej = false;
+        const bool use_sh = pristine && p <= n_sh;
+        int nc = T;
+        double *dl = delta;
+        if (use_sh) {
+            // order = rng.permutation(arange(T)) from the shared state: computed once per launch; the deltas came from the helper wave
+            Pg = p == 1 ? P1 : P2;
+            dl = p == 1 ? delta : delta2;
+            MTQ_SCAN_STAMP(2 + 3 * (p - 1));
+        } else {
+            Pg = nullptr;
+            // candidates = np.where(~fixed)[0] (:228): in tile order
+            nc = 0;
+            for (int t0 = 0; t0 < T; t0 += 64) {
+                const int t = t0 + lane;
+                const bool cand = t < T && ((uint8_t)ld_l2(map + t) & 0x80u) == 0u;
+                const uint64_t bm = __ballot(cand);
+                if (cand) ord.set((uint32_t)(nc + __builtin_popcountll(bm & below(lane))), (uint32_t)t);
+                nc += __builtin_popcountll(bm);
+            }
+            ord.sync();
+            if (nc == 0) break;                                            // :229-230
+            if (!wave_shuffle<true>(r, ord, nc, cnt, lane)) { status = 2; break; }   // order = rng.permutation(candidates), :231
+            MTQ_SCAN_STAMP(2 + 3 * (p - 1));
+            // deltas of every visit of the pass (a tile is visited once per pass, so its previous format is what the map holds now)
+            gather_deltas<kMae>(st, rec, po, f, nc, delta, lane, tile_at, prev_of);
+        }
+        MTQ_SCAN_STAMP(3 + 3 * (p - 1));
+        status = visit_pass<kMae>(tile_at, dl, nc, f, map, lds_d, lds_p, lane, n, mean_x, am2, thr, Sy, Sy2, Sxy, any_rej);
+        if (use_sh) { r.state = hdr->state[p]; r.has32 = hdr->has32[p] != 0u; r.u32 = hdr->u32[p]; }   // the generator as it stands after this pass's permutation
+        if (any_rej) pristine = false;
+        MTQ_SCAN_STAMP(4 + 3 * (p - 1));
+    }
+    if (b2_pending) __syncthreads();
+    mem_wait();
+
+    if (a.phase == 1) {
+        // the last pass's candidates (:228) → the launch's list of tiles whose remaining statistics are evaluated now (mtq_tile_stats_listed)
+        int nc = 0;
+        if (status == 0 && !done) {
+            for (int t0 = 0; t0 < T; t0 += 64) {
+                const int t = t0 + lane;
+                nc += __builtin_popcountll(__ballot(t < T && ((uint8_t)ld_l2(map + t) & 0x80u) == 0u));
+            }
+            unsigned first = 0u;
+            if (lane == 0 && nc > 0) first = atomicAdd(a.n_listed, (unsigned)nc);
+            first = (unsigned)__builtin_amdgcn_readfirstlane((int)first);
+            int at = 0;
+            for (int t0 = 0; t0 < T && nc > 0; t0 += 64) {
+                const int t = t0 + lane;
+                const bool cand = t < T && ((uint8_t)ld_l2(map + t) & 0x80u) == 0u;
+                const uint64_t bm = __ballot(cand);
+                if (cand) a.listed[first + (unsigned)(at + __builtin_popcountll(bm & below(lane)))] = (uint32_t)((int64_t)b * T + t);
+                at += __builtin_popcountll(bm);
+            }
+        }
+        if (lane == 0) {
+            Carry &c = a.carry[b];
+            c.Sy = Sy; c.Sy2 = Sy2; c.Sxy = Sxy; c.sum_x = sum_x; c.sum_x2 = sum_x2;
+            c.state = r.state; c.inc = inc; c.has32 = r.has32 ? 1u : 0u; c.u32 = r.u32;
+            c.status = status; c.done = (done || nc == 0) ? 1 : 0;       // no candidate: :229-230
+        }
+        return;
     }
 
-    stamp(1);
-    for (int p = 1; p < a.n_formats && status == 0 && !all_fixed; ++p) {
-        const int f = a.fmt[p];
-        const int oy_f = (int)((poy >> (8 * f)) & 0xFFu), oy2_f = (int)((poy2 >> (8 * f)) & 0xFFu), oxy_f = (int)((poxy >> (8 * f)) & 0xFFu);
-        // candidates = np.where(~fixed)[0] (:228): in tile order
-        int nc = 0;
-        for (int t0 = 0; t0 < T; t0 += 64) {
-            const int t = t0 + lane;
-            const bool cand = t < T && ((uint8_t)ld_l2(map + t) & 0x80u) == 0u;
-            const uint64_t bm = __ballot(cand);
-            if (cand) ord.set((uint32_t)(nc + __builtin_popcountll(bm & below(lane))), (uint32_t)t);
-            nc += __builtin_popcountll(bm);
-        }
-        ord.sync();
-        if (nc == 0) break;                                            // :229-230
-        if (!wave_shuffle<true>(r, ord, nc, cnt, lane)) { status = 2; break; }   // order = rng.permutation(candidates), :231
-        stamp(2 + 3 * (p - 1));
-        // deltas of every visit of the pass (a tile is visited once per pass, so its previous format is what the map holds now)
-        for (int k0 = 0; k0 < nc; k0 += 256) {   // four rounds of 64 visits in flight: the gathers are latency-bound
-            uint32_t tt[4];
-            int pv[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int k = k0 + 64 * u + lane;
-                tt[u] = k < nc ? ord.get((uint32_t)k) : 0u;
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) pv[u] = (int)((uint8_t)ld_l2(map + tt[u]) & 0x7Fu);
-            double dd[4][3];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const double *rt = st + (int64_t)tt[u] * rec;
-                const int sh = 8 * pv[u];                     // the previous format's offsets out of the packed tables: no indexed load
-                if (mae) {                                       // :293 — the candidate's Σ|x−y| minus the tile's current one
-                    dd[u][0] = rec_at(rt, (uint32_t)oy_f) - rec_at(rt, (poy >> sh) & 0xFFu);
-                    dd[u][1] = dd[u][2] = 0.0;
-                } else {
-                    dd[u][0] = rt[oy_f] - rt[(poy >> sh) & 0xFFu];   // :259-261
-                    dd[u][1] = rt[oy2_f] - rt[(poy2 >> sh) & 0xFFu];
-                    dd[u][2] = rt[oxy_f] - rt[(poxy >> sh) & 0xFFu];
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int k = k0 + 64 * u + lane;
-                if (k < nc) {
-                    double *d = delta + (int64_t)k * 4;
-                    d[0] = dd[u][0]; d[1] = dd[u][1]; d[2] = dd[u][2]; d[3] = __longlong_as_double((long long)pv[u]);
-                }
-            }
-        }
-        mem_wait();
-        stamp(3 + 3 * (p - 1));
-        // ---- the visits (:234-278), 64 per round
-        int k = 0, pk = -1;
-        double pdy = 0.0, pdy2 = 0.0, pdxy = 0.0;
-        int pprev = 0;
-        uint32_t pt = 0;
-        bool accept_mode = true;
-        int span = 16;   // visits an accept-mode round stages: its three serial chains cost per visit staged, and a run of acceptances is short
-                         // where rejections are frequent — 16 after a rejection, 64 after a round that accepted all of its visits
-        while (k < nc) {
-            const int m = min(accept_mode ? span : 64, nc - k);
-            const bool active = lane < m;
-            double dy = 0.0, dy2 = 0.0, dxy = 0.0;
-            int prev = 0;
-            uint32_t t = 0;
-            if (pk == k) {   // the window fetched ahead (the previous round consumed all of its visits)
-                dy = pdy; dy2 = pdy2; dxy = pdxy; prev = pprev; t = pt;
-            } else if (active) {
-                const double *d = delta + (int64_t)(k + lane) * 4;
-                dy = ld_l2(d); dy2 = ld_l2(d + 1); dxy = ld_l2(d + 2);
-                prev = (int)__double_as_longlong(ld_l2(d + 3));
-                t = ord.get((uint32_t)(k + lane));
-            }
-            pk = k + m;      // fetch the window after this one while this one is decided (useless only when the speculation fails)
-            pdy = pdy2 = pdxy = 0.0; pprev = 0; pt = 0;
-            if (pk + lane < nc) {
-                const double *d = delta + (int64_t)(pk + lane) * 4;
-                pdy = ld_l2(d); pdy2 = ld_l2(d + 1); pdxy = ld_l2(d + 2);
-                pprev = (int)__double_as_longlong(ld_l2(d + 3));
-                pt = ord.get((uint32_t)(pk + lane));
-            }
-            double cy, cy2, cxy;
-            if (accept_mode) {   // lane i: the running sums after visits 0..i, added one after the other as the sequential scan adds them
-                lds_d[lane * 4 + 0] = dy; lds_d[lane * 4 + 1] = dy2; lds_d[lane * 4 + 2] = dxy;
-                __syncthreads();
-                if (lane < 3) {   // inactive visits staged +0 deltas: their prefixes are never read
-                    const double s0 = lane == 0 ? Sy : (lane == 1 ? Sy2 : Sxy);
-                    if (span == 16) prefix_chain<16>(lds_d, lds_p, lane, s0);   // both fully unrolled: a run-time bound cost more than the short chain saves
-                    else prefix_chain<64>(lds_d, lds_p, lane, s0);
-                }
-                __syncthreads();
-                cy = lds_p[lane * 4 + 0]; cy2 = lds_p[lane * 4 + 1]; cxy = lds_p[lane * 4 + 2];
-                __syncthreads();
-            } else {             // lane i: the running sums plus its own delta
-                cy = Sy + dy; cy2 = Sy2 + dy2; cxy = Sxy + dxy;
-            }
-            bool special = false;
-            const bool good = mae ? cy / n <= thr : pcc_good(n, mean_x, am2, thr, cy, cy2, cxy, special);   // mae: is_good(cab / N) (:293-294)
-            const uint64_t act = below(m);
-            const uint64_t okm = __ballot(good && active) & act, spm = __ballot(special && active) & act;
-            int j, take = -1;
-            if (accept_mode) {
-                const uint64_t rej = ~okm & act;
-                j = rej ? __builtin_ctzll(rej) : m;            // first rejected visit
-                if (spm & below(min(j + 1, 64))) { status = 1; break; }   // a zero denominator among the visits this round settles
-                if (lane < j) map[t] = (int8_t)f;              // accepted (:264-276)
-                if (j > 0) take = j - 1;
-                if (j < m) { if (lane == j) map[t] = (int8_t)(prev | 0x80); k += j + 1; span = 16; if (j == 0) accept_mode = false; }   // fixed (:277-278)
-                else { k += m; span = 64; }
-            } else {
-                j = okm ? __builtin_ctzll(okm) : m;            // first accepted visit
-                if (spm & below(min(j + 1, 64))) { status = 1; break; }
-                if (lane < j) map[t] = (int8_t)(prev | 0x80);
-                if (j < m) { if (lane == j) map[t] = (int8_t)f; take = j; k += j + 1; if (j == 0) { accept_mode = true; span = 16; } }
-                else k += m;
-            }
-            if (take >= 0) { Sy = readlane_f64(cy, take); Sy2 = readlane_f64(cy2, take); Sxy = readlane_f64(cxy, take); }   // take is wave-uniform
-        }
-        mem_wait();
-        stamp(4 + 3 * (p - 1));
-    }
-    mem_wait();
     int per_fmt[MTQ_NUM_TILE_FORMATS] = {0, 0, 0, 0};
     for (int t0 = 0; t0 < T; t0 += 64) {
         const int t = t0 + lane;
@@ -633,34 +782,92 @@ __global__ __launch_bounds__(256) void greedy_atol(ScanArgs a)
     }
 }
 
-__global__ __launch_bounds__(64) void greedy_scan_pcc_lds(ScanArgs a)
+// One block per tensor: wave 0 searches; wave 1 (launched when the tensors share their visiting orders) gathers deltas ahead of it.
+__global__ __launch_bounds__(128) void greedy_scan_pcc_lds(ScanArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     OrderLds ord{reinterpret_cast<uint16_t *>(lds)};
-    if (a.metric == MTQ_METRIC_MAE) scan_tensor<true>(a, ord, blockIdx.x, lds + 2 * ((a.tiles + 7) & ~(int64_t)7), lane);
-    else scan_tensor<false>(a, ord, blockIdx.x, lds + 2 * ((a.tiles + 7) & ~(int64_t)7), lane);
+    if (a.metric == MTQ_METRIC_MAE) scan_tensor<true>(a, ord, blockIdx.x, lds + 2 * ((a.tiles + 7) & ~(int64_t)7), lane, wave, blockDim.x == 128);
+    else scan_tensor<false>(a, ord, blockIdx.x, lds + 2 * ((a.tiles + 7) & ~(int64_t)7), lane, wave, blockDim.x == 128);
 }
 
-__global__ __launch_bounds__(64) void greedy_scan_pcc_global(ScanArgs a)
+__global__ __launch_bounds__(128) void greedy_scan_pcc_global(ScanArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     OrderGlobal ord{a.order_g + (int64_t)blockIdx.x * a.tiles};
-    if (a.metric == MTQ_METRIC_MAE) scan_tensor<true>(a, ord, blockIdx.x, lds, lane);
-    else scan_tensor<false>(a, ord, blockIdx.x, lds, lane);
+    if (a.metric == MTQ_METRIC_MAE) scan_tensor<true>(a, ord, blockIdx.x, lds, lane, wave, blockDim.x == 128);
+    else scan_tensor<false>(a, ord, blockIdx.x, lds, lane, wave, blockDim.x == 128);
 }
 
 constexpr size_t kFixedLds = (64 * 4 + 64 * 4 + 64 * 5) * sizeof(double) + kTagSlots;
 
-// jump-ahead tables A_q = a^q, G_q = 1 + a + … + a^(q−1) (mod 2^128), uploaded once per device
+// The launch's shared orders: block w (one wave) computes order w+1.  Block 0: the base pass's draws, then pass 1's permutation of
+// range(T); block 1: the draws of the base pass and of pass 1, then pass 2's permutation of range(T).
+struct OrdersArgs {
+    uint64_t seed;
+    int64_t tiles;
+    int n_orders;
+    unsigned char *out;
+    const U128 *jump_a, *jump_g;
+};
+
+template <typename Order>
+__device__ void make_order(const OrdersArgs &a, const Order &ord, uint32_t *cnt, uint32_t *P, int which, int lane, bool copy_out)
+{
+    const int T = (int)a.tiles;
+    OrdersHdr *hdr = reinterpret_cast<OrdersHdr *>(a.out);
+    for (int i = lane; i < kTagSlots / 4; i += 64) cnt[i] = 0u;
+    compiler_fence();
+    Rng r;
+    U128 inc;
+    seed_pcg(a.seed, r.state, inc);
+    r.has32 = false;
+    r.u32 = 0u;
+    const int q0 = (lane >> 1) + 1, q1 = lane >= 1 ? ((lane - 1) >> 1) + 1 : 1;
+    r.a0 = a.jump_a[q0]; r.c0 = mul128(a.jump_g[q0], inc);
+    r.a1 = a.jump_a[q1]; r.c1 = mul128(a.jump_g[q1], inc);
+    bool ok = wave_shuffle<false>(r, ord, T, cnt, lane);                 // the base pass's draws
+    if (which == 0 && lane == 0) {
+        hdr->state[0] = r.state; hdr->has32[0] = r.has32 ? 1u : 0u; hdr->u32[0] = r.u32;
+        hdr->inc = inc; hdr->tiles = (uint32_t)T; hdr->n_orders = (uint32_t)a.n_orders; hdr->seed = a.seed;
+    }
+    if (which == 1) ok = wave_shuffle<false>(r, ord, T, cnt, lane) && ok;   // pass 1's draws
+    for (int t = lane; t < T; t += 64) ord.set((uint32_t)t, (uint32_t)t);
+    ord.sync();
+    ok = wave_shuffle<true>(r, ord, T, cnt, lane) && ok;
+    ord.sync();
+    if (copy_out)
+        for (int t = lane; t < T; t += 64) P[t] = ord.get((uint32_t)t);
+    if (lane == 0) {
+        hdr->state[1 + which] = r.state; hdr->has32[1 + which] = r.has32 ? 1u : 0u; hdr->u32[1 + which] = r.u32;
+        hdr->ok[which] = ok ? 1u : 0u;
+    }
+}
+
+__global__ __launch_bounds__(64) void scan_orders(OrdersArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int lane = threadIdx.x, which = blockIdx.x;
+    uint32_t *P = reinterpret_cast<uint32_t *>(a.out + sizeof(OrdersHdr)) + (size_t)which * orders_stride(a.tiles);
+    if (a.tiles <= kScanMaxTilesLds) {
+        OrderLds ord{reinterpret_cast<uint16_t *>(lds)};
+        make_order(a, ord, reinterpret_cast<uint32_t *>(lds + 2 * ((a.tiles + 7) & ~(int64_t)7)), P, which, lane, true);
+    } else {
+        OrderGlobal ord{P};
+        make_order(a, ord, reinterpret_cast<uint32_t *>(lds), P, which, lane, false);
+    }
+}
+
+// jump-ahead tables A_q = a^q, G_q = 1 + a + … + a^(q−1) (mod 2^128), uploaded once per device (freed by mtq_shutdown)
+std::mutex g_jump_mu;
+U128 *g_jump_tab[64] = {nullptr};
 const U128 *jump_tables(int dev)
 {
-    static U128 *tab[64] = {nullptr};
-    static std::mutex mu;
-    std::lock_guard<std::mutex> lock(mu);
+    std::lock_guard<std::mutex> lock(g_jump_mu);
     if (dev < 0 || dev >= 64) return nullptr;
-    if (!tab[dev]) {
+    if (!g_jump_tab[dev]) {
         U128 h[2 * kJump];
         const U128 mult = {kMultLo, kMultHi};
         h[0] = {1ull, 0ull};
@@ -672,15 +879,35 @@ const U128 *jump_tables(int dev)
         U128 *d = nullptr;
         if (hipMalloc(reinterpret_cast<void **>(&d), sizeof(h)) != hipSuccess) return nullptr;
         if (hipMemcpy(d, h, sizeof(h), hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(d); return nullptr; }
-        tab[dev] = d;
+        g_jump_tab[dev] = d;
     }
-    return tab[dev];
+    return g_jump_tab[dev];
+}
+
+std::atomic<bool> g_lds_raised[64][2];   // per device and kernel: the attribute belongs to the function's code object on the current device
+
+int raise_lds(int dev, int which, const void *fn, int bytes)
+{
+    if (dev < 64 && g_lds_raised[dev][which].load(std::memory_order_acquire)) return MTQ_OK;
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) return fail(MTQ_ERR_HIP, "could not raise the dynamic LDS limit");
+    if (dev < 64) g_lds_raised[dev][which].store(true, std::memory_order_release);
+    return MTQ_OK;
 }
 
 } // namespace
 } // namespace mtq
 
 using namespace mtq;
+
+// mtq_shutdown's part of this file: the device tables (no HIP call is ever made from a static destructor)
+void mtq::scan_shutdown()
+{
+    std::lock_guard<std::mutex> lock(g_jump_mu);
+    for (int d = 0; d < 64; ++d) {
+        if (g_jump_tab[d]) { (void)hipFree(g_jump_tab[d]); g_jump_tab[d] = nullptr; }
+        g_lds_raised[d][0].store(false); g_lds_raised[d][1].store(false);
+    }
+}
 
 extern "C" int mtq_debug_scan_ticks(uint64_t out[16])
 {
@@ -695,13 +922,42 @@ extern "C" int mtq_debug_scan_ticks(uint64_t out[16])
 extern "C" size_t mtq_greedy_scan_scratch_bytes(int64_t count, int64_t tiles)
 {
     if (count <= 0 || tiles <= 0) return 0;
-    const size_t per = (size_t)tiles * 4 * sizeof(double) + (tiles > kScanMaxTilesLds ? (size_t)tiles * sizeof(uint32_t) : 0);
+    const size_t per = (size_t)tiles * 8 * sizeof(double) + (tiles > kScanMaxTilesLds ? (size_t)tiles * sizeof(uint32_t) : 0);
     return (size_t)count * ((per + 255) & ~(size_t)255);
 }
 
-extern "C" int mtq_greedy_scan_device(const double *stats, int64_t count, int64_t tiles, uint32_t fmt_mask, const int *formats, int n_formats,
-                                      int metric, double threshold, double elem_count, const uint64_t *seeds, int8_t *maps, int32_t *status,
-                                      int32_t *counts, void *scratch, size_t scratch_bytes, void *stream)
+extern "C" size_t mtq_scan_orders_bytes(int64_t tiles) { return tiles <= 0 ? 0 : sizeof(OrdersHdr) + 2 * orders_stride(tiles) * sizeof(uint32_t); }
+extern "C" size_t mtq_scan_carry_bytes(int64_t count) { return count <= 0 ? 0 : (size_t)count * sizeof(Carry); }
+
+extern "C" int mtq_scan_orders_device(uint64_t seed, int64_t tiles, int n_orders, void *orders, size_t orders_bytes, void *stream)
+{
+    if (!orders) return fail(MTQ_ERR_INVALID, "null argument");
+    if (seed == 0) return fail(MTQ_ERR_INVALID, "seed 0 means 'draw a random seed' in the reference; pass a non-zero seed");
+    if (tiles <= 0 || tiles > MTQ_SCAN_DEVICE_MAX_TILES) return fail(MTQ_ERR_INVALID, "tiles out of range");
+    if (n_orders < 1 || n_orders > 2) return fail(MTQ_ERR_INVALID, "n_orders must be 1 or 2");
+    if (orders_bytes < mtq_scan_orders_bytes(tiles)) return fail(MTQ_ERR_INVALID, "orders is smaller than mtq_scan_orders_bytes()");
+    if (int rc = require_device()) return rc;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return fail(MTQ_ERR_HIP, "hipGetDevice failed");
+    const U128 *jt = jump_tables(dev);
+    if (!jt) return fail(MTQ_ERR_HIP, "could not upload the jump-ahead tables");
+    OrdersArgs a{seed, tiles, n_orders, static_cast<unsigned char *>(orders), jt, jt + kJump};
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    // ok[1] of a one-order buffer must read 0: the header's flags are cleared first (the kernel's two blocks set their own)
+    if (hipMemsetAsync(orders, 0, sizeof(OrdersHdr), st) != hipSuccess) return fail(MTQ_ERR_HIP, "hipMemsetAsync failed");
+    size_t lds = kTagSlots;
+    if (tiles <= kScanMaxTilesLds) {
+        lds += 2 * (size_t)((tiles + 7) & ~(int64_t)7);
+        if (int rc = raise_lds(dev, 1, reinterpret_cast<const void *>(scan_orders), 2 * kScanMaxTilesLds + kTagSlots)) return rc;
+    }
+    hipLaunchKernelGGL(scan_orders, dim3((unsigned)n_orders), dim3(64), lds, st, a);
+    return check_launch("mtq_scan_orders_device");
+}
+
+extern "C" int mtq_greedy_scan_device_ex(const double *stats, int64_t count, int64_t tiles, uint32_t fmt_mask, const int *formats, int n_formats,
+                                         int metric, double threshold, double elem_count, const uint64_t *seeds, int8_t *maps, int32_t *status,
+                                         int32_t *counts, void *scratch, size_t scratch_bytes, const void *orders, int phase, uint32_t *listed,
+                                         uint32_t *n_listed, void *carry, void *stream)
 {
     if (!stats || !formats || !seeds || !maps || !status || !scratch) return fail(MTQ_ERR_INVALID, "null argument");
     if (count <= 0 || count > (1 << 20) || tiles <= 0) return fail(MTQ_ERR_INVALID, "count and tiles must be positive");
@@ -711,6 +967,13 @@ extern "C" int mtq_greedy_scan_device(const double *stats, int64_t count, int64_
     if (fmt_mask & MTQ_MASK_SLIM) return fail(MTQ_ERR_INVALID, "the device scan reads full records");
     if (!(elem_count > 0.0)) return fail(MTQ_ERR_INVALID, "elem_count must be positive");
     if (scratch_bytes < mtq_greedy_scan_scratch_bytes(count, tiles)) return fail(MTQ_ERR_INVALID, "scratch is smaller than mtq_greedy_scan_scratch_bytes()");
+    if (phase < 0 || phase > 2) return fail(MTQ_ERR_INVALID, "phase must be 0, 1 or 2");
+    if (phase != 0) {
+        if (metric == MTQ_METRIC_ATOL) return fail(MTQ_ERR_UNSUPPORTED, "the atol walk has no phases");
+        if (n_formats < 2) return fail(MTQ_ERR_INVALID, "a split search needs at least two formats");
+        if (!carry || (phase == 1 && (!listed || !n_listed))) return fail(MTQ_ERR_INVALID, "a split search needs carry (and listed, n_listed in phase 1)");
+        if (count * tiles >= ((int64_t)1 << 32)) return fail(MTQ_ERR_INVALID, "too many tiles for the list of a split search");
+    }
     ScanArgs a{};
     a.stats = stats;
     a.tiles = tiles;
@@ -736,6 +999,11 @@ extern "C" int mtq_greedy_scan_device(const double *stats, int64_t count, int64_
     a.maps = maps;
     a.status = status;
     a.counts = counts;
+    a.orders = static_cast<const unsigned char *>(orders);
+    a.phase = phase;
+    a.listed = listed;
+    a.n_listed = n_listed;
+    a.carry = static_cast<Carry *>(carry);
     if (int rc = require_device()) return rc;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return fail(MTQ_ERR_HIP, "hipGetDevice failed");
@@ -743,25 +1011,30 @@ extern "C" int mtq_greedy_scan_device(const double *stats, int64_t count, int64_
     if (!jt) return fail(MTQ_ERR_HIP, "could not upload the jump-ahead tables");
     a.jump_a = jt;
     a.jump_g = jt + kJump;
-    // scratch: all deltas first, then (large tensors) all orders
+    // scratch: the deltas of two passes for every tensor first, then (large tensors) all orders
     a.delta = static_cast<double *>(scratch);
-    a.order_g = reinterpret_cast<uint32_t *>(static_cast<unsigned char *>(scratch) + (size_t)count * (size_t)tiles * 4 * sizeof(double));
+    a.delta2 = a.delta + (size_t)count * (size_t)tiles * 4;
+    a.order_g = reinterpret_cast<uint32_t *>(static_cast<unsigned char *>(scratch) + (size_t)count * (size_t)tiles * 8 * sizeof(double));
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (metric == MTQ_METRIC_ATOL) {
         hipLaunchKernelGGL(greedy_atol, dim3((unsigned)count), dim3(256), 0, st, a);
         return check_launch("mtq_greedy_scan_device");
     }
+    const unsigned threads = (orders && phase != 2) ? 128u : 64u;   // a helper wave per tensor when the visiting orders are shared
     if (tiles <= kScanMaxTilesLds) {
         const size_t lds = 2 * (size_t)((tiles + 7) & ~(int64_t)7) + kFixedLds;
-        static std::atomic<bool> raised[64];   // per device: the attribute belongs to the function's code object on the current device
-        if (dev >= 64 || !raised[dev].load(std::memory_order_acquire)) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void *>(greedy_scan_pcc_lds), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kScanMaxTilesLds + (int)kFixedLds) != hipSuccess)
-                return fail(MTQ_ERR_HIP, "could not raise the dynamic LDS limit");
-            if (dev < 64) raised[dev].store(true, std::memory_order_release);
-        }
-        hipLaunchKernelGGL(greedy_scan_pcc_lds, dim3((unsigned)count), dim3(64), lds, st, a);
+        if (int rc = raise_lds(dev, 0, reinterpret_cast<const void *>(greedy_scan_pcc_lds), 2 * kScanMaxTilesLds + (int)kFixedLds)) return rc;
+        hipLaunchKernelGGL(greedy_scan_pcc_lds, dim3((unsigned)count), dim3(threads), lds, st, a);
     } else {
-        hipLaunchKernelGGL(greedy_scan_pcc_global, dim3((unsigned)count), dim3(64), kFixedLds, st, a);
+        hipLaunchKernelGGL(greedy_scan_pcc_global, dim3((unsigned)count), dim3(threads), kFixedLds, st, a);
     }
     return check_launch("mtq_greedy_scan_device");
+}
+
+extern "C" int mtq_greedy_scan_device(const double *stats, int64_t count, int64_t tiles, uint32_t fmt_mask, const int *formats, int n_formats,
+                                      int metric, double threshold, double elem_count, const uint64_t *seeds, int8_t *maps, int32_t *status,
+                                      int32_t *counts, void *scratch, size_t scratch_bytes, void *stream)
+{
+    return mtq_greedy_scan_device_ex(stats, count, tiles, fmt_mask, formats, n_formats, metric, threshold, elem_count, seeds, maps, status, counts,
+                                     scratch, scratch_bytes, nullptr, 0, nullptr, nullptr, nullptr, stream);
 }

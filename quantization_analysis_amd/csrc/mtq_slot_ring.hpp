@@ -17,7 +17,7 @@ namespace mtq {
 template <typename Ops, int N>
 class SlotRing {
 public:
-    // → slot index, or −1 (every slot is held by a thread between acquire and release, or an event call failed)
+    // → slot index, or −1 (every slot is held by a thread between acquire and release, or no slot's event could be waited for)
     int acquire(typename Ops::stream s)
     {
         for (int tries = 0; tries < N; ++tries) {
@@ -25,7 +25,7 @@ public:
             Slot &sl = slots_[i];
             std::lock_guard<std::mutex> lock(sl.mu);
             if (sl.held) continue;                       // another thread is between acquire and release on it
-            if (sl.recorded && !Ops::wait(s, sl.ev)) return -1;
+            if (sl.recorded && !Ops::wait(s, sl.ev)) continue;   // no ordering to be had behind this slot's previous user: try the next one
             sl.held = true;
             return i;
         }
@@ -42,6 +42,25 @@ public:
         sl.recorded = ok;                                // a slot whose event could not be recorded has no ordering to offer
         sl.held = false;
         return ok;
+    }
+
+    // The launch the slot was acquired for never happened (its enqueue failed): give the slot back as it was — whatever its
+    // previous user recorded still orders its next user.
+    void abandon(int i)
+    {
+        Slot &sl = slots_[i];
+        std::lock_guard<std::mutex> lock(sl.mu);
+        sl.held = false;
+    }
+    // mtq_shutdown: every slot back to its fresh state, its event destroyed.  The caller has drained the device.
+    void reset()
+    {
+        for (int i = 0; i < N; ++i) {
+            Slot &sl = slots_[i];
+            std::lock_guard<std::mutex> lock(sl.mu);
+            if (sl.created) Ops::destroy(sl.ev);
+            sl.created = sl.recorded = sl.held = false;
+        }
     }
 
 private:

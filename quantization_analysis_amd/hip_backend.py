@@ -25,13 +25,14 @@ TILE = 32
 # every symbol include/mtq.h declares (tests check the library exports exactly these)
 EXPORTS = [
     "mtq_version", "mtq_last_error", "mtq_device_count", "mtq_stats_record_doubles",
-    "mtq_tile_stats", "mtq_tile_stats_batched", "mtq_quantize", "mtq_apply_assignment", "mtq_dequant_fp8_block", "mtq_pack_slim_records",
+    "mtq_shutdown", "mtq_tile_stats", "mtq_tile_stats_batched", "mtq_tile_stats_partial", "mtq_tile_stats_listed", "mtq_quantize", "mtq_apply_assignment", "mtq_dequant_fp8_block", "mtq_pack_slim_records",
     "mtq_greedy_create", "mtq_greedy_pass", "mtq_greedy_assignment", "mtq_greedy_fixed",
     "mtq_greedy_counts", "mtq_greedy_value", "mtq_greedy_destroy",
     "mtq_greedy_run_chain", "mtq_greedy_run_chain_batch", "mtq_pack_chain_records", "mtq_tile_scores", "mtq_threshold_assign", "mtq_columns_from_stats", "mtq_columns_from_sums", "mtq_tile_scores_device",
     "mtq_threshold_assign_device", "mtq_columns_scratch_doubles", "mtq_column_sums_device", "mtq_column_sums_device_batched",
     "mtq_rng_create", "mtq_rng_permutation", "mtq_rng_integers", "mtq_rng_destroy", "mtq_greedy_run", "mtq_greedy_run_batch",
-    "mtq_selftest_slot_ring", "mtq_device_copy_2d", "mtq_greedy_scan_scratch_bytes", "mtq_greedy_scan_device", "mtq_debug_scan_ticks",
+    "mtq_selftest_slot_ring", "mtq_device_copy_2d", "mtq_greedy_scan_scratch_bytes", "mtq_greedy_scan_device", "mtq_greedy_scan_device_ex", "mtq_scan_carry_bytes",
+    "mtq_scan_orders_bytes", "mtq_scan_orders_device", "mtq_debug_scan_ticks",
 ]
 
 
@@ -75,6 +76,7 @@ def lib() -> ctypes.CDLL:
     L.mtq_stats_record_doubles.restype = ctypes.c_size_t
     L.mtq_tile_stats.argtypes = [vp, ci, i64, i64, i64, u32, vp, vp]
     L.mtq_tile_stats_batched.argtypes = [vp, ci, i64, i64, i64, i64, i64, u32, vp, vp]
+    L.mtq_tile_stats_partial.argtypes = [vp, ci, i64, i64, i64, i64, i64, u32, u32, u32, vp, vp]
     L.mtq_quantize.argtypes = [vp, ci, i64, i64, i64, ci, vp, i64, vp]
     L.mtq_apply_assignment.argtypes = [vp, ci, i64, i64, i64, vp, vp, i64, vp]
     L.mtq_dequant_fp8_block.argtypes = [vp, vp, i64, i64, i64, i64, i64, vp, i64, vp]
@@ -110,12 +112,32 @@ def lib() -> ctypes.CDLL:
     L.mtq_greedy_scan_scratch_bytes.argtypes = [i64, i64]
     L.mtq_greedy_scan_scratch_bytes.restype = ctypes.c_size_t
     L.mtq_greedy_scan_device.argtypes = [vp, i64, i64, u32, vp, ci, ci, dbl, dbl, vp, vp, vp, vp, vp, ctypes.c_size_t, vp]
+    L.mtq_greedy_scan_device_ex.argtypes = [vp, i64, i64, u32, vp, ci, ci, dbl, dbl, vp, vp, vp, vp, vp, ctypes.c_size_t, vp, ci, vp, vp, vp, vp]
+    L.mtq_scan_carry_bytes.argtypes = [i64]
+    L.mtq_scan_carry_bytes.restype = ctypes.c_size_t
+    L.mtq_scan_orders_bytes.argtypes = [i64]
+    L.mtq_scan_orders_bytes.restype = ctypes.c_size_t
+    L.mtq_scan_orders_device.argtypes = [ctypes.c_uint64, i64, ci, vp, ctypes.c_size_t, vp]
+    L.mtq_tile_stats_listed.argtypes = [vp, ci, i64, i64, i64, i64, i64, u32, u32, u32, vp, vp, i64, vp, vp]
+    L.mtq_shutdown.restype = ci
     L.mtq_selftest_slot_ring.restype = ci
     L.mtq_device_copy_2d.argtypes = [vp, ctypes.c_size_t, vp, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_size_t, vp]
-    if L.mtq_version() < 130:
+    if L.mtq_version() < 140:
         raise MtqError("libmtq_hip.so is older than this package")
     _lib = L
+    # torch registered its exit hooks when it was imported above; a hook registered now runs BEFORE them: the library's threads,
+    # events and device tables are released while the HIP runtime is still there (mtq_shutdown; nothing is left to static destructors)
+    import atexit
+
+    atexit.register(shutdown)
     return L
+
+
+def shutdown() -> None:
+    """mtq_shutdown: joins the scan threads, drains the devices the library used and frees its device tables and events.  Idempotent;
+    registered with atexit by lib().  The library sets itself up again if it is used afterwards."""
+    if _lib is not None:
+        _lib.mtq_shutdown()
 
 
 def check(rc: int) -> None:
@@ -291,6 +313,22 @@ def tile_stats_batched(x3d, mask: int, out=None):
     if out is None:
         out = torch.empty((count, th * tw, rec), dtype=torch.float64, device=x3d.device)
     check(lib().mtq_tile_stats_batched(x3d.data_ptr(), _dtype_code(x3d), count, rows * cols, rows, cols, cols, mask,
+                                       out.data_ptr(), _stream_ptr()))
+    return out
+
+
+def tile_stats_partial(x3d, layout_mask: int, full_mask: int, sums_mask: int, out=None):
+    """K1 over a (count, rows, cols) device tensor with only part of every record promised (mtq_tile_stats_partial): the five statistics of
+    the formats in full_mask, Σy, Σy², Σxy of those in sums_mask; the rest of the layout is unspecified → [count, tiles, rec(layout)]."""
+    torch = _torch()
+    require_gpu()
+    if x3d.dim() != 3 or not x3d.is_cuda or not x3d.is_contiguous():
+        raise MtqError("expected a contiguous (count, rows, cols) device tensor")
+    count, rows, cols = x3d.shape
+    th, tw = tiles_hw(rows, cols)
+    if out is None:
+        out = torch.empty((count, th * tw, record_doubles(layout_mask)), dtype=torch.float64, device=x3d.device)
+    check(lib().mtq_tile_stats_partial(x3d.data_ptr(), _dtype_code(x3d), count, rows * cols, rows, cols, cols, layout_mask, full_mask, sums_mask,
                                        out.data_ptr(), _stream_ptr()))
     return out
 
@@ -477,12 +515,57 @@ def greedy_scan_device(stats_dev, mask: int, formats, metric: str, threshold: fl
     maps = maps_out if maps_out is not None else torch.empty((count, T), dtype=torch.int8, device=stats_dev.device)
     status = status_out if status_out is not None else torch.empty((count,), dtype=torch.int32, device=stats_dev.device)
     need = int(lib().mtq_greedy_scan_scratch_bytes(count, T))
-    if scratch is None or scratch.numel() < need:
+    if scratch is None:
         scratch = torch.empty((need,), dtype=torch.uint8, device=stats_dev.device)
+    elif scratch.numel() < need:   # a caller's slicing bug must not turn into a device allocation per call
+        raise ValueError(f"scratch holds {scratch.numel()} bytes, mtq_greedy_scan_scratch_bytes() asks for {need}")
     check(lib().mtq_greedy_scan_device(stats_dev.data_ptr(), count, T, mask, fm, len(formats), METRIC_CODE[metric], float(threshold),
                                        float(elem_count), seeds_dev.data_ptr(), maps.data_ptr(), status.data_ptr(),
                                        counts_out.data_ptr() if counts_out is not None else None, scratch.data_ptr(), int(scratch.numel()), _stream_ptr()))
     return maps, status
+
+
+def scan_orders_device(seed: int, tiles: int, n_orders: int = 2, out=None):
+    """The visiting orders every tensor of a launch shares (mtq_scan_orders_device): generator states and the permutations of
+    range(tiles) of passes 1 (and 2) for `seed` → uint8 device buffer, asynchronous on the current stream."""
+    torch = _torch()
+    require_gpu()
+    need = int(lib().mtq_scan_orders_bytes(int(tiles)))
+    if out is None:
+        out = torch.empty((need,), dtype=torch.uint8, device="cuda")
+    elif out.numel() < need:
+        raise ValueError("orders buffer is smaller than mtq_scan_orders_bytes()")
+    check(lib().mtq_scan_orders_device(int(seed), int(tiles), int(n_orders), out.data_ptr(), int(out.numel()), _stream_ptr()))
+    return out
+
+
+def greedy_scan_device_ex(stats_dev, mask: int, formats, metric: str, threshold: float, elem_count: float, seeds_dev, maps_out, status_out,
+                          scratch, counts_out=None, orders=None, phase: int = 0, listed=None, n_listed=None, carry=None) -> None:
+    """mtq_greedy_scan_device_ex: the device search with shared visiting orders (orders: scan_orders_device's buffer for the seed all
+    tensors share) and / or in phases (1: every pass but the last + the last pass's candidates → listed / n_listed, state → carry;
+    2: the last pass).  Caller-owned buffers throughout; scratch must hold mtq_greedy_scan_scratch_bytes(count, tiles) bytes."""
+    count, T = int(stats_dev.shape[0]), int(stats_dev.shape[1])
+    need = int(lib().mtq_greedy_scan_scratch_bytes(count, T))
+    if scratch.numel() < need:
+        raise ValueError("scratch is smaller than mtq_greedy_scan_scratch_bytes()")
+    fm = (ctypes.c_int * len(formats))(*[MIXED_TILE_FORMATS.index(f) for f in formats])
+    check(lib().mtq_greedy_scan_device_ex(stats_dev.data_ptr(), count, T, mask, fm, len(formats), METRIC_CODE[metric], float(threshold), float(elem_count),
+                                          seeds_dev.data_ptr(), maps_out.data_ptr(), status_out.data_ptr(),
+                                          counts_out.data_ptr() if counts_out is not None else None, scratch.data_ptr(), int(scratch.numel()),
+                                          orders.data_ptr() if orders is not None else None, int(phase),
+                                          listed.data_ptr() if listed is not None else None, n_listed.data_ptr() if n_listed is not None else None,
+                                          carry.data_ptr() if carry is not None else None, _stream_ptr()))
+
+
+def tile_stats_listed(x3d, layout_mask: int, full_mask: int, err_mask: int, listed, n_listed, stats) -> None:
+    """mtq_tile_stats_listed: for the tiles listed[0 .. n_listed[0]) (device uint32 / int32 tensors; entries tensor * tiles + tile) the five
+    statistics of full_mask's formats and Σ|x−y|, max|x−y| of err_mask's, into stats [count, tiles, rec(layout)] in place."""
+    require_gpu()
+    if x3d.dim() != 3 or not x3d.is_cuda or not x3d.is_contiguous():
+        raise MtqError("expected a contiguous (count, rows, cols) device tensor")
+    count, rows, cols = x3d.shape
+    check(lib().mtq_tile_stats_listed(x3d.data_ptr(), _dtype_code(x3d), count, rows * cols, rows, cols, cols, layout_mask, full_mask, err_mask,
+                                      listed.data_ptr(), n_listed.data_ptr(), int(listed.numel()), stats.data_ptr(), _stream_ptr()))
 
 
 def greedy_run_batch(stats: np.ndarray, mask: int, formats, metric: str, threshold: float, elem_count: float, seeds, n_threads: int):
