@@ -121,12 +121,14 @@ int mtq_tile_stats_partial(const void *x, int in_dtype, int64_t count, int64_t s
  * K1 for a list of tiles: what mtq_tile_stats_partial left out, for the tiles that turn out to need it.  listed[0 .. *n_listed) (device;
  * at most `capacity` entries are read) names tiles as tensor * tiles + tile; for each of them the five statistics of the formats in
  * full_mask and Σ|x−y|, max|x−y| of those in err_mask are written into the tile's record (layout `layout_mask`), bit for bit what
- * mtq_tile_stats writes there; nothing else of the record is touched.  BFP formats only.  The list comes from phase 1 of a split search
+ * mtq_tile_stats writes there; nothing else of the record is touched.  BFP formats only.  scratch: device memory of capacity + 1 uint32
+ * (bf16 storage goes through the exact-integer kernel, four listed tiles per wave, and parks the few tiles that kernel cannot take
+ * there for the one-wave-per-tile kernel), or NULL (every tile through the one-wave-per-tile kernel).  The list comes from phase 1 of a split search
  * (mtq_greedy_scan_device_ex), which is the only reader of these statistics before the map is final.
  */
 int mtq_tile_stats_listed(const void *x, int in_dtype, int64_t count, int64_t stride_elems, int64_t rows, int64_t cols, int64_t ld,
                           uint32_t layout_mask, uint32_t full_mask, uint32_t err_mask, const uint32_t *listed, const uint32_t *n_listed,
-                          int64_t capacity, double *stats, void *stream);
+                          int64_t capacity, uint32_t *scratch, double *stats, void *stream);
 
 /*
  * K2 quantize — materialise y = quantize→dequantize(x) for one format as float32.

@@ -449,10 +449,16 @@ extern "C" int mtq_launch_tile_stats_direct(const void *x, int in_dtype, int64_t
     return check_launch("mtq_tile_stats (direct)");
 }
 
-// mtq_tile_stats_listed (include/mtq.h): argument checks here, the kernel above.
+extern "C" int mtq_launch_tile_stats_bf16_listed(const void *x, int64_t count, int64_t stride_elems, int64_t rows, int64_t cols, int64_t ld,
+                                                 uint32_t fmt_mask, uint32_t full_mask, uint32_t err_mask, const uint32_t *list, const uint32_t *n_list,
+                                                 uint32_t cap, uint32_t *redo, uint32_t *n_redo, double *stats, void *stream);
+
+// mtq_tile_stats_listed (include/mtq.h): argument checks here.  bf16 storage with 16-byte aligned rows and the mask pairs the streamed
+// search produces go through the exact-integer kernel of mtq_fast.hip (four listed tiles per wave unit), which hands the tiles it cannot
+// take to the kernel above through `scratch`; everything else goes through the kernel above directly.
 extern "C" int mtq_tile_stats_listed(const void *x, int in_dtype, int64_t count, int64_t stride_elems, int64_t rows, int64_t cols, int64_t ld,
                                      uint32_t layout_mask, uint32_t full_mask, uint32_t err_mask, const uint32_t *listed, const uint32_t *n_listed,
-                                     int64_t capacity, double *stats, void *stream)
+                                     int64_t capacity, uint32_t *scratch, double *stats, void *stream)
 {
     if (!x || !listed || !n_listed || !stats) return fail(MTQ_ERR_INVALID, "null argument");
     if (in_dtype != MTQ_DTYPE_BF16 && in_dtype != MTQ_DTYPE_F32) return fail(MTQ_ERR_INVALID, "unknown input dtype");
@@ -488,6 +494,14 @@ extern "C" int mtq_tile_stats_listed(const void *x, int in_dtype, int64_t count,
     const dim3 grid((unsigned)(need < max_blocks ? need : max_blocks));
     hipStream_t st = static_cast<hipStream_t>(stream);
     const uint32_t cap = (uint32_t)(capacity < (int64_t)UINT32_MAX ? capacity : (int64_t)UINT32_MAX);
+    if (in_dtype == MTQ_DTYPE_BF16 && vec_ok && scratch && getenv("MTQ_LISTED_DIRECT") == nullptr) {
+        // scratch[0]: the redo list's length, scratch[1..]: the list
+        if (hipMemsetAsync(scratch, 0, sizeof(uint32_t), st) != hipSuccess) return fail(MTQ_ERR_HIP, "hipMemsetAsync failed");
+        const int rc = mtq_launch_tile_stats_bf16_listed(x, count, stride_elems, rows, cols, ld, layout_mask, full_mask, err_mask, listed, n_listed, cap,
+                                                         scratch + 1, scratch, stats, stream);
+        if (rc < 0) return rc;
+        if (rc == 0) { listed = scratch + 1; n_listed = scratch; }   // what is left for the kernel above: the tiles the exact route handed back
+    }
     if (in_dtype == MTQ_DTYPE_BF16)
         launch_listed<uint16_t>(fm, grid, st, static_cast<const uint16_t *>(x), stride_elems, rows, cols, ld, (uint32_t)tw, (uint32_t)tiles, listed,
                                 n_listed, cap, stats, vec_ok, rec, obase, wmask);

@@ -64,34 +64,33 @@ constexpr int kRecDoubles = kUnitTiles * (2 + 5 * kNumFmt);             // 4 rec
 // ds_read_b128 is serviced in ({0-3,12-15,20-27}, ...; MI355X_MICROARCH.md §LDS).
 __device__ __forceinline__ uint32_t swz(uint32_t j) { return (((j >> 2) ^ (j >> 3)) & 1u) | ((j & 3u) << 1) | (j & 8u); }
 
-struct Fmt8 { static constexpr uint32_t sh = 8, half = 0x007F007Fu, keep = 0xFF00FF00u, sat = 0x7F007F00u; static constexpr bool d2 = true, onebit = false; };
-struct Fmt4 { static constexpr uint32_t sh = 12, half = 0x07FF07FFu, keep = 0xF000F000u, sat = 0x70007000u; static constexpr bool d2 = false, onebit = false; };
-struct Fmt2 { static constexpr uint32_t sh = 14, half = 0x1FFF1FFFu, keep = 0xC000C000u, sat = 0x40004000u; static constexpr bool d2 = false, onebit = true; };
+struct Fmt8 { static constexpr uint32_t sh = 8, half = 0x007F007Fu, keep = 0xFF00FF00u, sat = 0x7F007F00u; static constexpr bool onebit = false; };
+struct Fmt4 { static constexpr uint32_t sh = 12, half = 0x07FF07FFu, keep = 0xF000F000u, sat = 0x70007000u; static constexpr bool onebit = false; };
+struct Fmt2 { static constexpr uint32_t sh = 14, half = 0x1FFF1FFFu, keep = 0xC000C000u, sat = 0x40004000u; static constexpr bool onebit = true; };
 
 struct FmtAcc {           // integer group sums of one BFP format
     int ssy;              // Σ ±y
     uint32_t sq2, saq, sad;
-    int sd2;              // Σ (a − y)²  (bfp8 only: gives Σa² without a 64-bit accumulation, see fast_group)
     uint32_t dmax, dmin;  // packed running max / min of (a − y) + 0x8000 (unsigned halves)
 };
 
-template <typename F, bool kErr>
+// One element pair of one BFP format.  kSum: Σy, Σy², Σxy (what the greedy search reads of a format); kErr: Σ|x−y|, max|x−y| (what a
+// map's mae / atol columns, the mae / atol searches and the threshold rule read).
+template <typename F, bool kSum, bool kErr>
 __device__ __forceinline__ void fmt_step(uint32_t a, uint32_t abias, uint32_t sgn, FmtAcc &A)
 {
     // RNE of `a` to a multiple of G = 2^sh, saturating at (2^mb − 1)·G (quantization_formats.py:133-141)
     const uint32_t lsb = (a >> F::sh) & 0x00010001u;
     const uint32_t t = a + F::half + lsb;                       // no carry between the halves (max 0x9F80)
     const uint32_t y = as_u32(__builtin_elementwise_min(as_us2(t & F::keep), as_us2(F::sat)));
-    const uint32_t q = y >> F::sh;                              // low sh bits of each half are zero: no cross-talk
-    A.ssy = __builtin_amdgcn_sdot2(as_s2(y), as_s2(sgn), A.ssy, false);
-    if constexpr (F::onebit) A.sq2 += q;   // q ∈ {0,1}: Σq² = Σq, kept as two packed 16-bit counters (≤ 8 each), folded at the end
-    else A.sq2 = __builtin_amdgcn_udot2(as_us2(q), as_us2(q), A.sq2, false);
-    A.saq = __builtin_amdgcn_udot2(as_us2(a), as_us2(q), A.saq, false);
-    if constexpr (F::d2) { // δ = a − y ∈ [−128, 128] as signed halves
-        const s2 dl = as_s2(a) - as_s2(y);
-        A.sd2 = __builtin_amdgcn_sdot2(dl, dl, A.sd2, false);
+    if constexpr (kSum) {
+        const uint32_t q = y >> F::sh;                          // low sh bits of each half are zero: no cross-talk
+        A.ssy = __builtin_amdgcn_sdot2(as_s2(y), as_s2(sgn), A.ssy, false);
+        if constexpr (F::onebit) A.sq2 += q;   // q ∈ {0,1}: Σq² = Σq, kept as two packed 16-bit counters (≤ 8 each), folded at the end
+        else A.sq2 = __builtin_amdgcn_udot2(as_us2(q), as_us2(q), A.sq2, false);
+        A.saq = __builtin_amdgcn_udot2(as_us2(a), as_us2(q), A.saq, false);
     }
-    if constexpr (kErr) {  // Σ|x−y| and max|x−y|: left out for a format whose record slot only carries Σy, Σy², Σxy (PART)
+    if constexpr (kErr) {
         A.sad = __builtin_amdgcn_sad_u16(a, y, A.sad);
         // a − y per half, biased by 0x8000 so that one 32-bit subtract serves both halves (no borrow: a|0x8000 ≥ y)
         const uint32_t db = abias - y;
@@ -112,8 +111,6 @@ __device__ __forceinline__ uint32_t fmt_maxabs(const FmtAcc &A)
 // asm; the compiler then put an `s_nop 0` — four issue cycles — behind each of the three per element pair.)
 __device__ __forceinline__ uint32_t pk_lshr(uint32_t v, uint32_t sh) { return as_u32(as_us2(v) >> as_us2(sh)); }
 
-__device__ __forceinline__ double pow2_f64(uint32_t biased_hi) { return __hiloint2double((int)biased_hi, 0); }
-
 // Per-group result handed to the tree: the 14 float64 terms of the group and its 3 float32 maxima.
 struct GroupOut {
     double term[kSums];
@@ -121,11 +118,38 @@ struct GroupOut {
     bool bad;   // outside the exact route's preconditions: the tile is redone by the literal fix-up kernel
 };
 
-// BFP: the BFP formats evaluated (bit 0 bfp8, 1 bfp4, 2 bfp2); PART ⊂ BFP: those of them whose slot only gets Σy, Σy², Σxy
-// (mtq_tile_stats_partial: the greedy search needs nothing else of a format until a tile ends up in it).
-template <uint32_t BFP, uint32_t PART, typename Reload>
+// What an instantiation evaluates (bit 0 bfp8, 1 bfp4, 2 bfp2).  SUMS: formats whose Σy, Σy², Σxy are formed; ERRS: formats whose
+// Σ|x−y|, max|x−y| are; XS: Σx, Σx² too.  The 14 group terms in record order: Σx, Σx², then per format Σy, Σy², Σxy, Σ|x−y|.
+//   mtq_tile_stats (bf16 storage, mask 0xE): SUMS = ERRS = 7, XS;   mtq_tile_stats_partial of the streamed greedy search: SUMS 3, ERRS 1, XS;
+//   mtq_tile_stats_listed behind it: SUMS 4, ERRS 6, no XS.
+__host__ __device__ constexpr bool term_needed(uint32_t sums, uint32_t errs, bool xs, int s)
+{
+    return s < 2 ? xs : ((((s - 2) & 3) < 3 ? sums : errs) >> ((s - 2) >> 2)) & 1u;
+}
+__host__ __device__ constexpr int terms_needed(uint32_t sums, uint32_t errs, bool xs)
+{
+    int n = 0;
+    for (int s = 0; s < kSums; ++s) n += term_needed(sums, errs, xs, s) ? 1 : 0;
+    return n;
+}
+__host__ __device__ constexpr int term_at(uint32_t sums, uint32_t errs, bool xs, int i)
+{
+    int n = 0;
+    for (int s = 0; s < kSums; ++s) {
+        if (!term_needed(sums, errs, xs, s)) continue;
+        if (n == i) return s;
+        ++n;
+    }
+    return 0;
+}
+// One reduce pass takes up to 13 statistics (4 tiles × n × 17 doubles of scratch + the record image inside the 8 KiB input image)
+constexpr int kOnePassMax = 13;
+
+template <uint32_t SUMS, uint32_t ERRS, bool XS, typename Reload>
 __device__ __forceinline__ void fast_group(const uint32_t w[8], GroupOut &G, Reload reload)
 {
+    constexpr uint32_t ANY = SUMS | ERRS;
+    constexpr bool need_sgn = XS || SUMS != 0u, need_b = XS || ERRS != 0u;
     uint32_t ab[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) ab[i] = w[i] & 0x7FFF7FFFu;
@@ -136,8 +160,9 @@ __device__ __forceinline__ void fast_group(const uint32_t w[8], GroupOut &G, Rel
     const uint32_t Ep = E | (E << 16);
 
     int sxa = 0, sxb = 0;
-    uint32_t sb2 = 0u, sbs = 0u, bmaxp = 0u, dor = 0u;
-    FmtAcc A8 = {0, 0u, 0u, 0u, 0, 0x80008000u, 0x80008000u}, A4 = A8, A2 = A8; // biased extremes start at δ = 0: a phantom zero never changes max |δ|
+    uint32_t sb2 = 0u, sbs = 0u, bmaxp = 0u, dor = 0u, sa2c = 0u;
+    uint64_t sa2 = 0ull;
+    FmtAcc A8 = {0, 0u, 0u, 0u, 0x80008000u, 0x80008000u}, A4 = A8, A2 = A8; // biased extremes start at δ = 0: a phantom zero never changes max |δ|
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const uint32_t e = pk_lshr(ab[i], 0x00070007u);          // per-half exponent field (the sign bits are already cleared)
@@ -145,18 +170,25 @@ __device__ __forceinline__ void fast_group(const uint32_t w[8], GroupOut &G, Rel
         dor |= d + 0x00010001u;                                 // bit 4 of a half set ⇔ that element is in the tail class
         const uint32_t m = (ab[i] & 0x007F007Fu) | 0x00800080u;
         const uint32_t a = as_u32(as_us2(m) * as_us2(pk_lshr(0x00800080u, d)));                 // m·2^(7−d), 0 for d ≥ 8
-        const uint32_t b = as_u32(as_us2(m) * as_us2(pk_lshr(0x40004000u, d) & 0x007F007Fu));   // m·2^(14−d), 8 ≤ d ≤ 14
-        const uint32_t sgn = as_u32(as_s2(w[i]) >> (short)15) | 0x00010001u;                   // ±1 per half
-        sxa = __builtin_amdgcn_sdot2(as_s2(a), as_s2(sgn), sxa, false);
-        sxb = __builtin_amdgcn_sdot2(as_s2(b), as_s2(sgn), sxb, false);
-        sb2 = __builtin_amdgcn_udot2(as_us2(b), as_us2(b), sb2, false);                        // b ≤ 0x3FC0: 16 squares fit
-        sbs = __builtin_amdgcn_udot2(as_us2(b), as_us2(0x00010001u), sbs, false);
-        bmaxp = as_u32(__builtin_elementwise_max(as_us2(bmaxp), as_us2(b)));
+        uint32_t b = 0u, sgn = 0u;
+        if constexpr (need_b) b = as_u32(as_us2(m) * as_us2(pk_lshr(0x40004000u, d) & 0x007F007Fu));   // m·2^(14−d), 8 ≤ d ≤ 14
+        if constexpr (need_sgn) sgn = as_u32(as_s2(w[i]) >> (short)15) | 0x00010001u;                  // ±1 per half
+        if constexpr (XS) {
+            sxa = __builtin_amdgcn_sdot2(as_s2(a), as_s2(sgn), sxa, false);
+            sxb = __builtin_amdgcn_sdot2(as_s2(b), as_s2(sgn), sxb, false);
+            sb2 = __builtin_amdgcn_udot2(as_us2(b), as_us2(b), sb2, false);                    // b ≤ 0x3FC0: 16 squares fit
+            // Σa²: four squares (a ≤ 0x7F80) fit 32 bits; every second pair the chunk moves to the 64-bit sum
+            sa2c = __builtin_amdgcn_udot2(as_us2(a), as_us2(a), (i & 1) ? sa2c : 0u, false);
+            if (i & 1) sa2 += sa2c;
+        }
+        if constexpr (ERRS != 0u) {
+            sbs = __builtin_amdgcn_udot2(as_us2(b), as_us2(0x00010001u), sbs, false);
+            bmaxp = as_u32(__builtin_elementwise_max(as_us2(bmaxp), as_us2(b)));
+        }
         const uint32_t abias = a | 0x80008000u;
-        // bfp8 also carries Σa² (see below), so it is evaluated for every mask; bfp4 / bfp2 only when requested
-        fmt_step<Fmt8, (BFP & 1u) != 0 && !(PART & 1u)>(a, abias, sgn, A8);
-        if constexpr (BFP & 2u) fmt_step<Fmt4, !(PART & 2u)>(a, abias, sgn, A4);
-        if constexpr (BFP & 4u) fmt_step<Fmt2, !(PART & 4u)>(a, abias, sgn, A2);
+        if constexpr (ANY & 1u) fmt_step<Fmt8, (SUMS & 1u) != 0, (ERRS & 1u) != 0>(a, abias, sgn, A8);
+        if constexpr (ANY & 2u) fmt_step<Fmt4, (SUMS & 2u) != 0, (ERRS & 2u) != 0>(a, abias, sgn, A4);
+        if constexpr (ANY & 4u) fmt_step<Fmt2, (SUMS & 4u) != 0, (ERRS & 4u) != 0>(a, abias, sgn, A2);
     }
     // exact route needs every float32 term normal and finite: E in [80, 180]; anything else marks the tile — except an
     // all-zero group (pruned weights, padding), which contributes nothing: its (garbage) integers are scaled by
@@ -166,27 +198,29 @@ __device__ __forceinline__ void fast_group(const uint32_t w[8], GroupOut &G, Rel
     const uint32_t bmax = max(bmaxp & 0xFFFFu, bmaxp >> 16);
     const int Ei = zero_group ? -3000 : (int)E;
     const int e1 = Ei - 148, e2 = 2 * Ei - 296;                 // 2^(E−148), 2^(2E−296)
-    G.term[0] = __builtin_ldexp((double)(sxa * 128 + sxb), e1);
-    // Σa² without 64-bit accumulation: a = y8 + δ8 with y8 = 256·q8, so Σa² = 512·Σa·q8 − 65536·Σq8² + Σδ8² (all exact in float64)
-    const double a2 = __builtin_fma(512.0, (double)A8.saq, __builtin_fma(-65536.0, (double)A8.sq2, (double)A8.sd2)); // < 2^35
-    G.term[1] = __builtin_ldexp(__builtin_fma(a2, 16384.0, (double)sb2), e2);                  // exact (< 2^49)
+    if constexpr (XS) {
+        G.term[0] = __builtin_ldexp((double)(sxa * 128 + sxb), e1);
+        G.term[1] = __builtin_ldexp(__builtin_fma((double)sa2, 16384.0, (double)sb2), e2);          // exact (< 2^49)
+    } else {
+        G.term[0] = G.term[1] = 0.0;
+    }
     const float sf = zero_group ? 0.0f : __uint_as_float(((E - 21u) & 0xFFu) << 23); // 2^(E−148) as float32 (masked: garbage-safe when bad)
     const FmtAcc *A[3] = {&A8, &A4, &A2};
     const int mbs[3] = {7, 3, 1};
 #pragma unroll
     for (int f = 0; f < 3; ++f) {
-        if (!(BFP & (1u << f))) { // format not requested: its record slot is not written
-            G.term[2 + 4 * f] = G.term[3 + 4 * f] = G.term[4 + 4 * f] = G.term[5 + 4 * f] = 0.0;
-            G.mx[f] = 0.0f;
-            continue;
+        G.term[2 + 4 * f] = G.term[3 + 4 * f] = G.term[4 + 4 * f] = G.term[5 + 4 * f] = 0.0;
+        G.mx[f] = 0.0f;
+        if (SUMS & (1u << f)) {
+            G.term[2 + 4 * f] = __builtin_ldexp((double)A[f]->ssy, e1 + 7);                       // Σ±y · 2^(E−141)
+            const uint32_t sq2 = f == 2 ? (A[f]->sq2 & 0xFFFFu) + (A[f]->sq2 >> 16) : A[f]->sq2;
+            G.term[3 + 4 * f] = __builtin_ldexp((double)sq2, 2 * (Ei - 126 - mbs[f]));            // Σq² · 2^(2(E−126−mb))
+            G.term[4 + 4 * f] = __builtin_ldexp((double)A[f]->saq, 2 * Ei - 267 - mbs[f]);        // Σa·q · 2^(2E−267−mb)
         }
-        G.term[2 + 4 * f] = __builtin_ldexp((double)A[f]->ssy, e1 + 7);                       // Σ±y · 2^(E−141)
-        const uint32_t sq2 = f == 2 ? (A[f]->sq2 & 0xFFFFu) + (A[f]->sq2 >> 16) : A[f]->sq2;
-        G.term[3 + 4 * f] = __builtin_ldexp((double)sq2, 2 * (Ei - 126 - mbs[f]));            // Σq² · 2^(2(E−126−mb))
-        G.term[4 + 4 * f] = __builtin_ldexp((double)A[f]->saq, 2 * Ei - 267 - mbs[f]);        // Σa·q · 2^(2E−267−mb)
-        if (PART & (1u << f)) { G.term[5 + 4 * f] = 0.0; G.mx[f] = 0.0f; continue; }
-        G.term[5 + 4 * f] = __builtin_ldexp((double)((A[f]->sad << 7) + sbs), e1);            // (128·Σ|a−y| + Σb) · 2^(E−148)
-        G.mx[f] = (float)max(fmt_maxabs(*A[f]) << 7, bmax) * sf; // integer < 2^23: exact
+        if (ERRS & (1u << f)) {
+            G.term[5 + 4 * f] = __builtin_ldexp((double)((A[f]->sad << 7) + sbs), e1);            // (128·Σ|a−y| + Σb) · 2^(E−148)
+            G.mx[f] = (float)max(fmt_maxabs(*A[f]) << 7, bmax) * sf; // integer < 2^23: exact
+        }
     }
     // tail class (more than 14 binades below the maximum; y = 0 in every BFP format): summed separately in
     // index order and added once — S = S_main + S_tail (include/mtq.h).  Zeros contribute nothing and are skipped.
@@ -208,77 +242,64 @@ __device__ __forceinline__ void fast_group(const uint32_t w[8], GroupOut &G, Rel
                 tx += (double)xv; tx2 += (double)p; tab += (double)av; tmx = fmaxf(tmx, av);
             }
         }
-        G.term[0] += tx;
-        G.term[1] += tx2;
+        if constexpr (XS) { G.term[0] += tx; G.term[1] += tx2; }
 #pragma unroll
         for (int f = 0; f < 3; ++f) {
-            if (!(BFP & (1u << f)) || (PART & (1u << f))) continue;
+            if (!(ERRS & (1u << f))) continue;
             G.term[5 + 4 * f] += tab; G.mx[f] = fmaxf(G.mx[f], tmx);
         }
     }
 }
 
-// Which of the 14 group terms an instantiation produces, in ascending order (compile-time): Σx, Σx², then per evaluated
-// format Σy, Σy², Σxy and — unless the format is partial — Σ|x−y|.
-__host__ __device__ constexpr bool term_needed(uint32_t bfp, uint32_t part, int s)
-{
-    return s < 2 || (((bfp >> ((s - 2) >> 2)) & 1u) && (((s - 2) & 3) < 3 || !((part >> ((s - 2) >> 2)) & 1u)));
-}
-__host__ __device__ constexpr int terms_needed(uint32_t bfp, uint32_t part)
-{
-    int n = 0;
-    for (int s = 0; s < kSums; ++s) n += term_needed(bfp, part, s) ? 1 : 0;
-    return n;
-}
-__host__ __device__ constexpr int term_at(uint32_t bfp, uint32_t part, int i)
-{
-    int n = 0;
-    for (int s = 0; s < kSums; ++s) {
-        if (!term_needed(bfp, part, s)) continue;
-        if (n == i) return s;
-        ++n;
-    }
-    return 0;
-}
-// One reduce pass takes up to 13 statistics (4 tiles × n × 17 doubles of scratch + the record image inside the 8 KiB input image)
-constexpr int kOnePassMax = 13;
-
 // ---------------------------------------------------------------------------------------------
 // The kernel.  The 4 groups of a lane run in a ROLLED loop that reads each group from the LDS image just
 // before use (a fully unrolled, software-pipelined form needed 230 VGPRs and ran no faster: the kernel is
-// VALU-issue bound).  ~115 VGPRs → 4 waves per SIMD; the reduce scratch and the record image
+// VALU-issue bound).  The reduce scratch and the record image
 // overlay the input image (8 KiB of LDS per wave) and the next unit's DMA is issued once the records sit in
 // registers.  Latency is hidden by occupancy instead of by a software pipeline.
 // ---------------------------------------------------------------------------------------------
-constexpr int kRolledWaveLds = kInBytes; // 8192 B: input image, then (scratch 3808 B | records 704 B)
-static_assert((kScratchDoubles + kRecDoubles) * 8 <= kInBytes, "reduce scratch + record image must fit in the input image");
+constexpr int kRolledWaveLds = kInBytes; // 8192 B: input image, then (scratch | records 704 B)
 
 // LDS-DMA through inline asm (the compiler then does not drain vmcnt before unrelated LDS reads; waits are ours).
 __device__ __forceinline__ void glds16(const void *sbase, uint32_t voff, uint32_t lds_addr)
 {
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_addr) : "memory");
 }
+// the same with a per-lane 64-bit address (the listed form: the four tiles of a unit lie anywhere)
+__device__ __forceinline__ void glds16v(const void *vaddr, uint32_t lds_addr)
+{
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(vaddr), "s"(lds_addr) : "memory");
+}
 
-// waves per SIMD an instantiation is compiled and launched for: the three-format kernel needs 146 VGPRs (3 waves); every smaller subset
-// fits 128 (4 waves: 8 KiB of LDS per wave allows 5).  -DMTQ_ROLLED_WAVES_PER_SIMD_FORCE=n overrides both.
-__host__ __device__ constexpr int rolled_waves(uint32_t bfp)
+// waves per SIMD an instantiation is compiled and launched for: the three-format kernel needs 146 VGPRs (3 waves); every smaller
+// evaluation fits 128 (4 waves: 8 KiB of LDS per wave allows 5).  -DMTQ_ROLLED_WAVES_PER_SIMD_FORCE=n overrides both.
+__host__ __device__ constexpr int rolled_waves(uint32_t sums, uint32_t errs)
 {
 #ifdef MTQ_ROLLED_WAVES_PER_SIMD_FORCE
     return MTQ_ROLLED_WAVES_PER_SIMD_FORCE;
 #else
-    return bfp == 7u ? 3 : 4;
+    return (sums == 7u && errs == 7u) ? 3 : 4;
 #endif
 }
 
-template <uint32_t BFP, uint32_t PART>
-__global__ __launch_bounds__(kFastWaves * 64, rolled_waves(BFP)) void tile_stats_bf16_rolled(
+// Arguments of the listed form (LISTED): the unit's four tiles come from a device list instead of the unit counter.
+struct ListedArgs {
+    const uint32_t *list, *n_list;   // tensor * tiles + tile; the list's length on the device
+    uint32_t cap;
+    uint32_t *redo, *n_redo;         // tiles the exact route cannot take are appended here (the caller runs them through the direct listed kernel)
+    uint32_t tiles_w32;              // tiles per tile row
+};
+
+template <uint32_t SUMS, uint32_t ERRS, bool XS, bool LISTED>
+__global__ __launch_bounds__(kFastWaves * 64, rolled_waves(SUMS, ERRS)) void tile_stats_bf16_rolled(
     const uint16_t *__restrict__ x, int64_t stride, int64_t ld, int tiles_w, int64_t tiles, int units_w, int units_per_tensor,
     int total_units, uint32_t fmt_mask, uint32_t eval_mask, uint32_t part_mask, int rec, double *__restrict__ stats, unsigned *__restrict__ work,
-    unsigned launch_id, int units_per_wave)
+    unsigned launch_id, int units_per_wave, ListedArgs la)
 {
     // fmt_mask: the record LAYOUT (which slots exist); eval_mask ⊂ fmt_mask: the slots this launch writes; part_mask ⊂ eval_mask: those
     // of them that only get Σy, Σy², Σxy.  Slots of the layout that are not written hold NaN afterwards (mtq_tile_stats_partial).
-    constexpr int nsum = terms_needed(BFP, PART);
+    // LISTED: nothing but the statistics the instantiation forms is written, each straight to its place in the tile's record.
+    constexpr int nsum = terms_needed(SUMS, ERRS, XS);
     constexpr bool one_pass = nsum <= kOnePassMax;
     constexpr int scratch_doubles = one_pass ? kUnitTiles * nsum * kScratchStride : kScratchDoubles;
     static_assert((scratch_doubles + kRecDoubles) * 8 <= kInBytes, "reduce scratch + record image must fit in the input image");
@@ -291,12 +312,13 @@ __global__ __launch_bounds__(kFastWaves * 64, rolled_waves(BFP)) void tile_stats
     const uint32_t in_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)in;
     const uint32_t t = lane >> 4, j = lane & 15;
 
-    uint32_t dma_off[8];
+    uint32_t dma_off[8], dma_tile[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const uint32_t rho = lane >> 4;
         const uint32_t c = (lane & 15u) ^ swz(2u * i + (rho >> 1));
-        dma_off[i] = (uint32_t)((4 * i + rho) * ld * 2) + c * 16u;
+        dma_off[i] = LISTED ? (uint32_t)((4 * i + rho) * ld * 2) + (c & 3u) * 16u : (uint32_t)((4 * i + rho) * ld * 2) + c * 16u;
+        dma_tile[i] = c >> 2;                                                 // which of the unit's four tiles this lane's chunk belongs to
     }
     const uint32_t rd_base = (j >> 1) * 1024u + (2u * (j & 1u)) * 256u;
     const uint32_t c0 = (4u * t) ^ swz(j);                                    // chunk (4t+kl)^swz(j) = c0 ^ kl
@@ -306,17 +328,30 @@ __global__ __launch_bounds__(kFastWaves * 64, rolled_waves(BFP)) void tile_stats
     // the resident waves take the whole queue instead of the launch waiting for the late blocks' fixed shares.
     // One counter per group of blocks (kWorkGroups counters on separate 128-B lines; ≈ 12 ns per same-address atomic on
     // MI355X, so a single queue would serialise the launch): group g of G = min(blocks, kWorkGroups) owns units g, g + G, …
+    // (The listed form strides: its launches are short, and it has no follow-up kernel to reset a counter.)
     const int groups = (int)min(gridDim.x, (unsigned)kWorkGroups), group = (int)(blockIdx.x % (unsigned)groups);
-    unsigned *queue = work + group * kWorkStride;
+    unsigned *queue = LISTED ? nullptr : work + group * kWorkStride;
+    uint32_t n_listed = 0u;
+    if constexpr (LISTED) {
+        n_listed = min(*la.n_list, la.cap);
+        total_units = (int)((n_listed + 3u) >> 2);
+    }
+    int stride_next = (int)(blockIdx.x * kFastWaves) + wave;                  // listed form: this wave's next unit
     auto claim = [&]() -> int {
-        unsigned v = 0u;
-        if (lane == 0) v = __hip_atomic_fetch_add(queue, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const unsigned k = (unsigned)__builtin_amdgcn_readfirstlane(v);
-        return k < 0x01000000u ? group + (int)k * groups : 0x7FFFFFFF;
+        if constexpr (LISTED) {
+            const int u = stride_next;
+            stride_next += (int)gridDim.x * kFastWaves;
+            return u;
+        } else {
+            unsigned v = 0u;
+            if (lane == 0) v = __hip_atomic_fetch_add(queue, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned k = (unsigned)__builtin_amdgcn_readfirstlane(v);
+            return k < 0x01000000u ? group + (int)k * groups : 0x7FFFFFFF;
+        }
     };
     const int o_bf16 = 2, o8 = 2 + 5 * __builtin_popcount(fmt_mask & 1u), o4 = 2 + 5 * __builtin_popcount(fmt_mask & 3u),
               o2 = 2 + 5 * __builtin_popcount(fmt_mask & 7u);
-    const bool holes = (eval_mask & ~part_mask & MTQ_MASK_ALL) != (fmt_mask & MTQ_MASK_ALL);   // some slot (or part of one) is not written
+    const bool holes = !LISTED && (eval_mask & ~part_mask & MTQ_MASK_ALL) != (fmt_mask & MTQ_MASK_ALL);   // some slot (or part of one) is not written
 
     auto unit_base = [&](int u, int &b, int &tr, int &uc) {
         b = u / units_per_tensor;
@@ -324,12 +359,28 @@ __global__ __launch_bounds__(kFastWaves * 64, rolled_waves(BFP)) void tile_stats
         tr = r / units_w;
         uc = r - tr * units_w;
     };
+    // listed form: the global tile this lane's 16-lane group serves in unit u (a short last unit repeats the list's last tile)
+    auto listed_tile = [&](int u, uint32_t q) -> uint32_t { return la.list[min((uint32_t)u * 4u + q, n_listed - 1u)]; };
     auto issue_dma = [&](int u) {
-        int b, tr, uc;
-        unit_base(u, b, tr, uc);
-        const unsigned char *base = reinterpret_cast<const unsigned char *>(x + (int64_t)b * stride + ((int64_t)tr * kTile) * ld + (int64_t)uc * kUnitCols);
+        if constexpr (LISTED) {
+            // lane q < 4 works out where tile q of the unit starts; every lane then picks the start of the tile its chunk belongs to
+            const uint32_t gt = listed_tile(u, (uint32_t)lane & 3u);
+            const uint32_t b = gt / (uint32_t)tiles, tt = gt - b * (uint32_t)tiles;
+            const uint32_t tr = tt / la.tiles_w32, tc = tt - tr * la.tiles_w32;
+            const unsigned long long mine = (unsigned long long)(uintptr_t)(x + (int64_t)b * stride + ((int64_t)tr * kTile) * ld + (int64_t)tc * kTile);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) glds16(base, dma_off[i], in_addr + i * 1024);
+            for (int i = 0; i < 8; ++i) {
+                const unsigned lo = (unsigned)__shfl((int)(unsigned)mine, (int)dma_tile[i], 64), hi = (unsigned)__shfl((int)(unsigned)(mine >> 32), (int)dma_tile[i], 64);
+                const unsigned long long src = (((unsigned long long)hi << 32) | lo) + dma_off[i];
+                glds16v(reinterpret_cast<const void *>((uintptr_t)src), in_addr + i * 1024);
+            }
+        } else {
+            int b, tr, uc;
+            unit_base(u, b, tr, uc);
+            const unsigned char *base = reinterpret_cast<const unsigned char *>(x + (int64_t)b * stride + ((int64_t)tr * kTile) * ld + (int64_t)uc * kUnitCols);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) glds16(base, dma_off[i], in_addr + i * 1024);
+        }
     };
     // lane j of a tile's 16 lanes reduces one statistic and puts it where the record wants it
     auto place = [&](double *rec_t, int sidx, double r) {
@@ -384,27 +435,54 @@ __global__ __launch_bounds__(kFastWaves * 64, rolled_waves(BFP)) void tile_stats
             const uint4 hi = *reinterpret_cast<const uint4 *>(rowp + ((c0 ^ (kl | 1u)) << 4));
             const uint32_t w[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
             GroupOut G;
-            fast_group<BFP, PART>(w, G, [&](uint32_t w2[8]) {
+            fast_group<SUMS, ERRS, XS>(w, G, [&](uint32_t w2[8]) {
                 const uint4 l2 = *reinterpret_cast<const uint4 *>(rowp + ((c0 ^ kl) << 4));
                 const uint4 h2 = *reinterpret_cast<const uint4 *>(rowp + ((c0 ^ (kl | 1u)) << 4));
                 w2[0] = l2.x; w2[1] = l2.y; w2[2] = l2.z; w2[3] = l2.w; w2[4] = h2.x; w2[5] = h2.y; w2[6] = h2.z; w2[7] = h2.w;
             });
 #pragma unroll
             for (int s = 0; s < kSums; ++s)
-                if (term_needed(BFP, PART, s)) acc[s] = acc[s] + G.term[s];   // 0.0 + t = t exactly: sequential ((g0+g1)+g2)+g3
+                if (term_needed(SUMS, ERRS, XS, s)) acc[s] = acc[s] + G.term[s];   // 0.0 + t = t exactly: sequential ((g0+g1)+g2)+g3
             mx[0] = fmaxf(mx[0], G.mx[0]); mx[1] = fmaxf(mx[1], G.mx[1]); mx[2] = fmaxf(mx[2], G.mx[2]);
             bad |= G.bad;
         }
 
 #pragma unroll
         for (int f = 0; f < 3; ++f) {
-            if (!(BFP & (1u << f)) || (PART & (1u << f))) continue;
+            if (!(ERRS & (1u << f))) continue;
 #pragma unroll
             for (int sft = 1; sft < 16; sft <<= 1) mx[f] = fmaxf(mx[f], __shfl_xor(mx[f], sft, 16));
         }
         const unsigned long long bad_lanes = __ballot(bad);
         const bool tile_bad = ((bad_lanes >> (16 * t)) & 0xFFFFull) != 0ull;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                   // every lane's image reads are done: overlay may begin
+
+        if constexpr (LISTED) {
+            // every statistic straight to its place in the tile's own record; a tile of the list's padding (a short last unit) writes nothing
+            const bool real = (uint32_t)u * 4u + t < n_listed;
+            const uint32_t gt = listed_tile(u, t);
+            double *rec_g = stats + (int64_t)gt * rec;
+#pragma unroll
+            for (int i = 0; i < nsum; ++i) scratch[(t * nsum + i) * kScratchStride + j] = acc[term_at(SUMS, ERRS, XS, i)];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if ((int)j < nsum && real && !tile_bad) {
+                const double r = tree16(scratch + (t * nsum + j) * kScratchStride);
+                int sidx = 0;
+#pragma unroll
+                for (int i = 0; i < nsum; ++i) sidx = (int)j == i ? term_at(SUMS, ERRS, XS, i) : sidx;
+                place(rec_g, sidx, r);
+            }
+            if (j == 15 && real && !tile_bad) {
+                if (ERRS & 1u) rec_g[o8 + 4] = (double)mx[0];
+                if (ERRS & 2u) rec_g[o4 + 4] = (double)mx[1];
+                if (ERRS & 4u) rec_g[o2 + 4] = (double)mx[2];
+            }
+            if (j == 0 && real && tile_bad) la.redo[atomicAdd(la.n_redo, 1u)] = gt;   // the direct listed kernel takes it (literal route)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // the scratch is consumed: the image may be refilled
+            if (u_next < total_units) issue_dma(u_next);
+            u = u_next;
+            continue;
+        }
 
         double *rec_t = recbuf + t * rec;
         const int nrec = kUnitTiles * rec;
@@ -416,13 +494,13 @@ __global__ __launch_bounds__(kFastWaves * 64, rolled_waves(BFP)) void tile_stats
         }
         if constexpr (one_pass) {
 #pragma unroll
-            for (int i = 0; i < nsum; ++i) scratch[(t * nsum + i) * kScratchStride + j] = acc[term_at(BFP, PART, i)];
+            for (int i = 0; i < nsum; ++i) scratch[(t * nsum + i) * kScratchStride + j] = acc[term_at(SUMS, ERRS, XS, i)];
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             if ((int)j < nsum) {
                 const double r = tree16(scratch + (t * nsum + j) * kScratchStride);
                 int sidx = 0;
 #pragma unroll
-                for (int i = 0; i < nsum; ++i) sidx = (int)j == i ? term_at(BFP, PART, i) : sidx;
+                for (int i = 0; i < nsum; ++i) sidx = (int)j == i ? term_at(SUMS, ERRS, XS, i) : sidx;
                 place(rec_t, sidx, r);
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -437,9 +515,9 @@ __global__ __launch_bounds__(kFastWaves * 64, rolled_waves(BFP)) void tile_stats
             }
         }
         if (j == 15) {
-            if (eval_mask & ~part_mask & 2u) rec_t[o8 + 4] = (double)mx[0];
-            if (eval_mask & ~part_mask & 4u) rec_t[o4 + 4] = (double)mx[1];
-            if (eval_mask & ~part_mask & 8u) rec_t[o2 + 4] = (double)mx[2];
+            if ((ERRS & 1u) && (eval_mask & ~part_mask & 2u)) rec_t[o8 + 4] = (double)mx[0];
+            if ((ERRS & 2u) && (eval_mask & ~part_mask & 4u)) rec_t[o4 + 4] = (double)mx[1];
+            if ((ERRS & 4u) && (eval_mask & ~part_mask & 8u)) rec_t[o2 + 4] = (double)mx[2];
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (tile_bad && j == 0) {
@@ -466,6 +544,18 @@ __global__ __launch_bounds__(kFastWaves * 64, rolled_waves(BFP)) void tile_stats
 
 using namespace mtq;
 
+static int fast_cus()
+{
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0;
+        hipDeviceProp_t p;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess) return 0;
+        cus = p.multiProcessorCount;
+    }
+    return cus;
+}
+
 // Launcher used by mtq_tile_stats_batched / mtq_tile_stats_partial when the input qualifies (mtq_kernels.hip decides).
 // fmt_mask: record layout; eval_mask ⊂ fmt_mask: slots to write; part_mask ⊂ eval_mask: slots that only get Σy, Σy², Σxy
 // (served for the combinations instantiated below; any other part_mask is widened to full slots, which is always allowed).
@@ -477,18 +567,16 @@ extern "C" int mtq_launch_tile_stats_bf16_fast(const void *x, int64_t count, int
     const int64_t units_w = cols / kUnitCols, upt = th * units_w, total = count * upt;
     if (total > INT32_MAX / 2 || 64 * ld > (int64_t)UINT32_MAX) return fail(MTQ_ERR_INVALID, "tensor batch too large for one fast launch");
     const int rec = 2 + 5 * __builtin_popcount(fmt_mask & MTQ_MASK_ALL);
-    static int cus = 0;
-    if (cus == 0) {
-        int dev = 0;
-        hipDeviceProp_t p;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess) return fail(MTQ_ERR_HIP, "hipGetDeviceProperties failed");
-        cus = p.multiProcessorCount;
-    }
-    const int64_t need = (total + kFastWaves - 1) / kFastWaves;
+    const int cus = fast_cus();
+    if (cus == 0) return fail(MTQ_ERR_HIP, "hipGetDeviceProperties failed");
     eval_mask &= fmt_mask & MTQ_MASK_ALL;
     part_mask &= eval_mask & 0xEu;
     const uint32_t bfp = (eval_mask >> 1) & 7u;
-    const int64_t max_blocks = (int64_t)cus * rolled_waves(bfp) * 4 / kFastWaves; // resident blocks: that many waves on each of a CU's 4 SIMDs
+    uint32_t part = (part_mask >> 1) & 7u;
+    if (!((bfp == 3u && part == 2u) || (bfp == 1u && part == 1u) || (bfp == 2u && part == 2u))) { part = 0u; part_mask = 0u; }
+    const uint32_t sums = bfp, errs = bfp & ~part;
+    const int64_t need = (total + kFastWaves - 1) / kFastWaves;
+    const int64_t max_blocks = (int64_t)cus * rolled_waves(sums, errs) * 4 / kFastWaves; // resident blocks: that many waves on each of a CU's 4 SIMDs
     // MTQ_K1_UNITS_PER_WAVE (default 8; 0 = persistent waves): with a bound, the grid is what the units need at that many per wave,
     // rounded up to whole counter groups plus one spare block per group (a block that finds its group's queue empty exits at once)
     static int upw = -1;
@@ -504,27 +592,56 @@ extern "C" int mtq_launch_tile_stats_bf16_fast(const void *x, int64_t count, int
     const size_t lds_bytes = kFastWaves * kRolledWaveLds;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const uint16_t *xp = static_cast<const uint16_t *>(x);
-    uint32_t part = (part_mask >> 1) & 7u;
-    if (!((bfp == 3u && part == 2u) || (bfp == 1u && part == 1u) || (bfp == 2u && part == 2u))) { part = 0u; part_mask = 0u; }
     if (int rc = work_counter_acquire(stream, work_out)) return rc;   // `st` now waits for the slot's previous launch to have reset it
     unsigned *work = work_out->counters;
-#define MTQ_LAUNCH_FAST(B, P) \
-    hipLaunchKernelGGL((tile_stats_bf16_rolled<B, P>), grid, block, lds_bytes, st, xp, stride_elems, ld, (int)tw, tiles, (int)units_w, (int)upt, (int)total, fmt_mask, eval_mask, part_mask, rec, stats, work, launch_id, (need > max_blocks ? upw : 0))
-    switch (bfp | (part << 4)) { // one instantiation per evaluated BFP subset: unrequested formats cost nothing
-    case 0x01: MTQ_LAUNCH_FAST(1u, 0u); break;
-    case 0x02: MTQ_LAUNCH_FAST(2u, 0u); break;
-    case 0x03: MTQ_LAUNCH_FAST(3u, 0u); break;
-    case 0x04: MTQ_LAUNCH_FAST(4u, 0u); break;
-    case 0x05: MTQ_LAUNCH_FAST(5u, 0u); break;
-    case 0x06: MTQ_LAUNCH_FAST(6u, 0u); break;
-    case 0x07: MTQ_LAUNCH_FAST(7u, 0u); break;
+    const ListedArgs none{};
+#define MTQ_LAUNCH_FAST(S, E) \
+    hipLaunchKernelGGL((tile_stats_bf16_rolled<S, E, true, false>), grid, block, lds_bytes, st, xp, stride_elems, ld, (int)tw, tiles, (int)units_w, (int)upt, (int)total, fmt_mask, eval_mask, part_mask, rec, stats, work, launch_id, (need > max_blocks ? upw : 0), none)
+    switch (sums | (errs << 4)) { // one instantiation per evaluated subset: what is not asked for costs nothing
     case 0x11: MTQ_LAUNCH_FAST(1u, 1u); break;
     case 0x22: MTQ_LAUNCH_FAST(2u, 2u); break;
-    case 0x23: MTQ_LAUNCH_FAST(3u, 2u); break;
+    case 0x33: MTQ_LAUNCH_FAST(3u, 3u); break;
+    case 0x44: MTQ_LAUNCH_FAST(4u, 4u); break;
+    case 0x55: MTQ_LAUNCH_FAST(5u, 5u); break;
+    case 0x66: MTQ_LAUNCH_FAST(6u, 6u); break;
+    case 0x77: MTQ_LAUNCH_FAST(7u, 7u); break;
+    case 0x01: MTQ_LAUNCH_FAST(1u, 0u); break;           // partial records: the last evaluated format without Σ|x−y|, max|x−y|
+    case 0x02: MTQ_LAUNCH_FAST(2u, 0u); break;
+    case 0x13: MTQ_LAUNCH_FAST(3u, 1u); break;
     default:                                             // no BFP format evaluated: the launcher's callers never ask for that
-        work_counter_release(*work_out, stream);
+        work_counter_abandon(*work_out);
         return fail(MTQ_ERR_INVALID, "the bf16 fast kernel needs at least one BFP format to evaluate");
     }
 #undef MTQ_LAUNCH_FAST
     return check_launch("mtq_tile_stats (bf16 fast)");
+}
+
+// The listed form (mtq_tile_stats_listed): → MTQ_OK when launched, 1 when this input / mask combination is not served here (the caller
+// uses the direct listed kernel), < 0 on error.  redo / n_redo: device list the kernel appends the tiles to that the exact route cannot
+// take (n_redo zeroed by the caller on the same stream).
+extern "C" int mtq_launch_tile_stats_bf16_listed(const void *x, int64_t count, int64_t stride_elems, int64_t rows, int64_t cols, int64_t ld,
+                                                 uint32_t fmt_mask, uint32_t full_mask, uint32_t err_mask, const uint32_t *list, const uint32_t *n_list,
+                                                 uint32_t cap, uint32_t *redo, uint32_t *n_redo, double *stats, void *stream)
+{
+    const uint32_t sums = (full_mask >> 1) & 7u, errs = ((full_mask | err_mask) >> 1) & 7u;
+    if (!((sums == 4u && errs == 6u) || (sums == 2u && errs == 3u))) return 1;
+    if (rows % kTile != 0 || cols % kTile != 0 || 64 * ld > (int64_t)UINT32_MAX) return 1;
+    const int64_t th = rows / kTile, tw = cols / kTile, tiles = th * tw;
+    const int rec = 2 + 5 * __builtin_popcount(fmt_mask & MTQ_MASK_ALL);
+    const int cus = fast_cus();
+    if (cus == 0) return fail(MTQ_ERR_HIP, "hipGetDeviceProperties failed");
+    const int64_t need = (((int64_t)cap + 3) / 4 + kFastWaves - 1) / kFastWaves;
+    const int64_t max_blocks = (int64_t)cus * rolled_waves(sums, errs) * 4 / kFastWaves;
+    const dim3 grid((unsigned)(need < max_blocks ? need : max_blocks)), block(kFastWaves * 64);
+    const size_t lds_bytes = kFastWaves * kRolledWaveLds;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const uint16_t *xp = static_cast<const uint16_t *>(x);
+    const ListedArgs la{list, n_list, cap, redo, n_redo, (uint32_t)tw};
+    const uint32_t eval = (full_mask | err_mask) & fmt_mask;
+#define MTQ_LAUNCH_LISTED_FAST(S, E) \
+    hipLaunchKernelGGL((tile_stats_bf16_rolled<S, E, false, true>), grid, block, lds_bytes, st, xp, stride_elems, ld, (int)tw, tiles, 0, 0, 0, fmt_mask, eval, 0u, rec, stats, (unsigned *)nullptr, 0u, 0, la)
+    if (sums == 4u) MTQ_LAUNCH_LISTED_FAST(4u, 6u);
+    else MTQ_LAUNCH_LISTED_FAST(2u, 3u);
+#undef MTQ_LAUNCH_LISTED_FAST
+    return check_launch("mtq_tile_stats_listed (bf16 fast)");
 }

@@ -118,7 +118,7 @@ def lib() -> ctypes.CDLL:
     L.mtq_scan_orders_bytes.argtypes = [i64]
     L.mtq_scan_orders_bytes.restype = ctypes.c_size_t
     L.mtq_scan_orders_device.argtypes = [ctypes.c_uint64, i64, ci, vp, ctypes.c_size_t, vp]
-    L.mtq_tile_stats_listed.argtypes = [vp, ci, i64, i64, i64, i64, i64, u32, u32, u32, vp, vp, i64, vp, vp]
+    L.mtq_tile_stats_listed.argtypes = [vp, ci, i64, i64, i64, i64, i64, u32, u32, u32, vp, vp, i64, vp, vp, vp]
     L.mtq_shutdown.restype = ci
     L.mtq_selftest_slot_ring.restype = ci
     L.mtq_device_copy_2d.argtypes = [vp, ctypes.c_size_t, vp, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_size_t, vp]
@@ -557,15 +557,17 @@ def greedy_scan_device_ex(stats_dev, mask: int, formats, metric: str, threshold:
                                           carry.data_ptr() if carry is not None else None, _stream_ptr()))
 
 
-def tile_stats_listed(x3d, layout_mask: int, full_mask: int, err_mask: int, listed, n_listed, stats) -> None:
+def tile_stats_listed(x3d, layout_mask: int, full_mask: int, err_mask: int, listed, n_listed, stats, scratch=None) -> None:
     """mtq_tile_stats_listed: for the tiles listed[0 .. n_listed[0]) (device uint32 / int32 tensors; entries tensor * tiles + tile) the five
-    statistics of full_mask's formats and Σ|x−y|, max|x−y| of err_mask's, into stats [count, tiles, rec(layout)] in place."""
+    statistics of full_mask's formats and Σ|x−y|, max|x−y| of err_mask's, into stats [count, tiles, rec(layout)] in place.  scratch:
+    int32 device tensor of listed.numel() + 1 entries (lets bf16 input take the exact-integer kernel), or None."""
     require_gpu()
     if x3d.dim() != 3 or not x3d.is_cuda or not x3d.is_contiguous():
         raise MtqError("expected a contiguous (count, rows, cols) device tensor")
     count, rows, cols = x3d.shape
     check(lib().mtq_tile_stats_listed(x3d.data_ptr(), _dtype_code(x3d), count, rows * cols, rows, cols, cols, layout_mask, full_mask, err_mask,
-                                      listed.data_ptr(), n_listed.data_ptr(), int(listed.numel()), stats.data_ptr(), _stream_ptr()))
+                                      listed.data_ptr(), n_listed.data_ptr(), int(listed.numel()),
+                                      scratch.data_ptr() if scratch is not None else None, stats.data_ptr(), _stream_ptr()))
 
 
 def greedy_run_batch(stats: np.ndarray, mask: int, formats, metric: str, threshold: float, elem_count: float, seeds, n_threads: int):

@@ -58,7 +58,7 @@ def run_case(x, formats, thr, seed, metric="pcc", label=""):
         carry = torch.empty((int(L.mtq_scan_carry_bytes(count)),), dtype=torch.uint8, device='cuda')
         maps.fill_(-1); cnt.zero_()
         hb.greedy_scan_device_ex(part, dec, formats, metric, thr, numel, sd, maps, status, scratch, counts_out=cnt, orders=orders, phase=1, listed=listed, n_listed=nl, carry=carry)
-        hb.tile_stats_listed(x, lay, last, prev, listed, nl, part)
+        hb.tile_stats_listed(x, lay, last, prev, listed, nl, part, scratch=torch.empty((count * T + 1,), dtype=torch.int32, device='cuda'))
         hb.greedy_scan_device_ex(part, dec, formats, metric, thr, numel, sd, maps, status, scratch, counts_out=cnt, phase=2, carry=carry)
         ok2 = check("split / lazy")
         # the columns of the final map from the lazily filled records == from the full records
@@ -108,6 +108,7 @@ orders = hb.scan_orders_device(123, T, 2)
 listed = torch.empty((n * T,), dtype=torch.int32, device='cuda'); nl = torch.zeros((1,), dtype=torch.int32, device='cuda')
 carry = torch.empty((int(L.mtq_scan_carry_bytes(n)),), dtype=torch.uint8, device='cuda')
 part = hb.tile_stats_partial(x, 0xE, 0x2, 0x4)
+lscr = torch.empty((n * T + 1,), dtype=torch.int32, device='cuda')
 
 
 def timeit(fn):
@@ -134,16 +135,17 @@ def phase1():
 
 print(f"  split: phase 1 (shared orders)                  {timeit(phase1):.3f}")
 phase1()
-print(f"  split: listed K1 ({int(nl.item())} tiles)                {timeit(lambda: hb.tile_stats_listed(x, 0xE, 0x8, 0x4, listed, nl, part)):.3f}")
+print(f"  split: listed K1 ({int(nl.item())} tiles)                {timeit(lambda: hb.tile_stats_listed(x, 0xE, 0x8, 0x4, listed, nl, part, scratch=lscr)):.3f}")
 
 
 def chain():
     phase1()
-    hb.tile_stats_listed(x, 0xE, 0x8, 0x4, listed, nl, part)
+    hb.tile_stats_listed(x, 0xE, 0x8, 0x4, listed, nl, part, scratch=lscr)
     hb.greedy_scan_device_ex(part, DEC, ALL, 'pcc', 0.999, numel, sd, maps, status, scratch, phase=2, carry=carry)
 
 
 print(f"  split: phase 1 + listed K1 + phase 2             {timeit(chain):.3f}")
+print(f"  split: listed K1, one wave per tile (no scratch) {timeit(lambda: hb.tile_stats_listed(x, 0xE, 0x8, 0x4, listed, nl, part)):.3f}")
 print(f"  K1 partial (bfp8 full, bfp4 sums)               {timeit(lambda: hb.tile_stats_partial(x, 0xE, 0x2, 0x4, out=part)):.3f}")
 print(f"  K1 full 0xE                                      {timeit(lambda: hb.tile_stats_batched(x, 0xE, out=recs)):.3f}")
 print("MISMATCHES:", bad)
