@@ -216,14 +216,13 @@ def main() -> None:
         torch.cuda.synchronize()
 
     # K1 alone (no scan, no copies beside it): the same launch the steps issue, HIP events on the current stream
-    k1_mask, _hm, _slim = pipe._layout(batch)
-    alone_out = hb.tile_stats_batched(batch[: args.chunk], k1_mask)
+    alone_out = pipe.launch_k1(batch[: args.chunk])     # the launch the route issues (round 3: partial records on the lazy route)
     torch.cuda.synchronize()
     alone = []
     for _ in range(5):
         a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a0.record()
-        hb.tile_stats_batched(batch[: args.chunk], k1_mask, out=alone_out)
+        pipe.launch_k1(batch[: args.chunk], out=alone_out)
         a1.record()
         a1.synchronize()
         alone.append(a0.elapsed_time(a1))

@@ -491,7 +491,7 @@ extern "C" int mtq_tile_stats_listed(const void *x, int in_dtype, int64_t count,
     // the list's length is only known on the device: a grid that fills the chip once, every wave striding through the list
     const int64_t need = (capacity + kDirectWaves - 1) / kDirectWaves;
     const int64_t max_blocks = (int64_t)cus * MTQ_DIRECT_WAVES_PER_SIMD * 4 / kDirectWaves;
-    const dim3 grid((unsigned)(need < max_blocks ? need : max_blocks));
+    dim3 grid((unsigned)(need < max_blocks ? need : max_blocks));
     hipStream_t st = static_cast<hipStream_t>(stream);
     const uint32_t cap = (uint32_t)(capacity < (int64_t)UINT32_MAX ? capacity : (int64_t)UINT32_MAX);
     if (in_dtype == MTQ_DTYPE_BF16 && vec_ok && scratch && getenv("MTQ_LISTED_DIRECT") == nullptr) {
@@ -500,7 +500,11 @@ extern "C" int mtq_tile_stats_listed(const void *x, int in_dtype, int64_t count,
         const int rc = mtq_launch_tile_stats_bf16_listed(x, count, stride_elems, rows, cols, ld, layout_mask, full_mask, err_mask, listed, n_listed, cap,
                                                          scratch + 1, scratch, stats, stream);
         if (rc < 0) return rc;
-        if (rc == 0) { listed = scratch + 1; n_listed = scratch; }   // what is left for the kernel above: the tiles the exact route handed back
+        if (rc == 0) {   // what is left for the kernel above: the tiles the exact route handed back — few or none: a small grid strides through them
+            listed = scratch + 1;
+            n_listed = scratch;
+            grid = dim3(grid.x < 64u ? grid.x : 64u);
+        }
     }
     if (in_dtype == MTQ_DTYPE_BF16)
         launch_listed<uint16_t>(fm, grid, st, static_cast<const uint16_t *>(x), stride_elems, rows, cols, ld, (uint32_t)tw, (uint32_t)tiles, listed,

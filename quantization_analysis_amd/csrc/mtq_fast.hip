@@ -576,7 +576,10 @@ extern "C" int mtq_launch_tile_stats_bf16_fast(const void *x, int64_t count, int
     if (!((bfp == 3u && part == 2u) || (bfp == 1u && part == 1u) || (bfp == 2u && part == 2u))) { part = 0u; part_mask = 0u; }
     const uint32_t sums = bfp, errs = bfp & ~part;
     const int64_t need = (total + kFastWaves - 1) / kFastWaves;
-    const int64_t max_blocks = (int64_t)cus * rolled_waves(sums, errs) * 4 / kFastWaves; // resident blocks: that many waves on each of a CU's 4 SIMDs
+    static int wps_env = -1;                              // MTQ_K1_WAVES: waves per SIMD the grid is sized for (experiments)
+    if (wps_env < 0) { const char *e = getenv("MTQ_K1_WAVES"); wps_env = e ? atoi(e) : 0; }
+    const int wps = wps_env > 0 ? wps_env : rolled_waves(sums, errs);
+    const int64_t max_blocks = (int64_t)cus * wps * 4 / kFastWaves; // resident blocks: that many waves on each of a CU's 4 SIMDs
     // MTQ_K1_UNITS_PER_WAVE (default 8; 0 = persistent waves): with a bound, the grid is what the units need at that many per wave,
     // rounded up to whole counter groups plus one spare block per group (a block that finds its group's queue empty exits at once)
     static int upw = -1;

@@ -75,18 +75,23 @@ __global__ __launch_bounds__(256) void tile_stats_redo_flagged(const T *__restri
 {
     if (blockIdx.x == 0 && threadIdx.x < kWorkGroups) work[threadIdx.x * kWorkStride] = 0u; // the launch's unit counters, ready for their next user
     if (work[kWorkStamp] != launch_id) return;                          // no tile of this launch was marked (the usual case): nothing to read
+    // a grid of at most kRedoBlocks blocks strides over the records (round 3: the follow-up sits on the K1 stream between two K1 launches,
+    // and a grid of one wave per 64 records — 8 192 blocks for a 128-tensor batch — took 20–55 µs to pass through the chip just to find nothing)
     const int lane = threadIdx.x & 63;
-    const int64_t first = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 64;
-    const int64_t mine = first + lane;
-    bool flagged = false;
-    if (mine < count * tiles) flagged = (unsigned long long)__double_as_longlong(stats[mine * rec]) == kRedoMagicGeneric;
-    unsigned long long todo = __ballot(flagged);
-    while (todo) {                                                     // wave-uniform loop over the flagged tiles
-        const int k = __builtin_ctzll(todo);
-        todo &= todo - 1;
-        tile_stats_one<T>(x, first + k, stride, rows, cols, ld, tiles_w, tiles, fmt_mask, rec, stats, vec_ok);
+    const int64_t total = count * tiles;
+    for (int64_t first = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 64; first < total; first += (int64_t)gridDim.x * 4 * 64) {
+        const int64_t mine = first + lane;
+        bool flagged = false;
+        if (mine < total) flagged = (unsigned long long)__double_as_longlong(stats[mine * rec]) == kRedoMagicGeneric;
+        unsigned long long todo = __ballot(flagged);
+        while (todo) {                                                     // wave-uniform loop over the flagged tiles
+            const int k = __builtin_ctzll(todo);
+            todo &= todo - 1;
+            tile_stats_one<T>(x, first + k, stride, rows, cols, ld, tiles_w, tiles, fmt_mask, rec, stats, vec_ok);
+        }
     }
 }
+constexpr int64_t kRedoBlocks = 512;
 
 // ---------------------------------------------------------------------------------------------
 // K2 / K3: one thread per shared-exponent group; fmt >= 0 → that format everywhere (K2),
@@ -528,7 +533,7 @@ static int tile_stats_launch(const void *x, int in_dtype, int64_t count, int64_t
             return rc;
         }
         const int64_t waves = (count * tiles + 63) / 64;
-        hipLaunchKernelGGL(tile_stats_redo_flagged<uint16_t>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, static_cast<hipStream_t>(stream),
+        hipLaunchKernelGGL(tile_stats_redo_flagged<uint16_t>, dim3((unsigned)std::min<int64_t>((waves + 3) / 4, kRedoBlocks)), dim3(256), 0, static_cast<hipStream_t>(stream),
                            static_cast<const uint16_t *>(x), count, stride_elems, rows, cols, ld, (int)tw, tiles, fmt_mask, rec, stats, vec_ok, work.counters, launch_id);
         return finish_counter_launch(work, static_cast<hipStream_t>(stream));
     }
@@ -541,7 +546,7 @@ static int tile_stats_launch(const void *x, int in_dtype, int64_t count, int64_t
             work_counter_abandon(work);
             return rc;
         }
-        const dim3 rgrid((unsigned)(((count * tiles + 63) / 64 + 3) / 4));
+        const dim3 rgrid((unsigned)std::min<int64_t>(((count * tiles + 63) / 64 + 3) / 4, kRedoBlocks));
         if (in_dtype == MTQ_DTYPE_BF16)
             hipLaunchKernelGGL(tile_stats_redo_flagged<uint16_t>, rgrid, dim3(256), 0, s, static_cast<const uint16_t *>(x), count, stride_elems,
                                rows, cols, ld, (int)tw, tiles, fmt_mask, rec, stats, vec_ok, work.counters, launch_id);

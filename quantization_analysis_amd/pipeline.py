@@ -127,7 +127,9 @@ def columns_from_sums_batch(sums: np.ndarray, n: float) -> np.ndarray:
 class GreedyPipeline:
     """mixed-tile-greedy over a (count, rows, cols) device tensor of equally shaped bf16/fp32 matrices."""
 
-    SLOTS = int(os.environ.get("MTQ_PIPE_SLOTS", "3"))   # record slots = batches in flight: one on the GPU, one queued behind it, one being scanned (see run_steps)
+    SLOTS = int(os.environ.get("MTQ_PIPE_SLOTS", "4"))   # record slots = batches in flight: one on the GPU, one queued behind it, the others being searched (see run_steps).
+                                                         # Round 3: a batch's search is a chain of launches (orders, phase 1, listed K1, phase 2, column sums) that takes 5–7 ms
+                                                         # beside K1 launches of ~2 ms, so three slots made the K1 stream wait for a slot (2.65 against 2.47 ms per step at four)
 
     def __init__(self, tile_formats=None, metric: str = "pcc", threshold: float = 0.999, seed: int = 123,
                  chunk: int = 8, workers: int = 8, pure_formats=(), scan: str = "auto", scan_streams: int | None = None):
@@ -170,10 +172,19 @@ class GreedyPipeline:
         # How many: as many as scans of consecutive batches overlap.  Steps of one shape (bench.py: a 2.0 ms scan launch per 2.5 ms step)
         # overlap two — three streams; with eight, K1's launch measured 2.5 % longer and the step 3 % (806 against 829 M tiles/s:
         # more hardware queues in play).  A model's shape groups (streamed.py) keep every batch of a window in flight and ask for eight.
-        n_scan = int(os.environ.get("MTQ_SCAN_STREAMS", str(3 if scan_streams is None else scan_streams)))
+        n_scan = int(os.environ.get("MTQ_SCAN_STREAMS", str(4 if scan_streams is None else scan_streams)))
         self.scan_streams = [torch.cuda.Stream(priority=int(os.environ.get("MTQ_SCAN_PRIORITY", "-1")))
                              for _ in range(max(1, n_scan))]   # priority -1: ahead of K1's blocks when a slot opens
         self._scan_rr = 0
+        # Round 3.  shared orders: the tensors of a batch are searched with one seed, so the base pass's draws and the permutations of
+        # passes 1 and 2 are computed once per launch (mtq_scan_orders_device, beside K1) and a helper wave per tensor gathers the deltas ahead
+        # of the visiting wave.  lazy: K1 leaves out the last format of the list (and Σ|x−y|, max|x−y| of the one before it); the search
+        # stops before its last pass, the left-out statistics are evaluated for that pass's candidates only (mtq_tile_stats_listed: the
+        # tiles that accepted every earlier format — 15 % at pcc >= 0.999), and the last pass follows.  Same maps, same columns.
+        self.shared_orders = os.environ.get("MTQ_SHARED_ORDERS", "1") != "0"
+        self.lazy = (os.environ.get("MTQ_LAZY", "1") != "0" and self.metric == "pcc" and len(self.tile_formats) >= 3 and self.tile_formats[0] == "bf16"
+                     and len(set(self.tile_formats)) == len(self.tile_formats) and not self.pure_formats)
+        self.listed_tiles = 0                    # tiles the lazy route evaluated late (diagnostics)
         self.host_fallbacks = 0                  # tensors the device scan handed back (zero denominator)
         self.host_seconds = {"enqueue": 0.0, "wait": 0.0, "wrap": 0.0}   # driver-thread time: launching, waiting for results, wrapping them
         self._devbufs = {}
@@ -195,6 +206,27 @@ class GreedyPipeline:
         host_mask = k1_mask | hb.MASK_BF16_IDENTITY if identity else self.mask
         slim = self.metric == "pcc" and os.environ.get("MTQ_SLIM_RECORDS", "1") != "0"
         return k1_mask, host_mask | (hb.MASK_SLIM if slim else 0), slim
+
+    def lazy_plan(self, x3d):
+        """→ None, or (layout mask, formats K1 evaluates in full, format K1 evaluates without Σ|x−y| / max|x−y|, format left to the listed
+        kernel) when a batch shaped like x3d takes the lazy route (see __init__): bf16 storage in whole 32x128 units — what the exact-integer
+        kernel serves — and the search on the device."""
+        torch = self.torch
+        count, rows, cols = x3d.shape
+        th, tw = hb.tiles_hw(rows, cols)
+        k1_mask = self._layout(x3d)[0]
+        if not (self.lazy and self._use_device_scan(th * tw) and x3d.dtype == torch.bfloat16 and (k1_mask & 1) == 0 and rows % 32 == 0 and cols % 128 == 0):
+            return None
+        bit = lambda f: 1 << MIXED_TILE_FORMATS.index(f)
+        last_bit, prev_bit = bit(self.tile_formats[-1]), bit(self.tile_formats[-2])
+        return k1_mask, k1_mask & ~last_bit & ~prev_bit, prev_bit, last_bit
+
+    def launch_k1(self, x3d, out=None):
+        """The K1 launch a batch's route issues (the whole record, or the lazy route's partial one) on the current stream."""
+        plan = self.lazy_plan(x3d)
+        if plan is None:
+            return hb.tile_stats_batched(x3d, self._layout(x3d)[0], out=out)
+        return hb.tile_stats_partial(x3d, plan[0], plan[1], plan[2], out=out)
 
     def _chain(self, slim: bool) -> bool:
         """Chain records (differences of consecutive formats' sums, 3 doubles per step of the format chain, plus Σx, Σx² — or the
@@ -386,6 +418,14 @@ class GreedyPipeline:
             "status_host": flat("status_host", count, torch.int32, pinned=True),
             "counts_host": flat("counts_host", count * nf, torch.int32, pinned=True).view(count, nf),
             "sums_host": flat("sums_host", P * count * 7, torch.float64, pinned=True).view(P, count, 7),
+            # round 3: shared visiting orders of the batch's seed; the split search's candidate list, its length per chunk, the state
+            # it carries from phase 1 to phase 2, and the listed kernel's hand-back list
+            "orders": flat("orders", int(hb.lib().mtq_scan_orders_bytes(tiles)), torch.uint8),
+            "listed": flat("listed", count * tiles, torch.int32),
+            "n_listed": flat("n_listed", count, torch.int32),
+            "carry": flat("carry", int(hb.lib().mtq_scan_carry_bytes(count)), torch.uint8),
+            "lscr": flat("lscr", count * tiles + count, torch.int32),
+            "n_listed_host": flat("n_listed_host", count, torch.int32, pinned=True),
         })
         for f, pm in zip(self.pure_formats, b["pure_maps"]):
             pm.fill_(MIXED_TILE_FORMATS.index(f))
@@ -406,11 +446,18 @@ class GreedyPipeline:
         if trace:
             marks.append(("buffers", time.perf_counter()))
         n_el = rows * cols if numel is None else int(numel)
-        sh = b["seeds_host"].numpy()
-        sh[:] = self.seed if seeds is None else np.asarray([int(v) for v in seeds], dtype=np.int64)
+        sh = b["seeds_host"].numpy().view(np.uint64)     # the kernel reads uint64 seeds: 2^63 and above are seeds too
+        sh[:] = np.uint64(self.seed) if seeds is None else np.asarray([int(v) for v in seeds], dtype=np.uint64)
         if (sh == 0).any():
             raise ValueError("seed 0 means 'draw a random seed' in the reference; pass non-zero seeds")
         per = int(hb.lib().mtq_greedy_scan_scratch_bytes(1, tiles))
+        per_carry = int(hb.lib().mtq_scan_carry_bytes(1))
+        uniform = seeds is None or len(set(int(v) for v in seeds)) == 1
+        shared = self.shared_orders and uniform and self.metric in ("pcc", "mae")
+        plan = self.lazy_plan(x3d)   # what K1 writes now, and what the listed kernel writes later (masks by format code)
+        lazy = plan is not None
+        if lazy:
+            _lay, full_now, prev_bit, last_bit = plan
         pending = []
         cur = torch.cuda.current_stream()
         if not cur.query():                             # x3d's producer may still be running there; an idle stream needs no event + barrier packet
@@ -422,11 +469,20 @@ class GreedyPipeline:
             n = min(self.chunk, count - first)
             scan_stream = self.scan_streams[self._scan_rr]
             self._scan_rr = (self._scan_rr + 1) % len(self.scan_streams)
+            ci = first // self.chunk
+            if shared and first == 0:
+                with torch.cuda.stream(scan_stream):    # needs nothing of K1: runs beside it.  One set of orders serves every chunk of the batch
+                    hb.scan_orders_device(int(sh[0]), tiles, 2 if len(self.tile_formats) > 2 else 1, out=b["orders"])
+                    orders_ready = torch.cuda.Event()
+                    orders_ready.record(scan_stream)
             with torch.cuda.stream(self.stream):
                 e0 = torch.cuda.Event(enable_timing=True)
                 e1 = torch.cuda.Event(enable_timing=True)
                 e0.record(self.stream)
-                hb.tile_stats_batched(x3d[first:first + n], k1_mask, out=b["dev"][first:first + n])
+                if lazy:
+                    hb.tile_stats_partial(x3d[first:first + n], k1_mask, full_now, prev_bit, out=b["dev"][first:first + n])
+                else:
+                    hb.tile_stats_batched(x3d[first:first + n], k1_mask, out=b["dev"][first:first + n])
                 e1.record(self.stream)
             self.timing.events.append((e0, e1, n * tiles))
             if trace:
@@ -442,9 +498,21 @@ class GreedyPipeline:
                 b["seeds_dev"][first:first + n].copy_(b["seeds_host"][first:first + n], non_blocking=True)
                 recs = b["dev"][first:first + n]
                 maps = b["maps_dev"][first:first + n]
-                hb.greedy_scan_device(recs, dec_mask, self.tile_formats, self.metric, self.threshold, float(n_el), b["seeds_dev"][first:first + n],
-                                      maps_out=maps, status_out=b["status_dev"][first:first + n], scratch=b["scratch"][first * per:(first + n) * per],
-                                      counts_out=b["counts_dev"][first:first + n])
+                if shared and first > 0:
+                    scan_stream.wait_event(orders_ready)
+                args = (recs, dec_mask, self.tile_formats, self.metric, self.threshold, float(n_el), b["seeds_dev"][first:first + n], maps,
+                        b["status_dev"][first:first + n], b["scratch"][first * per:(first + n) * per])
+                orders = b["orders"] if shared else None
+                if lazy:
+                    xs = x3d[first:first + n]
+                    listed, nl = b["listed"][first * tiles:(first + n) * tiles], b["n_listed"][ci:ci + 1]
+                    carry = b["carry"][first * per_carry:(first + n) * per_carry]
+                    nl.zero_()
+                    hb.greedy_scan_device_ex(*args, counts_out=b["counts_dev"][first:first + n], orders=orders, phase=1, listed=listed, n_listed=nl, carry=carry)
+                    hb.tile_stats_listed(xs, k1_mask, last_bit, prev_bit, listed, nl, recs, scratch=b["lscr"][first * tiles + ci:(first + n) * tiles + ci + 1])
+                    hb.greedy_scan_device_ex(*args, counts_out=b["counts_dev"][first:first + n], phase=2, carry=carry)
+                else:
+                    hb.greedy_scan_device_ex(*args, counts_out=b["counts_dev"][first:first + n], orders=orders)
                 hb.check(hb.lib().mtq_column_sums_device_batched(recs.data_ptr(), n, tiles, dec_mask, maps.data_ptr(),
                                                                  b["sums_dev"][0, first:first + n].data_ptr(), scan_stream.cuda_stream))
                 for k, pm in enumerate(b["pure_maps"]):
@@ -461,6 +529,8 @@ class GreedyPipeline:
                 hb.device_copy(b["maps_host"][first:first + n], maps)
                 hb.device_copy(b["status_host"][first:first + n], b["status_dev"][first:first + n])
                 hb.device_copy(b["counts_host"][first:first + n], b["counts_dev"][first:first + n])
+                if lazy:
+                    hb.device_copy(b["n_listed_host"][ci:ci + 1], b["n_listed"][ci:ci + 1])
                 for q in range(b["sums_dev"].shape[0]):
                     hb.device_copy(b["sums_host"][q, first:first + n], b["sums_dev"][q, first:first + n, :7])
                 done = torch.cuda.Event(blocking=True, enable_timing=trace)
@@ -469,7 +539,7 @@ class GreedyPipeline:
             if trace:
                 self._trace_rows = getattr(self, "_trace_rows", []) + [(count, tiles, e0, e1, scanned, done, time.perf_counter())]
         enq = {"device": True, "buf": b, "pending": pending, "tiles_hw": (th, tw), "numel": n_el, "x": x3d, "dec_mask": dec_mask,
-               "seeds": sh.copy()}
+               "seeds": sh.copy(), "lazy": lazy, "k1_mask": k1_mask}
         self._open.append(enq)
         self.host_seconds["enqueue"] += time.perf_counter() - t_enq
         if trace:
@@ -509,9 +579,14 @@ class GreedyPipeline:
                 c = dict(zip(names, counts[j]))
                 cj = cols[j]
                 results.append(TensorResult(first + j, maps[j], c, mixed_tile_total_bytes(c), cj[0], cj[1], cj[2], cj[k], pure))
+            if enq.get("lazy"):
+                self.listed_tiles += int(b["n_listed_host"][first // self.chunk])
             for j in bad:   # handed back by the device scan: the host scan on this tensor's records
                 self.host_fallbacks += 1
-                full = b["dev"][first + j].cpu().numpy()
+                if enq.get("lazy"):   # the records hold only what the search had asked for so far: the whole record of this one tensor now
+                    full = hb.tile_stats_batched(enq["x"][first + j:first + j + 1], enq["k1_mask"])[0].cpu().numpy()
+                else:
+                    full = b["dev"][first + j].cpu().numpy()
                 amap, c, out = hb.greedy_run(full, enq["dec_mask"], self.tile_formats, self.metric, self.threshold, n_el, int(enq["seeds"][first + j]))
                 r = results[len(results) - n + j]
                 r.assignment, r.counts, r.tile_bytes = amap.reshape(th, tw), c, mixed_tile_total_bytes(c)
