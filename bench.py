@@ -4,11 +4,18 @@
 Step  = one pass of the hot path (K1 tile_stats + the sequential greedy scan, both on the GPU by default [--scan host: stats
         D2H + host scan threads] → per-tile assignment maps + pcc/mae/atol on the host) over a batch of `--tensors` (128) synthetic 4096x4096 bf16 tensors
         (BASELINE.json configs[1], streamed; the batch is > 256 MiB so the Infinity Cache cannot hold it).
-value = tiles/s, whole job, inputs resident in HBM when the timed region starts.
+value = tiles/s, whole job, inputs resident in HBM when the timed region starts; the median of `--regions` (3) timed regions of
+        `--steps` steps each, every region bracketed by barrier + synchronize (a 20-step region lasts 50 ms: one scheduling hiccup of
+        the host moved a single region by 5 %).
 roofline = the K1 kernel alone: algorithmic 2048 B read per tile / HIP-event launch duration vs 8 TB/s.
 cpu_baseline = the C oracle (oracle/, a port of the reference's CPU path) on rank 0's host, 1 thread, on a bounded sample of
         the same tensors; cpu_baseline_threads = the same port on every core of the rank's CPU quota; cpu_baseline_emulation =
         the NumPy host backend (how the reference executes) on one tensor.
+extra   = one leg per further BASELINE.json config, N = 1 only (--legs none skips them): the single-tensor latency of configs[1],
+        mixed-tile-threshold and the 50-step sweep on the DeepSeek-R1 layer-0 shapes (configs[2], [4]), the 224 Llama-3-8B tensors
+        through the streamed pipeline (configs[3]).
+--workload llama3-8b: configs[3] as the step — 224 synthetic tensors, drawn on the device, LPT-sharded over the N ranks, one RCCL
+        gather of the summary rows: strong scaling (the total work is fixed).
 
   python bench.py --gpus 1 --steps 5 --warmup 1
   python bench.py --gpus N ...            (N > 1, not under a launcher: starts its own N ranks before any GPU call)
@@ -33,6 +40,7 @@ FORMATS = ["bf16", "bfp8", "bfp4", "bfp2"]
 METRIC, THRESHOLD, SEED = "pcc", 0.999, 123
 HBM_PEAK_GBS = 8000.0          # MI355X spec, /opt/skills/guides/MI355X_MICROARCH.md
 BYTES_PER_TILE_READ = 2048     # 32*32 bf16, SURVEY §8(d)
+METRIC_NAME = "32x32 tiles/s for mixed-tile-greedy (bf16->BFP{8,4,2}); achieved HBM GB/s vs peak"
 
 
 def make_batch(n: int, rank: int, device) -> torch.Tensor:
@@ -107,14 +115,21 @@ def cpu_baseline(sample: torch.Tensor, threads: int) -> dict:
 def gather_summary(rows: torch.Tensor, seconds: float, dist, rank: int, world: int):
     """The job's only data-path collective: every rank's fixed-width float64 summary rows to rank 0, and the
     MAX over ranks of the timed region.  → (all rows as ndarray on rank 0 else None, max seconds).  Works on any backend
-    (RCCL for the GPU job, gloo in the CPU test)."""
+    (RCCL for the GPU job, gloo in the CPU test).  Ranks may hold different numbers of rows (a model's shards): the counts go first."""
     t_max = torch.tensor([seconds], dtype=torch.float64, device=rows.device)
     if dist is None:
         return rows.cpu().numpy(), seconds
-    gathered = [torch.empty_like(rows) for _ in range(world)] if rank == 0 else None
-    dist.gather(rows, gathered, dst=0)
+    counts = [torch.zeros((1,), dtype=torch.int64, device=rows.device) for _ in range(world)]
+    dist.all_gather(counts, torch.tensor([rows.shape[0]], dtype=torch.int64, device=rows.device))
+    most = max(int(c.item()) for c in counts)
+    padded = torch.zeros((most, rows.shape[1]), dtype=rows.dtype, device=rows.device)
+    padded[: rows.shape[0]] = rows
+    gathered = [torch.empty_like(padded) for _ in range(world)] if rank == 0 else None
+    dist.gather(padded, gathered, dst=0)
     dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
-    return (torch.cat(gathered).cpu().numpy() if rank == 0 else None), float(t_max.item())
+    if rank != 0:
+        return None, float(t_max.item())
+    return torch.cat([g[: int(c.item())] for g, c in zip(gathered, counts)]).cpu().numpy(), float(t_max.item())
 
 
 from quantization_analysis_amd.pipeline import cpu_budget, default_workers  # noqa: E402  (no GPU call at import)
@@ -137,9 +152,46 @@ def self_launch(n: int, argv: list[str]) -> int:
     return subprocess.run(cmd, env=env).returncode
 
 
+# ---------------------------------------------------------------------------------------------------------------------------------
+# configs[3]: Llama-3-8B, all model.layers.* linear weights (224 tensors), sharded over the ranks
+# ---------------------------------------------------------------------------------------------------------------------------------
+MAX_BATCH_TILES = 1 << 21      # tiles per pipeline batch (streamed.py)
+
+
+def llama_shard(rank: int, world: int):
+    """→ (index, names of all 224 tensors, this rank's tensor indices, {(rows, cols): [tensor idx]} of the shard).  Pure host work:
+    every rank computes the same LPT partition (model_source.lpt_shards) without communication (wq:655)."""
+    from quantization_analysis_amd import model_source as ms
+
+    index = ms.build_model_index("synthetic:llama3-8b")
+    names = ms.resolve_selected_tensors(index, "model.layers")
+    mine = ms.lpt_shards(names, index.numel, world)[rank]
+    groups: dict = {}
+    for i in mine:
+        shape, _dtype = index.shape_dtype(names[i])
+        groups.setdefault((int(shape[0]), int(shape[1])), []).append(i)
+    return index, names, mine, groups
+
+
+def llama_batches(index, names, groups, device):
+    """The shard's tensors drawn on the device (one seeded generator call per tensor) and stacked per shape into pipeline batches
+    of at most MAX_BATCH_TILES tiles, largest tensors first (their scans are the long poles).  → [(tensor indices, x3d)]."""
+    out = []
+    for (rows, cols), idxs in sorted(groups.items(), key=lambda kv: -(kv[0][0] * kv[0][1])):
+        per = max(1, MAX_BATCH_TILES // ((rows // 32) * (cols // 32)))
+        for b0 in range(0, len(idxs), per):
+            part = idxs[b0:b0 + per]
+            out.append((part, torch.stack([index.load(names[i], device=device, draw_on_device=True) for i in part])))
+    return out
+
+
+def tiles_of(x3d) -> int:
+    return x3d.shape[0] * -(-x3d.shape[1] // 32) * -(-x3d.shape[2] // 32)
+
+
 def dry_run(args) -> None:
-    """--dry-run: the rank plumbing of this file with no GPU and no measurement (CPU test of the launcher branch and of the
-    job's only collective): gloo instead of RCCL, made-up summary rows, `value` null."""
+    """--dry-run: the rank plumbing of this file with no GPU and no measurement (CPU test of the launcher branch, of the model
+    workload's sharding and of the job's only collective): gloo instead of RCCL, made-up summary rows, `value` null."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     dist = None
@@ -147,15 +199,214 @@ def dry_run(args) -> None:
         import torch.distributed as dist
 
         dist.init_process_group("gloo")
-    rows = torch.full((2, 11), float(rank), dtype=torch.float64)
-    all_rows, dt = gather_summary(rows, 1.0 + rank, dist, rank, world)
-    if rank == 0:
-        print(json.dumps({"dry_run": True, "value": None, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-                          "ranks_seen": sorted({int(v) for v in all_rows[:, 1]}), "max_seconds": dt,
-                          "config": {"sharding": f"tensors x{world}, RCCL gather of summary rows"}}), flush=True)
+    if args.workload == "llama3-8b":
+        index, names, mine, groups = llama_shard(rank, world)
+        rows = torch.tensor([[i, index.numel(names[i]), 1.0, 0.0, 0.0, 0.0, 0, 0, 0, 0, float(rank)] for i in mine], dtype=torch.float64)
+        all_rows, dt = gather_summary(rows, 1.0 + rank, dist, rank, world)
+        if rank == 0:
+            per_rank = [int((all_rows[:, 10] == r).sum()) for r in range(world)]
+            numel = [float(all_rows[all_rows[:, 10] == r, 1].sum()) for r in range(world)]
+            print(json.dumps({"dry_run": True, "value": None, "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "scaling": "strong",
+                              "tensors": int(all_rows.shape[0]), "tensors_seen_once": len(set(all_rows[:, 0].tolist())) == len(names) == int(all_rows.shape[0]),
+                              "tensors_per_rank": per_rank, "imbalance": max(numel) / (sum(numel) / world), "max_seconds": dt,
+                              "config": {"workload": "llama3-8b", "sharding": f"224 tensors LPT over {world} ranks, RCCL gather of summary rows"}}), flush=True)
+    else:
+        rows = torch.full((2, 11), float(rank), dtype=torch.float64)
+        all_rows, dt = gather_summary(rows, 1.0 + rank, dist, rank, world)
+        if rank == 0:
+            print(json.dumps({"dry_run": True, "value": None, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                              "ranks_seen": sorted({int(v) for v in all_rows[:, 1]}), "max_seconds": dt,
+                              "config": {"sharding": f"tensors x{world}, RCCL gather of summary rows"}}), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def median(v):
+    s = sorted(v)
+    return s[len(s) // 2] if len(s) % 2 else 0.5 * (s[len(s) // 2 - 1] + s[len(s) // 2])
+
+
+def timed(fn, reps: int = 5):
+    """median wall milliseconds of fn() (synchronised), after one untimed call."""
+    fn()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        fn()
+        torch.cuda.synchronize()
+        ts.append((time.perf_counter() - t0) * 1e3)
+    return median(ts), ts
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# extra legs (N = 1): one driver-run number per BASELINE.json config beside the headline
+# ---------------------------------------------------------------------------------------------------------------------------------
+def leg_latency(sample, device) -> dict:
+    """configs[1] as written — ONE 4096x4096 bf16 tensor: the plug-in call the reference times (wq:680-682: perf_counter around
+    algo.run, y materialised) through Quantizer("hip"), and the same search through the streamed pipeline with a batch of one."""
+    from quantization_analysis_amd import hip_backend as hb
+    from quantization_analysis_amd.compression_algorithms import create_algorithm
+    from quantization_analysis_amd.compression_algorithms.cache import CacheContext
+    from quantization_analysis_amd.compression_algorithms.quantizer import Quantizer
+    from quantization_analysis_amd.pipeline import GreedyPipeline
+
+    x = sample[0]
+    cache = CacheContext(ROOT / "gpurun_out" / "bench-cache", "bench", "hip", True, "bench")
+    algo = create_algorithm("mixed-tile-greedy", {"metric": METRIC, "threshold": THRESHOLD, "seed": SEED})
+    q = Quantizer("hip")
+    run_ms, _ = timed(lambda: algo.run(x, FORMATS, q, cache))
+    with GreedyPipeline(FORMATS, METRIC, THRESHOLD, SEED, chunk=1, workers=2) as pipe:
+        one = x[None]
+        pipe.reserve(one)
+        pipe_ms, _ = timed(lambda: pipe.run(one))
+        route = "lazy" if pipe.lazy_plan(one) is not None else "whole records"
+    k1_ms, _ = timed(lambda: hb.tile_stats_batched(one, 0xE))
+    return {"workload": "one 4096x4096 bf16 tensor, mixed-tile-greedy {bf16,bfp8,bfp4,bfp2} pcc>=0.999 seed 123 (BASELINE.json configs[1])",
+            "algo_run_ms": run_ms, "pipeline_batch_of_one_ms": pipe_ms, "pipeline_route": route, "k1_whole_records_ms": k1_ms, "tiles": 16384,
+            "note": "median of 5 wall-clock calls each, synchronised; algo.run = the plug-in seam (K1, search, K3 for y), what wq:680-682 times"}
+
+
+def deepseek_tensors(device):
+    from quantization_analysis_amd import model_source as ms
+
+    index = ms.build_model_index("synthetic:deepseek-r1-layer0")
+    names = ms.resolve_selected_tensors(index, "model.layers.0.self_attn")
+    return names, [index.load(n, device=device, draw_on_device=True) for n in names]
+
+
+def leg_threshold(device) -> dict:
+    """configs[2]: mixed-tile-threshold over the seven DeepSeek-R1 model.layers.0.self_attn tensors (five float32 matrices after the
+    fp8 x scale dequantisation, two bf16 vectors) — K1 (tile_stats_direct for float32 storage) + K4 on the device + the knife-edge
+    re-score, through the streamed ThresholdPipeline (matrices) and the plug-in call (vectors)."""
+    from quantization_analysis_amd import hip_backend as hb
+    from quantization_analysis_amd.compression_algorithms import create_algorithm
+    from quantization_analysis_amd.compression_algorithms.quantizer import Quantizer
+    from quantization_analysis_amd.pipeline import ThresholdPipeline
+
+    names, xs = deepseek_tensors(device)
+    q = Quantizer("hip")
+    algo = create_algorithm("mixed-tile-threshold", {"metric": "pcc", "threshold": THRESHOLD, "materialize_y": False})
+    mats = [x for x in xs if x.dim() == 2]
+    vecs = [x for x in xs if x.dim() != 2]
+    tiles = sum(-(-x.shape[0] // 32) * -(-x.shape[1] // 32) for x in mats) + sum(-(-x.numel() // 1024) for x in vecs)
+    with ThresholdPipeline(FORMATS, "pcc", THRESHOLD, chunk=1) as pipe:
+        def once():
+            for x in mats:
+                pipe.run(x[None])
+            for v in vecs:
+                algo.run(v, FORMATS, q, None)
+
+        ms_, _ = timed(once, reps=5)
+        knife = pipe.knife_tiles // 6
+    # the float32 K1 alone on the matrices (HIP events): its share of the 4096 B/tile read roofline
+    f32 = [x for x in mats if x.dtype == torch.float32]
+    f32_tiles = sum(-(-x.shape[0] // 32) * -(-x.shape[1] // 32) for x in f32)
+    outs = [hb.tile_stats_batched(x[None], 0xF) for x in f32]
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(5):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for x, o in zip(f32, outs):
+            hb.tile_stats_batched(x[None], 0xF, out=o)
+        e1.record()
+        e1.synchronize()
+        ts.append(e0.elapsed_time(e1))
+    k1 = median(ts)
+    return {"workload": f"DeepSeek-R1 model.layers.0.self_attn, {len(xs)} tensors ({len(mats)} matrices, {len(vecs)} vectors), mixed-tile-threshold pcc>=0.999 (BASELINE.json configs[2])",
+            "value": tiles / (ms_ * 1e-3), "unit": "tiles/s", "ms": ms_, "tiles": tiles, "knife_edge_tiles": knife,
+            "roofline": {"bound": "hbm", "kernel": "tile_stats_direct<float, 15> (K1, float32 storage)", "achieved": 4096 * f32_tiles / (k1 * 1e-3) / 1e9,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": 4096 * f32_tiles / (k1 * 1e-3) / 1e9 / HBM_PEAK_GBS, "launch_ms": k1, "tiles": f32_tiles,
+                         "traffic": None, "note": "4096 B read per float32 tile; the five matrices back to back, HIP events"}}
+
+
+def leg_sweep(device) -> dict:
+    """configs[4]: the 50-step pcc-threshold sweep + pareto front (scripts/sweep_mixed_tile_threshold.py's core, sweep.sweep_tensor)
+    over the same DeepSeek-R1 layer-0 tensors: ONE K1 pass per tensor, every step a selection + sum of records."""
+    from quantization_analysis_amd.compression_algorithms.quantizer import Quantizer
+    from quantization_analysis_amd.sweep import pareto_frontier, sweep_tensor
+
+    names, xs = deepseek_tensors(device)
+    q = Quantizer("hip")
+    steps = 50
+    state = {}
+
+    def once():
+        state["rows"] = [sweep_tensor(x, FORMATS, "pcc", 0.9, steps, q)[0] for x in xs]
+
+    ms_, _ = timed(once, reps=3)
+    front = [len(pareto_frontier([{"size": r["size_bytes"], "metric": r["pcc"]} for r in rows], "pcc")) for rows in state["rows"]]
+    tiles = sum((-(-x.shape[0] // 32) * -(-x.shape[1] // 32)) if x.dim() == 2 else -(-x.numel() // 1024) for x in xs)
+    return {"workload": f"DeepSeek-R1 model.layers.0.self_attn, {len(xs)} tensors, {steps}-step pcc-threshold sweep + pareto (BASELINE.json configs[4])",
+            "value": tiles * steps / (ms_ * 1e-3), "unit": "tile-steps/s", "ms": ms_, "tiles": tiles, "steps": steps, "pareto_points_per_tensor": front}
+
+
+def leg_llama(device) -> dict:
+    """configs[3] on one GPU: the 224 Llama-3-8B linear weights (drawn on the device: the loader is reported, not measured with the
+    pipeline) through GreedyPipeline.run_batches, shape group by shape group — the --workload llama3-8b step with N = 1."""
+    from quantization_analysis_amd.pipeline import GreedyPipeline
+
+    index, names, mine, groups = llama_shard(0, 1)
+    t0 = time.perf_counter()
+    batches = llama_batches(index, names, groups, device)
+    torch.cuda.synchronize()
+    load_s = time.perf_counter() - t0
+    xs = [x for _p, x in batches]
+    tiles = sum(tiles_of(x) for x in xs)
+    with GreedyPipeline(FORMATS, METRIC, THRESHOLD, SEED, chunk=1 << 30, workers=default_workers(), scan_streams=8) as pipe:
+        pipe.SLOTS = max(pipe.SLOTS, min(len(xs), 8))
+        pipe.prepare(xs)
+        ms_, all_ms = timed(lambda: pipe.run_batches(xs), reps=5)
+        pipe.timing.drain()
+        k1_ms, k1_tiles = pipe.timing.kernel_ms, pipe.timing.tiles
+        res = pipe.run_batches(xs)
+        fallbacks = pipe.host_fallbacks
+    counts = [sum(r.counts[f] for rs in res for r in rs) for f in FORMATS]
+    return {"workload": "Llama-3-8B model.layers.* linear weights, 224 bf16 tensors (6.8 M tiles, 14 GB), mixed-tile-greedy pcc>=0.999 seed 123 (BASELINE.json configs[3]) on ONE GPU",
+            "value": tiles / (ms_ * 1e-3), "unit": "tiles/s", "pipeline_ms": ms_, "pipeline_ms_all": all_ms, "tiles": tiles, "tensors": len(mine), "batches": len(xs),
+            "loader_seconds": load_s, "loader": "synthetic tensors drawn on the device, one seeded generator call per tensor",
+            "k1_tiles_per_s": k1_tiles / max(k1_ms, 1e-9) * 1e3, "host_fallbacks": fallbacks, "counts_bf16_bfp8_bfp4_bfp2": counts}
+
+
+def run_legs(sample, device) -> dict:
+    out = {}
+    for name, fn in (("latency_single_tensor", lambda: leg_latency(sample, device)), ("threshold_deepseek_layer0", lambda: leg_threshold(device)),
+                     ("sweep_deepseek_layer0", lambda: leg_sweep(device)), ("llama3_8b", lambda: leg_llama(device))):
+        t0 = time.perf_counter()
+        try:
+            out[name] = fn()
+            out[name]["leg_seconds"] = time.perf_counter() - t0
+        except Exception as exc:  # noqa: BLE001 — a leg that fails is reported, the headline line still comes out
+            out[name] = {"error": f"{type(exc).__name__}: {exc}"}
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+    return out
+
+
+def k1_profile_blocks(tiles_per_launch: float, k_ms: float):
+    """traffic / VALU blocks of the roofline object from the committed PMC passes (profiles/k1_traffic.json, k1_valu.json)."""
+    traffic = traffic_source = valu = None
+    tfile = ROOT / "profiles" / "k1_traffic.json"  # HBM bytes per launch from a separate rocprofv3 --pmc pass
+    if tfile.exists():
+        try:
+            t = json.loads(tfile.read_text())
+            traffic = t.get("hbm_bytes_per_tile") * tiles_per_launch  # measured B/tile x tiles of this run's launches
+            traffic_source = t.get("source", "profiles/k1_traffic.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, B/tile x this run's tiles per launch)")
+        except Exception:
+            traffic = None
+    vfile = ROOT / "profiles" / "k1_valu.json"   # VALU instructions per tile from a separate rocprofv3 --pmc pass
+    if vfile.exists():
+        try:
+            v = json.loads(vfile.read_text())
+            valu = {"valu_insts_per_tile": v["valu_insts_per_tile"], "avg_issue_cycles_per_inst": v["avg_issue_cycles_per_inst"],
+                    "valu_frac": v["valu_insts_per_tile"] * tiles_per_launch / v["simds"] * v["avg_issue_cycles_per_inst"] / (k_ms * 1e-3 * v["clock_hz"]),
+                    "note": "share of the launch during which every SIMD's VALU issue port is taken (instructions per SIMD x issue cost / launch "
+                            "time at 2.4 GHz): the kernel is VALU-issue bound, not HBM bound", "source": "profiles/k1_valu.json"}
+        except Exception:
+            valu = None
+    return traffic, traffic_source, valu
 
 
 def main() -> None:
@@ -163,12 +414,17 @@ def main() -> None:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--regions", type=int, default=3, help="timed regions of --steps steps each; value is their median")
+    ap.add_argument("--workload", choices=["m1", "llama3-8b"], default="m1",
+                    help="m1: 128 x 4096x4096 bf16 per GPU per step (BASELINE.json configs[1], weak scaling); llama3-8b: the 224 linear weights of "
+                         "Llama-3-8B sharded over the ranks (configs[3], strong scaling)")
     ap.add_argument("--tensors", type=int, default=128, help="4096x4096 bf16 tensors per step per GPU (128 = 4 GiB, SURVEY §8(d) M1 stream)")
     ap.add_argument("--chunk", type=int, default=None,
                     help="tensors per K1 launch (default: the whole step's batch with the scan on the device — one K1 launch and one scan launch per "
                          "step; 32 with the host scan, where a chunk's records cross PCIe while the next chunk's K1 runs)")
     ap.add_argument("--workers", type=int, default=default_workers(), help="host scan threads per rank (default: this rank's share of the cgroup CPU quota / affinity mask, at most 32)")
     ap.add_argument("--cpu-sample", type=int, default=24, help="tensors timed on the CPU port, ~0.5 s each (0 = skip)")
+    ap.add_argument("--legs", choices=["all", "none"], default="all", help="the extra legs (other BASELINE configs), rank 0 at N = 1 only")
     ap.add_argument("--scan", choices=["auto", "host", "device"], default="auto",
                     help="where the sequential greedy scan runs: device (csrc/mtq_scan.hip, records never leave the GPU), host (records over PCIe, "
                          "host scan threads), auto = device where it serves the search")
@@ -199,21 +455,104 @@ def main() -> None:
         dist.init_process_group("nccl", device_id=device)  # nccl == RCCL on ROCm
 
     from quantization_analysis_amd import hip_backend as hb
-    from quantization_analysis_amd.pipeline import GreedyPipeline
 
     hb.require_gpu()
-    batch = make_batch(args.tensors, rank, device)
-    pipe = GreedyPipeline(FORMATS, METRIC, THRESHOLD, SEED, chunk=args.chunk or 32, workers=args.workers, scan=args.scan)
-    if args.chunk is None:
-        args.chunk = args.tensors if pipe.device_scan else 32
-    pipe.chunk = args.chunk
-    tiles_per_step = args.tensors * (ROWS // 32) * (COLS // 32)
 
     def barrier():
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
+
+    if args.workload == "llama3-8b":
+        run_llama_workload(args, dist, rank, world, device, barrier, numa)
+    else:
+        run_m1_workload(args, dist, rank, world, device, barrier, numa)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    hb.shutdown()   # the library's threads, events and device tables go while the HIP runtime is still there (also registered with atexit)
+
+
+def run_llama_workload(args, dist, rank, world, device, barrier, numa) -> None:
+    """configs[3] as the step: every rank streams its LPT shard of the 224 tensors (resident in HBM, drawn on the device before the
+    timed region), shape group by shape group; one gather of the summary rows.  Strong scaling: the model is the job."""
+    import gc
+
+    from quantization_analysis_amd.pipeline import GreedyPipeline
+
+    index, names, mine, groups = llama_shard(rank, world)
+    t0 = time.perf_counter()
+    batches = llama_batches(index, names, groups, device)
+    torch.cuda.synchronize()
+    load_s = time.perf_counter() - t0
+    xs = [x for _p, x in batches]
+    my_tiles = sum(tiles_of(x) for x in xs)
+    pipe = GreedyPipeline(FORMATS, METRIC, THRESHOLD, SEED, chunk=1 << 30, workers=args.workers, scan=args.scan, scan_streams=8)
+    pipe.SLOTS = max(pipe.SLOTS, min(len(xs), 8))
+    pipe.prepare(xs)
+    gc.collect()
+    gc.freeze()
+    res = None
+    for _ in range(max(1, args.warmup)):
+        res = pipe.run_batches(xs)
+    pipe.timing.drain()
+    pipe.timing.__init__()
+    region_s, my_region_s = [], []
+    for _ in range(max(1, args.regions)):
+        barrier()
+        t0 = time.perf_counter()
+        for _s in range(args.steps):
+            res = pipe.run_batches(xs)
+        torch.cuda.synchronize()
+        mine_dt = time.perf_counter() - t0
+        barrier()
+        my_region_s.append(mine_dt)
+        region_s.append(time.perf_counter() - t0)
+    pipe.timing.drain()
+    mid = sorted(range(len(region_s)), key=lambda i: region_s[i])[len(region_s) // 2]
+    rows = torch.tensor([[i, index.numel(names[i]), r.pcc, r.mae, r.atol, r.tile_bytes, r.counts["bf16"], r.counts["bfp8"], r.counts["bfp4"], r.counts["bfp2"], float(rank)]
+                         for (part, _x), rs in zip(batches, res) for i, r in zip(part, rs)], dtype=torch.float64, device=device)
+    all_rows, dt = gather_summary(rows, region_s[mid], dist, rank, world)
+    per_rank = torch.tensor([my_region_s[mid], float(my_tiles), load_s], dtype=torch.float64, device=device)
+    if dist is not None:
+        allp = [torch.empty_like(per_rank) for _ in range(world)]
+        dist.all_gather(allp, per_rank)
+        per_rank_all = torch.stack(allp).cpu().numpy()
+    else:
+        per_rank_all = per_rank[None].cpu().numpy()
+    if rank == 0:
+        total_tiles = int(per_rank_all[:, 1].sum())
+        kt = pipe.timing
+        secs = per_rank_all[:, 0] / args.steps
+        frac = BYTES_PER_TILE_READ * kt.tiles / max(kt.kernel_ms, 1e-9) / 1e6 / HBM_PEAK_GBS
+        out = {"metric": METRIC_NAME, "value": total_tiles * args.steps / dt, "unit": "tiles/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u32/f64", "data": "synthetic",
+               "config": {"workload": "Llama-3-8B model.layers.* linear weights: 224 synthetic bf16 tensors (6.8 M tiles, 14 GB) drawn on the device, mixed-tile-greedy "
+                                      "{bf16,bfp8,bfp4,bfp2} pcc>=0.999 seed 123 (BASELINE.json configs[3]); a step = the whole model once",
+                          "sharding": f"224 tensors LPT by element count over {world} ranks (model_source.lpt_shards), RCCL gather of summary rows",
+                          "tensors": int(all_rows.shape[0]), "tiles": total_tiles, "regions_ms_per_step": [s / args.steps * 1e3 for s in region_s],
+                          "per_rank_pipeline_ms_per_step": (secs * 1e3).tolist(), "per_rank_tiles": per_rank_all[:, 1].astype(int).tolist(),
+                          "imbalance_tiles": float(per_rank_all[:, 1].max() / per_rank_all[:, 1].mean()), "imbalance_time": float(secs.max() / secs.mean()),
+                          "loader_seconds_per_rank": per_rank_all[:, 2].tolist(), "scan": "device (csrc/mtq_scan.hip)" if pipe.device_scan else "host",
+                          "host_fallbacks": pipe.host_fallbacks, "numa_bind": numa},
+               "roofline": {"bound": "hbm", "kernel": "tile_stats (K1)", "achieved": frac * HBM_PEAK_GBS, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": frac, "traffic": None,
+                            "launches": kt.launches, "note": "rank 0's K1 launches of the timed regions (HIP events), all shape groups together"},
+               "summary": {"tensors": int(all_rows.shape[0]), "mean_pcc": float(all_rows[:, 2].mean()),
+                           "counts_bf16_bfp8_bfp4_bfp2": [int(all_rows[:, 6 + i].sum()) for i in range(4)]}}
+        print(json.dumps(out), flush=True)
+    pipe.close()
+
+
+def run_m1_workload(args, dist, rank, world, device, barrier, numa) -> None:
+    from quantization_analysis_amd.pipeline import GreedyPipeline
+
+    batch = make_batch(args.tensors, rank, device)
+    pipe = GreedyPipeline(FORMATS, METRIC, THRESHOLD, SEED, chunk=args.chunk or 32, workers=args.workers, scan=args.scan)
+    if args.chunk is None:
+        args.chunk = args.tensors if pipe.device_scan else 32
+    pipe.chunk = args.chunk
+    tiles_per_step = args.tensors * (ROWS // 32) * (COLS // 32)
 
     # K1 alone (no scan, no copies beside it): the same launch the steps issue, HIP events on the current stream
     alone_out = pipe.launch_k1(batch[: args.chunk])     # the launch the route issues (round 3: partial records on the lazy route)
@@ -228,7 +567,7 @@ def main() -> None:
         alone.append(a0.elapsed_time(a1))
     k1_alone_ms = sorted(alone)[len(alone) // 2]
     del alone_out
-    pipe.reserve(batch)  # record buffers of both slots + scan threads: allocations, not steps
+    pipe.reserve(batch)  # record buffers of every slot + scan threads: allocations, not steps
     # a generation-2 collection of the interpreter's heap (torch's module graph: ~40 ms here) would land inside a 7 ms
     # step every few dozen steps: collect now and move what exists to the permanent generation.  BEFORE the warm-up steps, not
     # between them and the timed ones: the GPU idles while the collector runs, its clocks fall, and the first six launches of the
@@ -240,46 +579,42 @@ def main() -> None:
     res = pipe.run_steps(batch for _ in range(args.warmup))
     pipe.timing.drain()
     pipe.timing.__init__()
-    barrier()
-    cpu0 = time.process_time()
-    t0 = time.perf_counter()
-    res = pipe.run_steps(batch for _ in range(args.steps))  # every step fully processed; step s+1's GPU work overlaps step s's scan tail
-    barrier()
-    dt = time.perf_counter() - t0
-    host_cpu_ms = (time.process_time() - cpu0) / args.steps * 1e3   # CPU time of every thread of this rank, per step
+    regions, cpu_ms = [], []
+    for _ in range(max(1, args.regions)):   # every region: exactly --steps steps between two barriers; every step fully processed
+        barrier()
+        cpu0 = time.process_time()
+        t0 = time.perf_counter()
+        res = pipe.run_steps(batch for _ in range(args.steps))  # step s+1's GPU work overlaps step s's scan tail
+        barrier()
+        regions.append(time.perf_counter() - t0)
+        cpu_ms.append((time.process_time() - cpu0) / args.steps * 1e3)   # CPU time of every thread of this rank, per step
     pipe.timing.drain()
+    mid = sorted(range(len(regions)), key=lambda i: regions[i])[len(regions) // 2]
+    host_cpu_ms = cpu_ms[mid]
 
     # the only data-path collective: per-tensor summary rows to rank 0; outside the timed steps
     # the rows of the LAST step are gathered so the multi-GPU path is exercised end to end.
     rows = torch.tensor([[r.index, ROWS * COLS, r.pcc, r.mae, r.atol, r.tile_bytes, r.counts["bf16"], r.counts["bfp8"],
                           r.counts["bfp4"], r.counts["bfp2"], 0.0] for r in res], dtype=torch.float64, device=device)
-    all_rows, dt = gather_summary(rows, dt, dist, rank, world)
+    all_rows, dt = gather_summary(rows, regions[mid], dist, rank, world)
+    if dist is not None:   # every region's MAX over ranks, for the record
+        rt = torch.tensor(regions, dtype=torch.float64, device=device)
+        dist.all_reduce(rt, op=dist.ReduceOp.MAX)
+        regions_max = rt.cpu().tolist()
+    else:
+        regions_max = list(regions)
 
+    out = None
     if rank == 0:
         kt = pipe.timing
         k_ms = kt.kernel_ms / max(kt.launches, 1)
         tiles_per_launch = kt.tiles / max(kt.launches, 1)
         achieved = BYTES_PER_TILE_READ * tiles_per_launch / (k_ms * 1e-3) / 1e9
-        traffic = None
-        tfile = ROOT / "profiles" / "k1_traffic.json"  # HBM bytes per launch from a separate rocprofv3 --pmc pass
-        if tfile.exists():
-            try:
-                traffic = json.loads(tfile.read_text()).get("hbm_bytes_per_tile") * tiles_per_launch  # measured B/tile x tiles of this run's launches
-            except Exception:
-                traffic = None
-        valu = None
-        vfile = ROOT / "profiles" / "k1_valu.json"   # VALU instructions per tile from a separate rocprofv3 --pmc pass
-        if vfile.exists():
-            try:
-                v = json.loads(vfile.read_text())
-                valu = {"valu_insts_per_tile": v["valu_insts_per_tile"], "avg_issue_cycles_per_inst": v["avg_issue_cycles_per_inst"],
-                        "valu_frac": v["valu_insts_per_tile"] * tiles_per_launch / v["simds"] * v["avg_issue_cycles_per_inst"] / (k_ms * 1e-3 * v["clock_hz"]),
-                        "note": "share of the launch during which every SIMD's VALU issue port is taken (instructions per SIMD x issue cost / launch "
-                                "time at 2.4 GHz): the kernel is VALU-issue bound, not HBM bound", "source": "profiles/k1_valu.json"}
-            except Exception:
-                valu = None
+        traffic, traffic_source, valu = k1_profile_blocks(tiles_per_launch, k_ms)
+        lazy = pipe.lazy_plan(batch[: args.chunk]) is not None
+        total_steps = args.steps * len(regions)
         out = {
-            "metric": "32x32 tiles/s for mixed-tile-greedy (bf16->BFP{8,4,2}); achieved HBM GB/s vs peak",
+            "metric": METRIC_NAME,
             "value": world * args.steps * tiles_per_step / dt,
             "unit": "tiles/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -289,16 +624,20 @@ def main() -> None:
             "config": {"workload": f"{args.tensors} x 4096x4096 bf16 N(0,0.02^2) per GPU per step, mixed-tile-greedy "
                                    f"{{bf16,bfp8,bfp4,bfp2}} pcc>=0.999 seed 123 (BASELINE.json configs[1], streamed)",
                        "tensors_per_step_per_gpu": args.tensors, "tiles_per_step_per_gpu": tiles_per_step,
+                       "regions": len(regions), "regions_tiles_per_s": [world * args.steps * tiles_per_step / s for s in regions_max],
+                       "value_is": "the median region (each region = exactly --steps steps between barrier + synchronize)",
                        "k1_chunk": args.chunk, "scan": "device (csrc/mtq_scan.hip)" if pipe.device_scan else f"host ({args.workers} threads)",
+                       "route": ("lazy: K1 evaluates bfp8 (five statistics) and bfp4 (three sums); the search stops before its last pass, the listed kernel evaluates bfp2 and "
+                                 "bfp4's error statistics for that pass's candidates, the last pass follows (DESIGN.md §4)") if lazy else "whole records",
+                       "listed_tiles_per_step": pipe.listed_tiles / max(total_steps + args.warmup, 1), "shared_visiting_orders": bool(pipe.shared_orders and pipe.device_scan),
                        "host_cpu_ms_per_step": host_cpu_ms, "host_fallbacks": pipe.host_fallbacks,
-                       "driver_thread_ms_per_step": {k: v / (args.steps + args.warmup) * 1e3 for k, v in pipe.host_seconds.items()}, "scan_workers": args.workers, "numa_bind": numa, "sharding": f"tensors x{world}, RCCL gather of summary rows"},
-            "roofline": {"bound": "hbm", "kernel": "tile_stats (K1)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "traffic_source": "profiles/k1_traffic.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, B/tile x this run's tiles per launch)" if traffic is not None else None,
+                       "driver_thread_ms_per_step": {k: v / (total_steps + args.warmup) * 1e3 for k, v in pipe.host_seconds.items()}, "scan_workers": args.workers, "numa_bind": numa, "sharding": f"tensors x{world}, RCCL gather of summary rows"},
+            "roofline": {"bound": "hbm", "kernel": "tile_stats (K1)" + (": tile_stats_bf16_rolled<3, 1> (partial records)" if lazy else ""), "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                          "launch_ms": k_ms, "tiles_per_launch": tiles_per_launch, "launches": kt.launches,
                          "kernel_tiles_per_s": tiles_per_launch / (k_ms * 1e-3),
-                         "note": "launch_ms / achieved / frac: HIP events around the K1 launches of the timed region, i.e. with the previous steps' scan "
-                                 "kernels (one wave per tensor) and copies running beside them; kernel_alone: the same launch with nothing beside it",
+                         "note": "launch_ms / achieved / frac: HIP events around the K1 launches of the timed regions, i.e. with the earlier steps' search kernels (two "
+                                 "waves per tensor), the listed K1 and the column sums running beside them; kernel_alone: the same launch with nothing beside it",
                          "kernel_alone": {"launch_ms": k1_alone_ms, "achieved": BYTES_PER_TILE_READ * args.chunk * (ROWS // 32) * (COLS // 32) / (k1_alone_ms * 1e-3) / 1e9,
                                           "frac": BYTES_PER_TILE_READ * args.chunk * (ROWS // 32) * (COLS // 32) / (k1_alone_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
                          "valu": valu},
@@ -307,11 +646,14 @@ def main() -> None:
         }
         if args.cpu_sample > 0 and world == 1:   # the CPU legs are a N = 1 report: the other ranks would wait in the barrier below
             out.update(cpu_baseline(batch[: min(args.cpu_sample, args.tensors)], cpu_budget()))
-        print(json.dumps(out), flush=True)
     pipe.close()
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    if rank == 0:
+        if args.legs == "all" and world == 1:
+            sample = batch[:1].clone()
+            del batch
+            torch.cuda.empty_cache()
+            out["extra"] = run_legs(sample, device)
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

@@ -342,8 +342,6 @@ def _evaluate_shard(shard, tensor_names, index, algorithms, selected_algo, forma
     """This rank's tensors → (summary rows [R, ROW_W], note lines).  hip + a search algorithm: streamed groups (streamed.py)."""
     from . import streamed
 
-    if os.environ.get("MTQ_FAULT_INJECT") == f"rank:{rank}":   # test hook: this rank's share fails (tests/test_cli.py)
-        raise RuntimeError(f"injected fault on rank {rank}")
     notes = []
     per_tensor = list(shard)
     rows_by_idx = {}

@@ -592,7 +592,9 @@ extern "C" int mtq_launch_tile_stats_bf16_fast(const void *x, int64_t count, int
     }
     const unsigned blocks = (unsigned)want;
     const dim3 grid(blocks), block(kFastWaves * 64);
-    const size_t lds_bytes = kFastWaves * kRolledWaveLds;
+    static int lds_pad = -1;                              // MTQ_K1_LDS_PAD: extra LDS bytes per block (experiments on what fits beside K1)
+    if (lds_pad < 0) { const char *e = getenv("MTQ_K1_LDS_PAD"); lds_pad = e ? atoi(e) : 0; }
+    const size_t lds_bytes = kFastWaves * kRolledWaveLds + (size_t)lds_pad;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const uint16_t *xp = static_cast<const uint16_t *>(x);
     if (int rc = work_counter_acquire(stream, work_out)) return rc;   // `st` now waits for the slot's previous launch to have reset it
@@ -634,7 +636,9 @@ extern "C" int mtq_launch_tile_stats_bf16_listed(const void *x, int64_t count, i
     const int cus = fast_cus();
     if (cus == 0) return fail(MTQ_ERR_HIP, "hipGetDeviceProperties failed");
     const int64_t need = (((int64_t)cap + 3) / 4 + kFastWaves - 1) / kFastWaves;
-    const int64_t max_blocks = (int64_t)cus * rolled_waves(sums, errs) * 4 / kFastWaves;
+    static int lw = -1;                                  // MTQ_LISTED_WAVES: waves per SIMD the listed grid is sized for
+    if (lw < 0) { const char *e = getenv("MTQ_LISTED_WAVES"); lw = e ? atoi(e) : 0; }
+    const int64_t max_blocks = (int64_t)cus * (lw > 0 ? lw : rolled_waves(sums, errs)) * 4 / kFastWaves;
     const dim3 grid((unsigned)(need < max_blocks ? need : max_blocks)), block(kFastWaves * 64);
     const size_t lds_bytes = kFastWaves * kRolledWaveLds;
     hipStream_t st = static_cast<hipStream_t>(stream);

@@ -25,6 +25,7 @@
 #include <stdint.h>
 
 #include <atomic>
+#include <stdlib.h>
 #include <mutex>
 
 #include "../../include/mtq.h"
@@ -509,6 +510,7 @@ __device__ void scan_tensor(const ScanArgs &a, const Order &ord, int b, unsigned
     double *lds_p = lds_d + 64 * 4;                                    // [64][4] prefixes
     double *lds_i = lds_p + 64 * 4;                                    // [64][5] initial-sum staging
     uint32_t *cnt = reinterpret_cast<uint32_t *>(lds_i + 64 * 5);   // [kTagSlots / 4] byte counters of the shuffle's conflict detection
+    uint32_t *helper_flag = cnt + kTagSlots / 4;                       // [2] set by the helper wave when the deltas of pass 1 / pass 2 are in memory
     constexpr bool mae = kMae;   // compiled per metric (a run-time flag cost the pcc scan 9 %): one running sum, Σ|x−y| (:280-301), carried where the pcc search carries Σy; Σy², Σxy idle
     const int base = a.fmt[0];
     // record offsets by format code, one byte each (rec <= 22): a per-lane code picks its offset with a shift, where indexing the
@@ -534,6 +536,13 @@ __device__ void scan_tensor(const ScanArgs &a, const Order &ord, int b, unsigned
     int prev_code = -1;
     auto prev_of = [&](uint32_t t) -> int { return prev_code >= 0 ? prev_code : (int)((uint8_t)ld_l2(map + t) & 0x7Fu); };
 
+    if (two_waves) {   // both waves: the flags start at zero before either of them is set or read
+        if (wave == 0 && lane < 2) helper_flag[lane] = 0u;
+        __syncthreads();
+    }
+    auto wait_helper = [&](int p) {   // the visiting wave: until the helper wave has stored the deltas of pass p (it always gets there: it waits for nothing)
+        while (__hip_atomic_load(helper_flag + (p - 1), __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == 0u) __builtin_amdgcn_s_sleep(8);
+    };
     if (wave == 1) {
         // Helper wave: the deltas of the passes that use the shared orders, speculating that pass p finds every tile in format fmt[p−1]
         // (true while every earlier pass accepted every tile — the visiting wave checks, and gathers its own deltas otherwise).  Pass 1's
@@ -543,9 +552,11 @@ __device__ void scan_tensor(const ScanArgs &a, const Order &ord, int b, unsigned
             if (p <= n_sh) {
                 Pg = p == 1 ? P1 : P2;
                 prev_code = a.fmt[p - 1];
-                gather_deltas<kMae>(st, rec, po, a.fmt[p], T, p == 1 ? delta : delta2, lane, tile_at, prev_of);
+                gather_deltas<kMae>(st, rec, po, a.fmt[p], T, p == 1 ? delta : delta2, lane, tile_at, prev_of);   // returns with its stores complete
             }
-            __syncthreads();
+            // "pass p's deltas are in memory": a word in LDS the visiting wave polls — not a barrier, so that this wave can end (and give its
+            // registers back to K1's waves) as soon as its gathers are done instead of waiting for the visiting wave to reach a rendezvous
+            if (lane == 0) __hip_atomic_store(helper_flag + (p - 1), 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
         return;
     }
@@ -642,15 +653,14 @@ __device__ void scan_tensor(const ScanArgs &a, const Order &ord, int b, unsigned
         if (special) status = 1;
         done = !good;                                                  // every tile is fixed at once: no later pass has a candidate
         if (n_sh == 0 && !wave_shuffle<false>(r, ord, T, cnt, lane)) status = 2;   // the generator advances as the permutation would have
-        if (two_waves) __syncthreads();                                // the helper wave's deltas of pass 1 are in memory
+        if (two_waves) wait_helper(1);                                  // the helper wave's deltas of pass 1 are in memory
     }
     MTQ_SCAN_STAMP(1);
 
     bool pristine = a.phase != 2;     // every pass so far accepted every tile: the next pass's candidates are all T tiles, in tile order
-    bool b2_pending = two_waves && a.phase != 2;
     for (int p = p_begin; p < p_end && status == 0 && !done; ++p) {
         const int f = a.fmt[p];
-        if (p == 2 && b2_pending) { __syncthreads(); b2_pending = false; }   // the helper wave's deltas of pass 2 are in memory
+        if (p == 2 && two_waves && n_sh >= 2) wait_helper(2);             // the helper wave's deltas of pass 2 are in memory
         bool any_rej = false;
         const bool use_sh = pristine && p <= n_sh;
         int nc = T;
@@ -684,7 +694,6 @@ __device__ void scan_tensor(const ScanArgs &a, const Order &ord, int b, unsigned
         if (any_rej) pristine = false;
         MTQ_SCAN_STAMP(4 + 3 * (p - 1));
     }
-    if (b2_pending) __syncthreads();
     mem_wait();
 
     if (a.phase == 1) {
@@ -801,7 +810,7 @@ __global__ __launch_bounds__(128) void greedy_scan_pcc_global(ScanArgs a)
     else scan_tensor<false>(a, ord, blockIdx.x, lds, lane, wave, blockDim.x == 128);
 }
 
-constexpr size_t kFixedLds = (64 * 4 + 64 * 4 + 64 * 5) * sizeof(double) + kTagSlots;
+constexpr size_t kFixedLds = (64 * 4 + 64 * 4 + 64 * 5) * sizeof(double) + kTagSlots + 16;
 
 // The launch's shared orders: block w (one wave) computes order w+1.  Block 0: the base pass's draws, then pass 1's permutation of
 // range(T); block 1: the draws of the base pass and of pass 1, then pass 2's permutation of range(T).
@@ -922,7 +931,9 @@ extern "C" int mtq_debug_scan_ticks(uint64_t out[16])
 extern "C" size_t mtq_greedy_scan_scratch_bytes(int64_t count, int64_t tiles)
 {
     if (count <= 0 || tiles <= 0) return 0;
-    const size_t per = (size_t)tiles * 8 * sizeof(double) + (tiles > kScanMaxTilesLds ? (size_t)tiles * sizeof(uint32_t) : 0);
+    // per tensor: the deltas of two passes (2 x 32 B per tile) and a visiting order in global memory (4 B per tile: tensors of more than
+    // kScanMaxTilesLds tiles, and — with shared orders — any tensor that has to shuffle for itself)
+    const size_t per = (size_t)tiles * 8 * sizeof(double) + (size_t)tiles * sizeof(uint32_t);
     return (size_t)count * ((per + 255) & ~(size_t)255);
 }
 
@@ -1021,7 +1032,12 @@ extern "C" int mtq_greedy_scan_device_ex(const double *stats, int64_t count, int
         return check_launch("mtq_greedy_scan_device");
     }
     const unsigned threads = (orders && phase != 2) ? 128u : 64u;   // a helper wave per tensor when the visiting orders are shared
-    if (tiles <= kScanMaxTilesLds) {
+    // With shared orders a tensor shuffles for itself only when its course leaves the common one (a rejection in pass 1): that rare
+    // shuffle may as well run in global scratch, and the block then needs 23 KiB of LDS instead of 23 + 2·tiles — a block that K1's
+    // blocks make room for far sooner.  MTQ_SCAN_SHARED_LDS=1 keeps the order in LDS.
+    static int shared_lds = -1;
+    if (shared_lds < 0) { const char *e = getenv("MTQ_SCAN_SHARED_LDS"); shared_lds = e ? atoi(e) : 0; }
+    if (tiles <= kScanMaxTilesLds && !(threads == 128u && !shared_lds)) {
         const size_t lds = 2 * (size_t)((tiles + 7) & ~(int64_t)7) + kFixedLds;
         if (int rc = raise_lds(dev, 0, reinterpret_cast<const void *>(greedy_scan_pcc_lds), 2 * kScanMaxTilesLds + (int)kFixedLds)) return rc;
         hipLaunchKernelGGL(greedy_scan_pcc_lds, dim3((unsigned)count), dim3(threads), lds, st, a);

@@ -114,8 +114,11 @@ class ModelIndex:
             sl = f.get_slice(name)
             return tuple(sl.get_shape()), ("bf16" if str(sl.get_dtype()).upper() in ("BF16", "BFLOAT16") and f"{name}_scale_inv" not in self.files else "f32")
 
-    def load(self, name: str, device=None):
-        """→ torch tensor (bf16 kept as bf16, everything else float32) on `device` (None = host)."""
+    def load(self, name: str, device=None, draw_on_device: bool = False):
+        """→ torch tensor (bf16 kept as bf16, everything else float32) on `device` (None = host).  draw_on_device: a synthetic
+        tensor is drawn by the device's generator (seeded per tensor) instead of the CPU's — other values of the same distribution,
+        three orders of magnitude faster for a whole model (bench.py's model-sized workloads, where the loader must not be what is
+        measured); the default keeps one set of values for every backend and rank."""
         import torch
 
         if name in self.files:
@@ -137,7 +140,7 @@ class ModelIndex:
                 t = t.to(torch.float32)
             return t.to(device) if device is not None else t
         spec = self.specs[name]
-        dev = "cpu"  # always drawn from the CPU generator: the same tensor whatever backend / rank evaluates it
+        dev = device if (draw_on_device and device is not None) else "cpu"  # CPU generator by default: the same tensor whatever backend / rank evaluates it
         g = torch.Generator(device=dev)
         g.manual_seed(spec.seed)
         shape = spec.shape if spec.shape else (1,)

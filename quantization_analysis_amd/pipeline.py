@@ -508,13 +508,17 @@ class GreedyPipeline:
                     listed, nl = b["listed"][first * tiles:(first + n) * tiles], b["n_listed"][ci:ci + 1]
                     carry = b["carry"][first * per_carry:(first + n) * per_carry]
                     nl.zero_()
-                    hb.greedy_scan_device_ex(*args, counts_out=b["counts_dev"][first:first + n], orders=orders, phase=1, listed=listed, n_listed=nl, carry=carry)
-                    hb.tile_stats_listed(xs, k1_mask, last_bit, prev_bit, listed, nl, recs, scratch=b["lscr"][first * tiles + ci:(first + n) * tiles + ci + 1])
-                    hb.greedy_scan_device_ex(*args, counts_out=b["counts_dev"][first:first + n], phase=2, carry=carry)
+                    if "phase1" not in os.environ.get("MTQ_ABLATE", ""):
+                        hb.greedy_scan_device_ex(*args, counts_out=b["counts_dev"][first:first + n], orders=orders, phase=1, listed=listed, n_listed=nl, carry=carry)
+                    if "listed" not in os.environ.get("MTQ_ABLATE", ""):
+                        hb.tile_stats_listed(xs, k1_mask, last_bit, prev_bit, listed, nl, recs, scratch=b["lscr"][first * tiles + ci:(first + n) * tiles + ci + 1])
+                    if "phase2" not in os.environ.get("MTQ_ABLATE", ""):
+                        hb.greedy_scan_device_ex(*args, counts_out=b["counts_dev"][first:first + n], phase=2, carry=carry)
                 else:
                     hb.greedy_scan_device_ex(*args, counts_out=b["counts_dev"][first:first + n], orders=orders)
-                hb.check(hb.lib().mtq_column_sums_device_batched(recs.data_ptr(), n, tiles, dec_mask, maps.data_ptr(),
-                                                                 b["sums_dev"][0, first:first + n].data_ptr(), scan_stream.cuda_stream))
+                if "colsum" not in os.environ.get("MTQ_ABLATE", ""):
+                    hb.check(hb.lib().mtq_column_sums_device_batched(recs.data_ptr(), n, tiles, dec_mask, maps.data_ptr(),
+                                                                     b["sums_dev"][0, first:first + n].data_ptr(), scan_stream.cuda_stream))
                 for k, pm in enumerate(b["pure_maps"]):
                     hb.check(hb.lib().mtq_column_sums_device_batched(recs.data_ptr(), n, tiles, dec_mask, pm[first:first + n].data_ptr(),
                                                                      b["sums_dev"][1 + k, first:first + n].data_ptr(), scan_stream.cuda_stream))
@@ -846,7 +850,30 @@ class GreedyPipeline:
         return results
 
     def close(self) -> None:
-        self.pool.shutdown(wait=True)
+        """Ends the pipeline in an orderly way: its streams drained, its chunk-task threads joined, its device and pinned buffers
+        released now — while the HIP runtime is certainly still there — rather than whenever the interpreter gets to them at exit
+        (round 2 saw a SIGSEGV inside __cxa_finalize after a profiled `wq` run; hip_backend.shutdown() is the library's half).
+        Idempotent; the pipeline must not be used afterwards."""
+        if getattr(self, "_closed", False):
+            return
+        self._closed = True
+        try:
+            for st in (self.stream, self.copy_stream, self.col_stream, *self.scan_streams):
+                st.synchronize()
+        finally:
+            self.pool.shutdown(wait=True)
+            self._open.clear()
+            self._unresolved.clear()
+            for d in (self._devbufs, self._bufs, self._chainbufs, self._colbufs):
+                d.clear()
+            self.timing.events.clear()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
 
 
 class ThresholdPipeline:
@@ -872,6 +899,18 @@ class ThresholdPipeline:
         self.knife_tiles = 0
         self._pin = {}
 
+    def close(self) -> None:
+        """Drains the device and releases the pinned mirrors now (see GreedyPipeline.close)."""
+        self.torch.cuda.synchronize()
+        self._pin.clear()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
+
     def _pinned(self, name: str, numel: int, dtype):
         """Flat pinned host storage that only grows (a pinned allocation costs milliseconds)."""
         t = self._pin.get(name)
@@ -880,30 +919,38 @@ class ThresholdPipeline:
             self._pin[name] = t
         return t[:numel]
 
-    def _rescore_chunk(self, xc, maps: np.ndarray, near: np.ndarray, jj: np.ndarray, tt: np.ndarray, tiles_w: int) -> None:
-        """The knife-edge tiles of a whole chunk at once: one indexed gather on the device, then per format K2 and the
-        reference's literal float32 tile score (tile_utils.py:46-57) for exactly the (tile, format) pairs inside the band
-        (mixed_tile_threshold.decide_knife_tiles); maps patched in place (reference :117-123)."""
+    def _rescore(self, xc, maps: np.ndarray, near: np.ndarray, jj: np.ndarray, tt: np.ndarray, tiles_w: int) -> None:
+        """The knife-edge tiles of a whole batch at once: ONE indexed gather on the device, every format of the search quantised for
+        them by K2 in one go, one copy home; then the reference's literal float32 tile score (tile_utils.py:46-57, here
+        tile_utils.pearson_corr_tiles: the per-tile call's bits at a third of its cost) for exactly the (tile, format) pairs inside
+        the band (mixed_tile_threshold.decide_knife_tiles); maps patched in place (reference :117-123).  Round 2 did this per chunk
+        with a device round trip per format: with ~3 knife tiles per tensor it cost more than K1 and K4 together."""
         from .compression_algorithms.mixed_tile_threshold import decide_knife_tiles
         from .compression_algorithms.tile_utils import tile_metrics
 
         torch = self.torch
         n, h, w = xc.shape
         dev = xc.device
-        j = torch.from_numpy(jj.astype(np.int64)).to(dev)
-        t = torch.from_numpy(tt.astype(np.int64)).to(dev)
+        k = int(jj.size)
+        idx = torch.from_numpy(np.stack([jj, tt]).astype(np.int64)).to(dev, non_blocking=True)
+        j, t = idx[0], idx[1]
         ar = torch.arange(32, device=dev)
         rows = (t // tiles_w)[:, None] * 32 + ar
         cols = (t % tiles_w)[:, None] * 32 + ar
         vals = xc[j[:, None, None], rows.clamp(max=h - 1)[:, :, None], cols.clamp(max=w - 1)[:, None, :]].float()
         inside = (rows < h)[:, :, None] & (cols < w)[:, None, :]
         x_dev = torch.where(inside, vals, torch.zeros((), dtype=torch.float32, device=dev)).contiguous()   # (k, 32, 32), pads zero
-        x_tiles = x_dev.cpu().numpy()
+        fmts = list(self.tile_formats)
+        both = torch.empty((1 + len(fmts), k, 32, 32), dtype=torch.float32, device=dev)
+        both[0] = x_dev
+        flat = x_dev.reshape(k * 32, 32)
+        for i, f in enumerate(fmts):
+            hb.quantize(flat, f, out=both[1 + i].reshape(k * 32, 32))
+        host = both.cpu().numpy()                                                                          # the one wait of the rescoring
+        x_tiles = host[0]
 
         def literal_scores(fmt: str, sel: np.ndarray) -> np.ndarray:
-            xs = x_dev if sel.size == x_dev.shape[0] else x_dev[torch.from_numpy(sel).to(dev)]
-            y = hb.quantize(xs.reshape(sel.size * 32, 32), fmt).cpu().numpy().reshape(sel.size, 32, 32)
-            return tile_metrics(x_tiles[sel], y, self.metric)
+            return tile_metrics(x_tiles[sel], host[1 + fmts.index(fmt)][sel], self.metric)
 
         maps[jj, tt] = decide_knife_tiles(maps[jj, tt], near[jj, tt].astype(np.uint8), self.tile_formats, self.metric, self.threshold, literal_scores)
 
@@ -935,17 +982,24 @@ class ThresholdPipeline:
             launched.append((first, n, recs, both, mirror))
         torch.cuda.current_stream().synchronize()
         codes = torch.arange(nf, dtype=torch.int8, device=x3d.device)
-        all_maps = []
+        # maps and knife-edge masks of the whole batch; the knife-edge (tensor, tile) pairs (few) are decided together, once
+        maps_all = np.empty((count, tiles), dtype=np.int8)
+        near_all = np.empty((count, tiles), dtype=np.int8)
         for first, n, recs, both, mirror in launched:
             host = mirror.numpy()
-            maps = host[0].reshape(n, tiles).copy()                                            # the mirror is reused by the next batch
-            near = host[1].reshape(n, tiles)                                                   # per tile: mask of format codes inside the band
-            jj, tt = np.divmod(np.flatnonzero(near.view(np.bool_)), tiles)                     # knife-edge (tensor, tile) pairs of the chunk (few)
-            dirty = jj.size > 0
-            if dirty:
-                self._rescore_chunk(x3d[first:first + n], maps, near, jj, tt, tw)
-                self.knife_tiles += int(jj.size)
-            dmaps = (torch.from_numpy(maps).to(x3d.device) if dirty else both[0].view(n, tiles)).contiguous()
+            maps_all[first:first + n] = host[0].reshape(n, tiles)                              # the mirror is reused by the next batch
+            near_all[first:first + n] = host[1].reshape(n, tiles)                              # per tile: mask of format codes inside the band
+        jj, tt = np.divmod(np.flatnonzero(near_all.view(np.bool_)), tiles)
+        dirty = np.zeros(count, dtype=bool)
+        if jj.size:
+            self._rescore(x3d, maps_all, near_all, jj, tt, tw)
+            self.knife_tiles += int(jj.size)
+            dirty[jj] = True
+        for first, n, recs, both, mirror in launched:
+            if dirty[first:first + n].any():
+                dmaps = torch.from_numpy(maps_all[first:first + n]).to(x3d.device, non_blocking=True).contiguous()
+            else:
+                dmaps = both[0].view(n, tiles)
             scratch = torch.empty((P, n, scratch_n), dtype=torch.float64, device=x3d.device)
             hb.check(hb.lib().mtq_column_sums_device_batched(recs.data_ptr(), n, tiles, dec_mask, dmaps.data_ptr(), scratch[0].data_ptr(), hb._stream_ptr()))
             for k, f in enumerate(self.pure_formats):   # wq's `none` rows from the same records
@@ -954,14 +1008,12 @@ class ThresholdPipeline:
             for q in range(P):
                 hb.device_copy(sums_host[q, first:first + n], scratch[q, :, :7])
             hb.device_copy(counts_host[first:first + n], (dmaps.unsqueeze(-1) == codes).sum(dim=1))   # counts ≡ np.bincount per tensor
-            all_maps.append(maps)
         torch.cuda.current_stream().synchronize()                                              # one wait for all chunks' sums and counts
         k = {"pcc": 0, "mae": 1, "atol": 2}[self.metric]
         sums = sums_host.numpy()
         cols = columns_from_sums_batch(sums[0], float(numel))
         pure_cols = [columns_from_sums_batch(sums[1 + i], float(numel)) for i in range(len(self.pure_formats))]
         bc = counts_host.numpy()
-        maps_all = np.concatenate(all_maps, axis=0) if all_maps else np.zeros((0, tiles), dtype=np.int8)
         for j in range(count):
             counts = {f: int(bc[j, i]) for i, f in enumerate(MIXED_TILE_FORMATS)}
             pure = {f: tuple(float(v) for v in pure_cols[i][j]) for i, f in enumerate(self.pure_formats)} or None

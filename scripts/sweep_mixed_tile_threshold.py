@@ -116,8 +116,6 @@ def main(argv=None) -> int:
     for i in lpt_shards(selected, index.numel, world)[rank]:
         name = selected[i]
         try:
-            if os.environ.get("MTQ_FAULT_INJECT") == f"rank:{rank}":   # test hook: one rank's tensor fails (tests/test_sweep.py)
-                raise RuntimeError(f"injected fault on rank {rank}")
             x = index.load(name, device=device)
             xf = x if device is not None else x.float().numpy()
             rows, baselines, _thr = sweep_tensor(xf, formats, args.metric, args.lowest_metric_val, args.steps, quantizer)

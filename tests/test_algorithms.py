@@ -290,3 +290,29 @@ def test_threshold_mid_size_hip():
     import torch
 
     _threshold_mid_size(Quantizer("hip"), to_input=lambda x: torch.from_numpy(x).cuda().to(torch.bfloat16))
+
+
+def test_pearson_corr_tiles_is_the_per_tile_call_bit_for_bit():
+    """tile_utils.pearson_corr_tiles (what the knife-edge tiles of mixed-tile-threshold, the sweep and mixed-tile-random are re-scored
+    with) against metrics.pearson_corr tile by tile: 10^4 tiles of several magnitudes and error levels, plus constant, identical, zero
+    and single-outlier tiles — the same float32 bits."""
+    from quantization_analysis_amd.compression_algorithms.metrics import pearson_corr
+    from quantization_analysis_amd.compression_algorithms.tile_utils import pearson_corr_tiles, tile_metrics
+
+    rng = np.random.default_rng(20261005)
+    k = 10000
+    scale = np.exp(rng.normal(0.0, 3.0, size=(k, 1, 1))).astype(np.float32)
+    p = (rng.standard_normal((k, 32, 32)).astype(np.float32) * scale).astype(np.float32)
+    noise = np.exp(rng.normal(-6.0, 2.0, size=(k, 1, 1))).astype(np.float32)
+    q = (p + rng.standard_normal((k, 32, 32)).astype(np.float32) * scale * noise).astype(np.float32)
+    p[0] = 0.0; q[0] = 0.0                  # zero variance, identical
+    p[1] = 1.5; q[1] = 1.5                  # constant, identical
+    p[2] = 1.5; q[2] = 1.25                 # constant, different
+    q[3] = p[3]                             # identical
+    q[4] = 0.0                              # y all zero (a format that flushes the tile)
+    p[5] = 0.0; p[5, 3, 4] = 7.0; q[5] = p[5] * 0.5
+    want = np.fromiter((pearson_corr(p[t], q[t]) for t in range(k)), dtype=np.float32, count=k)
+    got = pearson_corr_tiles(p, q)
+    assert np.array_equal(want.view(np.uint32), got.view(np.uint32)), int((want.view(np.uint32) != got.view(np.uint32)).sum())
+    assert np.array_equal(tile_metrics(p[:64], q[:64], "pcc").view(np.uint32), want[:64].view(np.uint32))
+    assert pearson_corr_tiles(np.zeros((0, 32, 32), np.float32), np.zeros((0, 32, 32), np.float32)).shape == (0,)

@@ -160,12 +160,26 @@ def test_wq_two_ranks_gloo_matches_single_process(tmp_path):
 
 
 def test_wq_two_ranks_one_fails_gloo(tmp_path):
-    """A failure on one rank (MTQ_FAULT_INJECT) must not leave the other in a collective: both exit, the job returns non-zero
-    well inside the collective timeout, and the error names the rank."""
+    """A failure on one rank must not leave the other in a collective: both exit, the job returns non-zero well inside the
+    collective timeout, and the error names the rank.  The fault is injected by this test's launcher script (rank 1's
+    cli._evaluate_shard is replaced by one that raises): the package carries no test hook."""
     cfg = write_cfg(tmp_path, algo="mixed-tile-threshold", seed=None, params={"metric": "pcc", "threshold": 0.99})
-    env = dict(os.environ, PYTHONPATH=str(ROOT), HSA_ENABLE_IPC_MODE_LEGACY="0", MTQ_FAULT_INJECT="rank:1")
+    env = dict(os.environ, PYTHONPATH=str(ROOT), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    launcher = tmp_path / "wq_faulty.py"
+    launcher.write_text(
+        "import os, sys\n"
+        f"sys.path.insert(0, {str(ROOT)!r})\n"
+        "from quantization_analysis_amd import cli\n"
+        "real = cli._evaluate_shard\n"
+        "def faulty(*a, **k):\n"
+        "    rank = int(os.environ.get('RANK', '0'))\n"
+        "    if rank == 1:\n"
+        "        raise RuntimeError(f'injected fault on rank {rank}')\n"
+        "    return real(*a, **k)\n"
+        "cli._evaluate_shard = faulty\n"
+        "cli.main()\n")
     two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                          "--master-port", str(_free_port()), str(ROOT / "wq"), "synthetic:tiny", "--compression-config", cfg,
+                          "--master-port", str(_free_port()), str(launcher), "synthetic:tiny", "--compression-config", cfg,
                           "--results-dir", str(tmp_path / "r2"), "--no-plots"], cwd=tmp_path, env=env, capture_output=True, text=True, timeout=300)
     assert two.returncode != 0
     assert "injected fault on rank 1" in two.stderr and "Timeout" not in two.stderr and "timed out" not in two.stderr.lower()
@@ -218,6 +232,25 @@ def test_bench_self_launches_its_ranks(tmp_path):
     # N = 1 never goes through the launcher
     r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--dry-run"], cwd=tmp_path, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and json.loads(r.stdout.strip().splitlines()[-1])["n_gpus"] == 1, r.stderr[-2000:]
+
+
+def test_bench_model_workload_shards_over_two_ranks(tmp_path):
+    """`bench.py --workload llama3-8b` (BASELINE configs[3], strong scaling): the 224 tensors are LPT-sharded over the ranks without
+    communication, every tensor lands on exactly one rank, the ranks' differently sized sets of summary rows arrive at rank 0 through
+    the job's one gather (gloo here, RCCL on the GPUs) — the --dry-run of that mode on a world of 2 and of 3."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE")}
+    env.update(PYTHONPATH=str(ROOT), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for world in (2, 3):
+        r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", str(world), "--steps", "2", "--warmup", "1", "--workload", "llama3-8b", "--dry-run"],
+                           cwd=tmp_path, env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        out = [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+        assert out["n_gpus"] == world and out["scaling"] == "strong" and out["tensors"] == 224 and out["tensors_seen_once"] is True
+        assert sum(out["tensors_per_rank"]) == 224 and out["imbalance"] < 1.05 and out["max_seconds"] == float(world)
+    from bench import llama_shard
+
+    index, names, mine, groups = llama_shard(1, 8)
+    assert len(names) == 224 and sum(len(v) for v in groups.values()) == len(mine) and set(groups) <= {(4096, 4096), (1024, 4096), (14336, 4096), (4096, 14336)}
 
 
 @pytest.mark.gpu

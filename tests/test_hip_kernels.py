@@ -800,3 +800,216 @@ def test_device_scan_refusals_and_zero_variance():
         hb.greedy_scan_device(recs, 0xE | hb.MASK_BF16_IDENTITY | hb.MASK_SLIM, ALL, "pcc", 0.9, 64.0 * 128, sd)   # full records only
     with pytest.raises(hb.MtqError):
         hb.greedy_scan_device(recs, 0xE | hb.MASK_BF16_IDENTITY, ["bfp8", "bfp8"], "pcc", 0.9, 64.0 * 128, sd)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Round 3: partial / listed K1, shared visiting orders, the search in phases
+# ------------------------------------------------------------------------------------------------------------------
+def _promised_columns(layout, full, sums=0, err=0):
+    cols, slot = [], 0
+    for f in range(4):
+        if not layout & (1 << f):
+            continue
+        o = 2 + 5 * slot
+        if full & (1 << f):
+            cols += list(range(o, o + 5))
+        elif sums & (1 << f):
+            cols += list(range(o, o + 3))
+        elif err & (1 << f):
+            cols += [o + 3, o + 4]
+        slot += 1
+    return cols
+
+
+@pytest.mark.gpu
+def test_partial_records_and_listed_completion():
+    """mtq_tile_stats_partial writes the promised statistics bit for bit as the whole-record launch does (and NaN elsewhere on the
+    exact-integer route); mtq_tile_stats_listed then completes exactly the listed tiles' records — through the four-tiles-per-wave
+    exact-integer form (bf16, scratch given), through the one-wave-per-tile form, and by the literal route for the tiles neither
+    takes (an Inf, a denormal-only group, a huge exponent)."""
+    import torch
+
+    rng = np.random.default_rng(5)
+    x = np.stack([gen("normal_bf16", 40 + i, (256, 384)) for i in range(3)])
+    x[0, :32, :128] = 0.0                      # an all-zero unit
+    x[0, 40, 130] = 3.0e4                      # tail-class neighbours
+    x[1, 7, 9] = np.inf                        # the exact routes hand this tile over
+    x[2, 64:96, 256:288] = 1e-40               # denormal-only tile
+    xd = dev(x, bf16=True)
+    count, T = 3, 8 * 12
+    for layout, full, sums, lfull, lerr in ((0xE, 0x2, 0x4, 0x8, 0x4), (0x6, 0x0, 0x2, 0x4, 0x2), (0xE, 0x6, 0x0, 0x8, 0x0), (0xC, 0x0, 0x4, 0x8, 0x4)):
+        ref = hb.tile_stats_batched(xd, layout)
+        got = hb.tile_stats_partial(xd, layout, full, sums)
+        cols = [0, 1] + _promised_columns(layout, full, sums)
+        assert torch.equal(ref[..., cols].view(torch.int64), got[..., cols].view(torch.int64)), (layout, full, sums)
+        # a list with a short last unit, tiles of every tensor, the flagged tiles among them
+        ids = np.sort(rng.choice(count * T, size=37, replace=False)).astype(np.int32)
+        ids = np.unique(np.concatenate([ids, [T + 0, 2 * T + 2 * 12 + 8]])).astype(np.int32)      # the Inf tile (tensor 1, tile 0) and the denormal tile
+        listed = torch.zeros((count * T,), dtype=torch.int32, device="cuda")
+        listed[: ids.size] = torch.from_numpy(ids).cuda()
+        nl = torch.tensor([ids.size], dtype=torch.int32, device="cuda")
+        lcols = _promised_columns(layout, lfull, err=lerr)
+        for scratch in (torch.empty((count * T + 1,), dtype=torch.int32, device="cuda"), None):
+            work = got.clone()
+            hb.tile_stats_listed(xd, layout, lfull, lerr, listed, nl, work, scratch=scratch)
+            flat_w, flat_r, flat_g = work.view(count * T, -1), ref.view(count * T, -1), got.view(count * T, -1)
+            sel = torch.from_numpy(ids.astype(np.int64)).cuda()
+            assert torch.equal(flat_w[sel][:, lcols].view(torch.int64), flat_r[sel][:, lcols].view(torch.int64)), (layout, lfull, lerr, scratch is None)
+            rest = torch.ones(count * T, dtype=torch.bool, device="cuda")
+            rest[sel] = False
+            assert torch.equal(flat_w[rest].view(torch.int64), flat_g[rest].view(torch.int64))              # unlisted tiles untouched
+            other = [c for c in range(ref.shape[-1]) if c not in lcols]
+            assert torch.equal(flat_w[sel][:, other].view(torch.int64), flat_g[sel][:, other].view(torch.int64))   # nothing else of a listed record touched
+    # float32 storage and ragged shapes: every route writes whole records (always allowed), the listed form takes them one wave per tile
+    xf = dev(np.stack([gen("heavy_f32", 60 + i, (100, 130)) for i in range(2)]))
+    ref = hb.tile_stats_batched(xf, 0xF)
+    got = hb.tile_stats_partial(xf, 0xF, 0x3, 0x4)
+    cols = [0, 1] + _promised_columns(0xF, 0x3, 0x4)
+    assert torch.equal(ref[..., cols].view(torch.int64), got[..., cols].view(torch.int64))
+    listed = torch.tensor([1, 5, 19, 20, 39], dtype=torch.int32, device="cuda")
+    work = torch.full_like(ref, float("nan"))
+    hb.tile_stats_listed(xf, 0xF, 0x8, 0x4, listed, torch.tensor([5], dtype=torch.int32, device="cuda"), work)
+    lcols = _promised_columns(0xF, 0x8, err=0x4)
+    sel = listed.long()
+    assert torch.equal(work.view(40, -1)[sel][:, lcols].view(torch.int64), ref.view(40, -1)[sel][:, lcols].view(torch.int64))
+    with pytest.raises(hb.MtqError):
+        hb.tile_stats_partial(xd, 0xE, 0x2, 0x2)              # full and sums overlap
+    with pytest.raises(hb.MtqError):
+        hb.tile_stats_listed(xd, 0xE, 0x1, 0x0, listed, listed[:1], ref)   # bf16 has no late evaluation
+
+
+@pytest.mark.gpu
+def test_scan_orders_are_numpys_permutations():
+    """mtq_scan_orders_device: pass 1's and pass 2's orders are what default_rng(seed) hands out after the base pass's permutation —
+    in LDS (tiles <= 32 768) and in global memory (above) — and the generator states in between carry on NumPy's stream."""
+    import torch
+
+    L = hb.lib()
+    for seed, T in ((123, 16384), (7, 1), (7, 2), (2**40 + 9, 4097), (5, 40000)):
+        buf = hb.scan_orders_device(seed, T, 2)
+        torch.cuda.synchronize()
+        raw = buf.cpu().numpy()
+        stride = (T + 63) // 64 * 64
+        p = raw[128:128 + 8 * stride].view(np.uint32)
+        rng = np.random.default_rng(seed)
+        rng.permutation(T)                                    # the base pass's draws
+        assert np.array_equal(p[:T], rng.permutation(T).astype(np.uint32)), (seed, T)
+        assert np.array_equal(p[stride:stride + T], rng.permutation(T).astype(np.uint32)), (seed, T)
+    with pytest.raises(hb.MtqError):
+        hb.scan_orders_device(0, 64, 2)
+    assert L.mtq_scan_orders_bytes(64) == 128 + 2 * 64 * 4
+
+
+def _search_variants_vs_host(xs, formats, thr, seed, metric="pcc"):
+    """Host scan on whole records = the reference for: the device search with its own shuffles, with the launch's shared orders (helper
+    wave), and — pcc, bf16 base, three formats or more — split in phases on partial records with the listed completion in between."""
+    import torch
+
+    L = hb.lib()
+    count, rows, cols = xs.shape
+    ident = xs.dtype == torch.bfloat16 and "bf16" in formats and any(f != "bf16" for f in formats)
+    k1 = hb.fmt_mask(formats) & 0xE if ident else hb.fmt_mask(formats)
+    dec = k1 | hb.MASK_BF16_IDENTITY if ident else k1
+    recs = hb.tile_stats_batched(xs, k1)
+    T = recs.shape[1]
+    numel = float(rows * cols)
+    want, wcounts, _o = hb.greedy_run_batch(recs.cpu().numpy(), dec, formats, metric, thr, numel, [seed] * count, 4)
+    sd = torch.full((count,), seed, dtype=torch.int64, device="cuda")
+    scratch = torch.empty((int(L.mtq_greedy_scan_scratch_bytes(count, T)),), dtype=torch.uint8, device="cuda")
+    maps = torch.empty((count, T), dtype=torch.int8, device="cuda")
+    status = torch.empty((count,), dtype=torch.int32, device="cuda")
+    cnt = torch.zeros((count, 4), dtype=torch.int32, device="cuda")
+
+    def same(tag):
+        torch.cuda.synchronize()
+        assert status.cpu().tolist() == [0] * count, (tag, formats, thr)
+        assert np.array_equal(maps.cpu().numpy(), want) and np.array_equal(cnt.cpu().numpy(), wcounts), (tag, formats, thr, metric)
+
+    hb.greedy_scan_device_ex(recs, dec, formats, metric, thr, numel, sd, maps, status, scratch, counts_out=cnt)
+    same("own shuffles")
+    orders = hb.scan_orders_device(seed, T, 2)
+    maps.fill_(-1)
+    hb.greedy_scan_device_ex(recs, dec, formats, metric, thr, numel, sd, maps, status, scratch, counts_out=cnt, orders=orders)
+    same("shared orders")
+    if len(formats) >= 3 and metric == "pcc" and ident and rows % 32 == 0 and cols % 128 == 0:
+        last, prev = hb.fmt_mask([formats[-1]]), hb.fmt_mask([formats[-2]])
+        part = hb.tile_stats_partial(xs, k1, k1 & ~last & ~prev, prev)
+        listed = torch.empty((count * T,), dtype=torch.int32, device="cuda")
+        nl = torch.zeros((1,), dtype=torch.int32, device="cuda")
+        carry = torch.empty((int(L.mtq_scan_carry_bytes(count)),), dtype=torch.uint8, device="cuda")
+        maps.fill_(-1)
+        hb.greedy_scan_device_ex(part, dec, formats, metric, thr, numel, sd, maps, status, scratch, counts_out=cnt, orders=orders, phase=1, listed=listed, n_listed=nl, carry=carry)
+        hb.tile_stats_listed(xs, k1, last, prev, listed, nl, part, scratch=torch.empty((count * T + 1,), dtype=torch.int32, device="cuda"))
+        hb.greedy_scan_device_ex(part, dec, formats, metric, thr, numel, sd, maps, status, scratch, counts_out=cnt, phase=2, carry=carry)
+        same("phases on partial records")
+        ns = int(L.mtq_columns_scratch_doubles())
+        s_full = torch.empty((count, ns), dtype=torch.float64, device="cuda")
+        s_lazy = torch.empty_like(s_full)
+        hb.check(L.mtq_column_sums_device_batched(recs.data_ptr(), count, T, dec, maps.data_ptr(), s_full.data_ptr(), hb._stream_ptr()))
+        hb.check(L.mtq_column_sums_device_batched(part.data_ptr(), count, T, dec, maps.data_ptr(), s_lazy.data_ptr(), hb._stream_ptr()))
+        torch.cuda.synchronize()
+        assert torch.equal(s_full[:, :7].view(torch.int64), s_lazy[:, :7].view(torch.int64)), (formats, thr)   # pcc / mae / atol of the final map
+        return int(nl.item())
+    return None
+
+
+@pytest.mark.gpu
+def test_device_search_shared_orders_and_phases():
+    """Thresholds on both sides of every pass (a pass that accepts everything takes the shared order of the next one; a rejection in
+    pass 1 sends the tensor to its own shuffle; a base pass that fails ends the search), format lists of 2–4 entries, the mae metric,
+    tensors shorter than a wave, and tensors above 32 768 tiles."""
+    import torch
+
+    g = torch.Generator(device="cuda")
+    g.manual_seed(11)
+    xs = (torch.randn((5, 512, 1024), generator=g, device="cuda") * 0.02).to(torch.bfloat16)
+    listed = {}
+    for thr in (0.9, 0.99, 0.999, 0.9999, 0.99999, 0.9999999):
+        listed[thr] = _search_variants_vs_host(xs, ALL, thr, 123)
+    assert listed[0.9] == 5 * 512 and 0 < listed[0.999] < 5 * 512 and listed[0.9999999] == 0
+    _search_variants_vs_host(xs, ["bf16", "bfp8", "bfp4"], 0.999, 7)
+    _search_variants_vs_host(xs, ["bf16", "bfp4", "bfp2"], 0.99, 9)
+    _search_variants_vs_host(xs, ["bf16", "bfp2", "bfp8", "bfp4"], 0.999, 9)      # an order the partial kernel has no instantiation for: whole slots
+    _search_variants_vs_host(xs, ["bf16", "bfp2"], 0.9, 11)
+    _search_variants_vs_host(xs, ["bfp8", "bfp4", "bfp2"], 0.995, 5)
+    _search_variants_vs_host(xs.float(), ["bfp4", "bfp8", "bf16"], 0.99, 13)
+    for thr in (2e-4, 1e-3):
+        _search_variants_vs_host(xs, ALL, thr, 31, metric="mae")
+    tiny = (torch.randn((4, 32, 128), generator=g, device="cuda") * 0.02).to(torch.bfloat16)
+    _search_variants_vs_host(tiny, ALL, 0.999, 51)
+    _search_variants_vs_host(tiny[:, :, :32].contiguous(), ALL, 0.999, 61)
+    heavy = (torch.randn((3, 512, 512), generator=g, device="cuda") * 0.02 * torch.exp(1.5 * torch.randn((3, 512, 512), generator=g, device="cuda"))).to(torch.bfloat16)
+    for thr in (0.9, 0.99, 0.999):
+        _search_variants_vs_host(heavy, ALL, thr, 41)
+    big = (torch.randn((2, 14336, 4096), generator=g, device="cuda") * 0.02).to(torch.bfloat16)
+    _search_variants_vs_host(big, ALL, 0.999, 123)
+
+
+@pytest.mark.gpu
+def test_lazy_pipeline_equals_whole_record_pipeline(monkeypatch):
+    """GreedyPipeline's lazy route (partial K1 → phase 1 → listed K1 → phase 2) and its whole-record route give the same results object
+    for object: maps, counts and the three columns bit for bit (both take their column sums from the device in the same tree order);
+    seeds at 2^63 and above are seeds too."""
+    import torch
+    from quantization_analysis_amd.pipeline import GreedyPipeline
+
+    g = torch.Generator(device="cuda")
+    g.manual_seed(3)
+    xs = (torch.randn((6, 256, 512), generator=g, device="cuda") * 0.02).to(torch.bfloat16)
+    got = {}
+    for lazy in ("1", "0"):
+        monkeypatch.setenv("MTQ_LAZY", lazy)
+        for seeds in (None, [2**63 + 1, 5, 5, 2**64 - 1, 9, 123]):
+            with GreedyPipeline(ALL, "pcc", 0.999, 2**63 + 12345, chunk=4, workers=2) as pipe:
+                assert (pipe.lazy_plan(xs) is not None) == (lazy == "1")
+                res = pipe.run(xs, seeds=seeds)
+                got[(lazy, seeds is None)] = res
+                if lazy == "1":
+                    assert pipe.listed_tiles > 0
+    for key in (True, False):
+        for a, b in zip(got[("1", key)], got[("0", key)]):
+            assert np.array_equal(a.assignment, b.assignment) and a.counts == b.counts
+            assert (a.pcc, a.mae, a.atol) == (b.pcc, b.mae, b.atol)
+    x0 = xs[0].float().cpu().numpy()
+    a, counts, _st = orc.greedy(x0, ALL, "pcc", 0.999, 2**63 + 12345)
+    assert np.array_equal(got[("1", True)][0].assignment, a) and got[("1", True)][0].counts == counts

@@ -87,8 +87,9 @@ def test_sweep_script_two_ranks_gloo(tmp_path):
 
 
 def test_sweep_script_two_ranks_one_fails_gloo(tmp_path):
-    """One rank's tensor fails (MTQ_FAULT_INJECT): it still takes part in the gather / verdict broadcast / barrier, and every
-    rank exits non-zero instead of the job hanging in a collective."""
+    """One rank's tensor fails: it still takes part in the gather / verdict broadcast / barrier, and every rank exits non-zero
+    instead of the job hanging in a collective.  The fault is injected by this test's launcher (rank 0's loader raises): the
+    script carries no test hook."""
     import os
     import socket
 
@@ -97,9 +98,23 @@ def test_sweep_script_two_ranks_one_fails_gloo(tmp_path):
     port = s.getsockname()[1]
     s.close()
     script = str(ROOT / "scripts" / "sweep_mixed_tile_threshold.py")
-    env = dict(os.environ, PYTHONPATH=str(ROOT), HSA_ENABLE_IPC_MODE_LEGACY="0", MTQ_FAULT_INJECT="rank:0")
+    env = dict(os.environ, PYTHONPATH=str(ROOT), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    launcher = tmp_path / "sweep_faulty.py"
+    launcher.write_text(
+        "import os, runpy, sys\n"
+        f"sys.path.insert(0, {str(ROOT)!r})\n"
+        "from quantization_analysis_amd import model_source\n"
+        "real = model_source.ModelIndex.load\n"
+        "def faulty(self, *a, **k):\n"
+        "    rank = int(os.environ.get('RANK', '0'))\n"
+        "    if rank == 0:\n"
+        "        raise RuntimeError(f'injected fault on rank {rank}')\n"
+        "    return real(self, *a, **k)\n"
+        "model_source.ModelIndex.load = faulty\n"
+        f"sys.argv[0] = {script!r}\n"
+        f"runpy.run_path({script!r}, run_name='__main__')\n")
     two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                          "--master-port", str(port), script, "synthetic:tiny", "layers", "--steps", "4", "--lowest-metric-val", "0.95", "--no-plots",
+                          "--master-port", str(port), str(launcher), "synthetic:tiny", "layers", "--steps", "4", "--lowest-metric-val", "0.95", "--no-plots",
                           "--out-dir", str(tmp_path / "two")], capture_output=True, text=True, timeout=300, env=env)
     assert two.returncode != 0
     assert "injected fault on rank 0" in two.stdout and "[rank 1]" in two.stdout and "Wrote sweep results" not in two.stdout
