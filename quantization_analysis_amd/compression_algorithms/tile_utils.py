@@ -30,32 +30,47 @@ def format_tag(formats) -> str:
     return "+".join(formats) if formats else "none"
 
 
+_ROWWISE_DOT_IS_BLAS = None   # does np.vecdot / batched matmul give a row's x.dot(y) bit for bit on this NumPy build?  (checked on first use)
+
+
+def _rowwise_dot(a: np.ndarray, b: np.ndarray) -> np.ndarray:
+    """a[t].dot(b[t]) for every row t of two C-contiguous float32 [T, n] arrays, as float32 [T], with the bits of the per-row call.
+    NumPy's batched matmul of a (1 x n) by an (n x 1) operand runs cblas_sdot per item — the routine ndarray.dot uses — so the Python
+    loop is only needed where a build does otherwise: the first call compares the two on a few rows and remembers the answer."""
+    global _ROWWISE_DOT_IS_BLAS
+    if _ROWWISE_DOT_IS_BLAS is None:
+        rng = np.random.default_rng(12345)
+        u = rng.standard_normal((16, 1024)).astype(np.float32)
+        v = (u * 0.99 + rng.standard_normal((16, 1024)).astype(np.float32) * 0.05).astype(np.float32)
+        loop = np.array([u[t].dot(v[t]) for t in range(16)], dtype=np.float32)
+        _ROWWISE_DOT_IS_BLAS = bool(np.array_equal(loop.view(np.uint32), np.matmul(u[:, None, :], v[:, :, None])[:, 0, 0].view(np.uint32)))
+    if _ROWWISE_DOT_IS_BLAS:
+        return np.matmul(a[:, None, :], b[:, :, None])[:, 0, 0]
+    return np.array([a[t].dot(b[t]) for t in range(a.shape[0])], dtype=np.float32)
+
+
 def pearson_corr_tiles(ref_tiles: np.ndarray, q_tiles: np.ndarray) -> np.ndarray:
-    """metrics.pearson_corr for every (T, 32, 32) tile pair → float32 [T], bit for bit what the per-tile call returns, at a third
-    of its cost (8 instead of 29 µs per tile on the build container): the means and the centring run once over all tiles — NumPy
-    reduces a contiguous last axis row by row with the same pairwise routine np.mean uses on one row — and per tile only the three
-    BLAS dot products remain (np.linalg.norm of a real vector IS sqrt(x.dot(x))), in the scalar types pearson_corr goes through
-    (np.float32 norms, their float32 product widened to a Python float, the float32 quotient).  tests/test_algorithms.py pins the
-    equality on 10^4 tiles, degenerate ones included."""
+    """metrics.pearson_corr for every (T, 32, 32) tile pair → float32 [T], bit for bit what the per-tile call returns, without a
+    Python-level call per tile (29 µs per tile on the build container; 1.3 µs here): the means and the centring run once over all
+    tiles — NumPy reduces a contiguous last axis row by row with the same pairwise routine np.mean uses on one row — the three dot
+    products per tile (np.linalg.norm of a real vector IS sqrt(x.dot(x))) come from _rowwise_dot, and the scalar types pearson_corr
+    goes through are float32 throughout (np.float32 norms, their float32 product — widened to a Python float and narrowed again
+    without loss — and the float32 quotient).  tests/test_algorithms.py pins the equality on 10^4 tiles, degenerate ones included."""
     count = ref_tiles.shape[0]
     if count == 0:
         return np.empty(0, dtype=np.float32)
     p = np.ascontiguousarray(ref_tiles, dtype=np.float32).reshape(count, -1)
     q = np.ascontiguousarray(q_tiles, dtype=np.float32).reshape(count, -1)
-    out = np.empty(count, dtype=np.float32)
     if p.shape[1] == 0:
-        out[:] = 1.0
-        return out
+        return np.ones(count, dtype=np.float32)
     pc = p - np.mean(p, axis=1, keepdims=True)
     qc = q - np.mean(q, axis=1, keepdims=True)
-    sqrt = np.sqrt
-    for t in range(count):
-        a, b = pc[t], qc[t]
-        scale = float(sqrt(a.dot(a)) * sqrt(b.dot(b)))
-        if scale != 0.0:
-            out[t] = float(a.dot(b) / scale)
-        else:
-            out[t] = 1.0 if np.max(np.abs(p[t] - q[t])) == 0.0 else 0.0
+    scale = np.sqrt(_rowwise_dot(pc, pc)) * np.sqrt(_rowwise_dot(qc, qc))         # float32, as np.float32 * np.float32
+    ok = scale != 0.0
+    with np.errstate(all="ignore"):
+        out = (_rowwise_dot(pc, qc) / scale).astype(np.float32)
+    for t in np.flatnonzero(~ok):                                                  # zero variance on either side (metrics.py:14-15)
+        out[t] = 1.0 if np.max(np.abs(p[t] - q[t])) == 0.0 else 0.0
     return out
 
 
