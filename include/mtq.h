@@ -117,6 +117,17 @@ int mtq_tile_stats_partial(const void *x, int in_dtype, int64_t count, int64_t s
                            int64_t rows, int64_t cols, int64_t ld,
                            uint32_t layout_mask, uint32_t full_mask, uint32_t sums_mask, double *stats, void *stream);
 
+/* mtq_tile_stats_partial as two launches the caller places itself (bf16 storage in whole 32x128 units with 16-byte aligned rows;
+ * MTQ_ERR_UNSUPPORTED otherwise): _begin launches the exact-integer kernel alone — it resets its own unit counters, and stores *launch_id
+ * (returned to the host) into the device word *mark if it meets a tile it cannot take; _end, given that id, recomputes those tiles by the
+ * literal route (it returns at once when *mark holds another value).  The records are complete behind _end.  The streamed driver puts
+ * _begin on its K1 stream, where nothing then sits between two K1 launches, and _end on the batch's search stream. */
+int mtq_tile_stats_partial_begin(const void *x, int in_dtype, int64_t count, int64_t stride_elems, int64_t rows, int64_t cols, int64_t ld,
+                                 uint32_t layout_mask, uint32_t full_mask, uint32_t sums_mask, double *stats, uint32_t *mark,
+                                 uint32_t *launch_id_out, void *stream);
+int mtq_tile_stats_partial_end(const void *x, int in_dtype, int64_t count, int64_t stride_elems, int64_t rows, int64_t cols, int64_t ld,
+                               uint32_t layout_mask, double *stats, const uint32_t *mark, uint32_t launch_id, void *stream);
+
 /*
  * K1 for a list of tiles: what mtq_tile_stats_partial left out, for the tiles that turn out to need it.  listed[0 .. *n_listed) (device;
  * at most `capacity` entries are read) names tiles as tensor * tiles + tile; for each of them the five statistics of the formats in

@@ -17,6 +17,9 @@ constexpr int kWorkGroups = 64, kWorkStride = 32, kWorkSlots = 128;
 // Word 1 of a slot carries the id of the last launch that marked a tile for the literal fix-up (ids are unique per launch,
 // so the word never needs resetting): the follow-up kernel returns at once unless it finds its own launch's id there.
 constexpr int kWorkStamp = 1;
+// Word 2 of a slot counts the waves of the launch that have finished (exact-integer bf16 kernel): the wave that completes the count sets
+// the unit counters and this word back to zero, so that launch needs no follow-up kernel for the reset (round 3).
+constexpr int kWorkDone = 2;
 unsigned next_launch_id();
 struct WorkSlot { unsigned *counters = nullptr; int index = -1, device = -1; };
 // MTQ_OK and a slot whose previous user `stream` now waits for, or MTQ_ERR_HIP.

@@ -294,7 +294,7 @@ template <uint32_t SUMS, uint32_t ERRS, bool XS, bool LISTED>
 __global__ __launch_bounds__(kFastWaves * 64, rolled_waves(SUMS, ERRS)) void tile_stats_bf16_rolled(
     const uint16_t *__restrict__ x, int64_t stride, int64_t ld, int tiles_w, int64_t tiles, int units_w, int units_per_tensor,
     int total_units, uint32_t fmt_mask, uint32_t eval_mask, uint32_t part_mask, int rec, double *__restrict__ stats, unsigned *__restrict__ work,
-    unsigned launch_id, int units_per_wave, ListedArgs la)
+    unsigned launch_id, int units_per_wave, ListedArgs la, unsigned *__restrict__ mark, int self_reset)
 {
     // fmt_mask: the record LAYOUT (which slots exist); eval_mask ⊂ fmt_mask: the slots this launch writes; part_mask ⊂ eval_mask: those
     // of them that only get Σy, Σy², Σxy.  Slots of the layout that are not written hold NaN afterwards (mtq_tile_stats_partial).
@@ -523,6 +523,7 @@ __global__ __launch_bounds__(kFastWaves * 64, rolled_waves(SUMS, ERRS)) void til
         if (tile_bad && j == 0) {
             rec_t[0] = __longlong_as_double((long long)kRedoMagic);
             work[kWorkStamp] = launch_id;                                         // tells the follow-up kernel there is something to redo
+            if (mark) *mark = launch_id;                                          // … and the caller's own word, where the fix-up is the caller's launch (mtq_tile_stats_partial_begin / _end)
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 
@@ -537,6 +538,17 @@ __global__ __launch_bounds__(kFastWaves * 64, rolled_waves(SUMS, ERRS)) void til
         if (lane < nrec) out[lane] = r0;
         if (lane + 64 < nrec) out[lane + 64] = r1;
         u = u_next;
+    }
+    if constexpr (!LISTED) {
+        // The launch resets its own unit counters: every wave of the grid ends here once, and the one that completes the count knows that
+        // no other wave will touch the counters again (each wave's last claim returned before it counted itself).
+        if (self_reset && lane == 0) {
+            const unsigned waves = gridDim.x * (unsigned)kFastWaves;
+            if (__hip_atomic_fetch_add(work + kWorkDone, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == waves - 1u) {
+                for (int g = 0; g < kWorkGroups; ++g) __hip_atomic_store(work + g * kWorkStride, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(work + kWorkDone, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
     }
 }
 
@@ -561,7 +573,7 @@ static int fast_cus()
 // (served for the combinations instantiated below; any other part_mask is widened to full slots, which is always allowed).
 extern "C" int mtq_launch_tile_stats_bf16_fast(const void *x, int64_t count, int64_t stride_elems, int64_t rows, int64_t cols,
                                                int64_t ld, uint32_t fmt_mask, uint32_t eval_mask, uint32_t part_mask, double *stats, void *stream,
-                                               mtq::WorkSlot *work_out, unsigned launch_id)
+                                               mtq::WorkSlot *work_out, unsigned launch_id, unsigned *mark, int self_reset)
 {
     const int64_t th = rows / kTile, tw = cols / kTile, tiles = th * tw;
     const int64_t units_w = cols / kUnitCols, upt = th * units_w, total = count * upt;
@@ -601,7 +613,7 @@ extern "C" int mtq_launch_tile_stats_bf16_fast(const void *x, int64_t count, int
     unsigned *work = work_out->counters;
     const ListedArgs none{};
 #define MTQ_LAUNCH_FAST(S, E) \
-    hipLaunchKernelGGL((tile_stats_bf16_rolled<S, E, true, false>), grid, block, lds_bytes, st, xp, stride_elems, ld, (int)tw, tiles, (int)units_w, (int)upt, (int)total, fmt_mask, eval_mask, part_mask, rec, stats, work, launch_id, (need > max_blocks ? upw : 0), none)
+    hipLaunchKernelGGL((tile_stats_bf16_rolled<S, E, true, false>), grid, block, lds_bytes, st, xp, stride_elems, ld, (int)tw, tiles, (int)units_w, (int)upt, (int)total, fmt_mask, eval_mask, part_mask, rec, stats, work, launch_id, (need > max_blocks ? upw : 0), none, mark, self_reset)
     switch (sums | (errs << 4)) { // one instantiation per evaluated subset: what is not asked for costs nothing
     case 0x11: MTQ_LAUNCH_FAST(1u, 1u); break;
     case 0x22: MTQ_LAUNCH_FAST(2u, 2u); break;
@@ -646,7 +658,7 @@ extern "C" int mtq_launch_tile_stats_bf16_listed(const void *x, int64_t count, i
     const ListedArgs la{list, n_list, cap, redo, n_redo, (uint32_t)tw};
     const uint32_t eval = (full_mask | err_mask) & fmt_mask;
 #define MTQ_LAUNCH_LISTED_FAST(S, E) \
-    hipLaunchKernelGGL((tile_stats_bf16_rolled<S, E, false, true>), grid, block, lds_bytes, st, xp, stride_elems, ld, (int)tw, tiles, 0, 0, 0, fmt_mask, eval, 0u, rec, stats, (unsigned *)nullptr, 0u, 0, la)
+    hipLaunchKernelGGL((tile_stats_bf16_rolled<S, E, false, true>), grid, block, lds_bytes, st, xp, stride_elems, ld, (int)tw, tiles, 0, 0, 0, fmt_mask, eval, 0u, rec, stats, (unsigned *)nullptr, 0u, 0, la, (unsigned *)nullptr, 0)
     if (sums == 4u) MTQ_LAUNCH_LISTED_FAST(4u, 6u);
     else MTQ_LAUNCH_LISTED_FAST(2u, 3u);
 #undef MTQ_LAUNCH_LISTED_FAST

@@ -93,6 +93,27 @@ __global__ __launch_bounds__(256) void tile_stats_redo_flagged(const T *__restri
 }
 constexpr int64_t kRedoBlocks = 512;
 
+// The fix-up as a launch of its own (mtq_tile_stats_partial_end): the same search for marked records, decided by the caller's word.
+__global__ __launch_bounds__(256) void tile_stats_redo_marked(const uint16_t *__restrict__ x, int64_t count, int64_t stride, int64_t rows, int64_t cols, int64_t ld,
+                                                              int tiles_w, int64_t tiles, uint32_t fmt_mask, int rec, double *__restrict__ stats, int vec_ok,
+                                                              const unsigned *__restrict__ mark, unsigned launch_id)
+{
+    if (*mark != launch_id) return;                                     // no tile of that launch was marked (the usual case)
+    const int lane = threadIdx.x & 63;
+    const int64_t total = count * tiles;
+    for (int64_t first = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 64; first < total; first += (int64_t)gridDim.x * 4 * 64) {
+        const int64_t mine = first + lane;
+        bool flagged = false;
+        if (mine < total) flagged = (unsigned long long)__double_as_longlong(stats[mine * rec]) == kRedoMagicGeneric;
+        unsigned long long todo = __ballot(flagged);
+        while (todo) {
+            const int k = __builtin_ctzll(todo);
+            todo &= todo - 1;
+            tile_stats_one<uint16_t>(x, first + k, stride, rows, cols, ld, tiles_w, tiles, fmt_mask, rec, stats, vec_ok);
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // K2 / K3: one thread per shared-exponent group; fmt >= 0 → that format everywhere (K2),
 // fmt < 0 → the format named by map[tile] (K3).  Output float32.
@@ -263,7 +284,7 @@ using namespace mtq;
 
 extern "C" int mtq_launch_tile_stats_bf16_fast(const void *x, int64_t count, int64_t stride_elems, int64_t rows, int64_t cols,
                                                int64_t ld, uint32_t fmt_mask, uint32_t eval_mask, uint32_t part_mask, double *stats, void *stream,
-                                               mtq::WorkSlot *work_out, unsigned launch_id);
+                                               mtq::WorkSlot *work_out, unsigned launch_id, unsigned *mark, int self_reset);
 extern "C" int mtq_launch_tile_stats_direct(const void *x, int in_dtype, int64_t count, int64_t stride_elems, int64_t rows, int64_t cols,
                                             int64_t ld, uint32_t fmt_mask, double *stats, int vec_ok, void *stream, mtq::WorkSlot *work_out, unsigned launch_id);
 
@@ -528,7 +549,7 @@ static int tile_stats_launch(const void *x, int in_dtype, int64_t count, int64_t
         const unsigned launch_id = next_launch_id();
         // the exact-integer kernel serves partial evaluation; every other route below writes the whole layout (always allowed)
         const uint32_t ev = (eval_mask & 0xEu) ? eval_mask : fmt_mask;
-        if (int rc = mtq_launch_tile_stats_bf16_fast(x, count, stride_elems, rows, cols, ld, fmt_mask, ev, ev == eval_mask ? part_mask : 0u, stats, stream, &work, launch_id)) {
+        if (int rc = mtq_launch_tile_stats_bf16_fast(x, count, stride_elems, rows, cols, ld, fmt_mask, ev, ev == eval_mask ? part_mask : 0u, stats, stream, &work, launch_id, nullptr, 0)) {
             work_counter_abandon(work);                  // the launch never happened: the slot keeps its previous user's event
             return rc;
         }
@@ -578,6 +599,52 @@ extern "C" int mtq_tile_stats_partial(const void *x, int in_dtype, int64_t count
         return fail(MTQ_ERR_INVALID, "full_mask and sums_mask must be disjoint subsets of layout_mask");
     if (sums_mask & 1u) return fail(MTQ_ERR_INVALID, "the bf16 slot has no partial form");
     return tile_stats_launch(x, in_dtype, count, stride_elems, rows, cols, ld, layout_mask, full_mask | sums_mask, sums_mask, stats, stream);
+}
+
+// mtq_tile_stats_partial in two launches the caller places itself: _begin is the exact-integer kernel alone (it resets its own unit
+// counters and leaves its launch id in *mark when it meets a tile it cannot take), _end the literal fix-up of those tiles.  The
+// streamed driver issues _begin on its K1 stream — nothing then sits between two K1 launches — and _end on the batch's search stream.
+extern "C" int mtq_tile_stats_partial_begin(const void *x, int in_dtype, int64_t count, int64_t stride_elems, int64_t rows, int64_t cols,
+                                            int64_t ld, uint32_t layout_mask, uint32_t full_mask, uint32_t sums_mask, double *stats,
+                                            uint32_t *mark, uint32_t *launch_id_out, void *stream)
+{
+    if (!mark || !launch_id_out) return fail(MTQ_ERR_INVALID, "null argument");
+    if (((full_mask | sums_mask) & ~layout_mask) != 0 || (full_mask & sums_mask) != 0 || (layout_mask & ~MTQ_MASK_ALL) != 0 || (sums_mask & 1u))
+        return fail(MTQ_ERR_INVALID, "full_mask and sums_mask must be disjoint subsets of layout_mask (and the bf16 slot has no partial form)");
+    if (int rc = check_matrix(x, in_dtype, rows, cols, ld)) return rc;
+    if (!stats || count <= 0) return fail(MTQ_ERR_INVALID, "stats is null or count is not positive");
+    if (int rc = require_device()) return rc;
+    const int64_t th = (rows + kTile - 1) / kTile, tw = (cols + kTile - 1) / kTile, tiles = th * tw;
+    if (tw > INT32_MAX || count * tiles > ((int64_t)1 << 33)) return fail(MTQ_ERR_INVALID, "too many tiles for one launch");
+    const uint32_t eval = full_mask | sums_mask;
+    const int vec_ok = aligned16(x) && (ld * 2) % 16 == 0 && (stride_elems * 2) % 16 == 0;
+    if (!(in_dtype == MTQ_DTYPE_BF16 && vec_ok && rows % kTile == 0 && cols % 128 == 0 && (eval & 0xEu) != 0 && !force_generic()))
+        return fail(MTQ_ERR_UNSUPPORTED, "the two-launch form serves bf16 storage in whole 32x128 units with 16-byte aligned rows: use mtq_tile_stats_partial");
+    WorkSlot work;
+    const unsigned launch_id = next_launch_id();
+    if (int rc = mtq_launch_tile_stats_bf16_fast(x, count, stride_elems, rows, cols, ld, layout_mask, eval, sums_mask, stats, stream, &work, launch_id, mark, 1)) {
+        work_counter_abandon(work);
+        return rc;
+    }
+    work_counter_release(work, stream);   // the kernel has reset the counters when it ends: the slot's next user is ordered behind it
+    *launch_id_out = launch_id;
+    return MTQ_OK;
+}
+
+extern "C" int mtq_tile_stats_partial_end(const void *x, int in_dtype, int64_t count, int64_t stride_elems, int64_t rows, int64_t cols,
+                                          int64_t ld, uint32_t layout_mask, double *stats, const uint32_t *mark, uint32_t launch_id, void *stream)
+{
+    if (!mark || !stats) return fail(MTQ_ERR_INVALID, "null argument");
+    if (int rc = check_matrix(x, in_dtype, rows, cols, ld)) return rc;
+    if (in_dtype != MTQ_DTYPE_BF16 || count <= 0 || (layout_mask & ~MTQ_MASK_ALL) != 0) return fail(MTQ_ERR_INVALID, "arguments do not belong to a mtq_tile_stats_partial_begin launch");
+    if (int rc = require_device()) return rc;
+    const int64_t th = (rows + kTile - 1) / kTile, tw = (cols + kTile - 1) / kTile, tiles = th * tw;
+    const int rec = (int)mtq_stats_record_doubles(layout_mask);
+    const int vec_ok = aligned16(x) && (ld * 2) % 16 == 0 && (stride_elems * 2) % 16 == 0;
+    const int64_t waves = (count * tiles + 63) / 64;
+    hipLaunchKernelGGL(tile_stats_redo_marked, dim3((unsigned)std::min<int64_t>((waves + 3) / 4, kRedoBlocks)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       static_cast<const uint16_t *>(x), count, stride_elems, rows, cols, ld, (int)tw, tiles, layout_mask, rec, stats, vec_ok, mark, launch_id);
+    return check_launch("mtq_tile_stats_partial_end");
 }
 
 extern "C" int mtq_tile_stats(const void *x, int in_dtype, int64_t rows, int64_t cols, int64_t ld, uint32_t fmt_mask,

@@ -25,7 +25,7 @@ TILE = 32
 # every symbol include/mtq.h declares (tests check the library exports exactly these)
 EXPORTS = [
     "mtq_version", "mtq_last_error", "mtq_device_count", "mtq_stats_record_doubles",
-    "mtq_shutdown", "mtq_tile_stats", "mtq_tile_stats_batched", "mtq_tile_stats_partial", "mtq_tile_stats_listed", "mtq_quantize", "mtq_apply_assignment", "mtq_dequant_fp8_block", "mtq_pack_slim_records",
+    "mtq_shutdown", "mtq_tile_stats", "mtq_tile_stats_batched", "mtq_tile_stats_partial", "mtq_tile_stats_partial_begin", "mtq_tile_stats_partial_end", "mtq_tile_stats_listed", "mtq_quantize", "mtq_apply_assignment", "mtq_dequant_fp8_block", "mtq_pack_slim_records",
     "mtq_greedy_create", "mtq_greedy_pass", "mtq_greedy_assignment", "mtq_greedy_fixed",
     "mtq_greedy_counts", "mtq_greedy_value", "mtq_greedy_destroy",
     "mtq_greedy_run_chain", "mtq_greedy_run_chain_batch", "mtq_pack_chain_records", "mtq_tile_scores", "mtq_threshold_assign", "mtq_columns_from_stats", "mtq_columns_from_sums", "mtq_tile_scores_device",
@@ -77,6 +77,8 @@ def lib() -> ctypes.CDLL:
     L.mtq_tile_stats.argtypes = [vp, ci, i64, i64, i64, u32, vp, vp]
     L.mtq_tile_stats_batched.argtypes = [vp, ci, i64, i64, i64, i64, i64, u32, vp, vp]
     L.mtq_tile_stats_partial.argtypes = [vp, ci, i64, i64, i64, i64, i64, u32, u32, u32, vp, vp]
+    L.mtq_tile_stats_partial_begin.argtypes = [vp, ci, i64, i64, i64, i64, i64, u32, u32, u32, vp, vp, ctypes.POINTER(u32), vp]
+    L.mtq_tile_stats_partial_end.argtypes = [vp, ci, i64, i64, i64, i64, i64, u32, vp, vp, u32, vp]
     L.mtq_quantize.argtypes = [vp, ci, i64, i64, i64, ci, vp, i64, vp]
     L.mtq_apply_assignment.argtypes = [vp, ci, i64, i64, i64, vp, vp, i64, vp]
     L.mtq_dequant_fp8_block.argtypes = [vp, vp, i64, i64, i64, i64, i64, vp, i64, vp]
@@ -331,6 +333,23 @@ def tile_stats_partial(x3d, layout_mask: int, full_mask: int, sums_mask: int, ou
     check(lib().mtq_tile_stats_partial(x3d.data_ptr(), _dtype_code(x3d), count, rows * cols, rows, cols, cols, layout_mask, full_mask, sums_mask,
                                        out.data_ptr(), _stream_ptr()))
     return out
+
+
+def tile_stats_partial_begin(x3d, layout_mask: int, full_mask: int, sums_mask: int, out, mark) -> int:
+    """mtq_tile_stats_partial_begin on the current stream (the exact-integer kernel alone) → the launch id tile_stats_partial_end wants.
+    mark: int32 device tensor of one element that stays the caller's until _end has run."""
+    count, rows, cols = x3d.shape
+    lid = ctypes.c_uint32(0)
+    check(lib().mtq_tile_stats_partial_begin(x3d.data_ptr(), _dtype_code(x3d), count, rows * cols, rows, cols, cols, layout_mask, full_mask, sums_mask,
+                                             out.data_ptr(), mark.data_ptr(), ctypes.byref(lid), _stream_ptr()))
+    return int(lid.value)
+
+
+def tile_stats_partial_end(x3d, layout_mask: int, stats, mark, launch_id: int) -> None:
+    """mtq_tile_stats_partial_end on the current stream: the literal fix-up of the tiles that launch could not take (usually none)."""
+    count, rows, cols = x3d.shape
+    check(lib().mtq_tile_stats_partial_end(x3d.data_ptr(), _dtype_code(x3d), count, rows * cols, rows, cols, cols, layout_mask, stats.data_ptr(),
+                                           mark.data_ptr(), int(launch_id), _stream_ptr()))
 
 
 def quantize(x2d, fmt: str, out=None):

@@ -426,6 +426,7 @@ class GreedyPipeline:
             "carry": flat("carry", int(hb.lib().mtq_scan_carry_bytes(count)), torch.uint8),
             "lscr": flat("lscr", count * tiles + count, torch.int32),
             "n_listed_host": flat("n_listed_host", count, torch.int32, pinned=True),
+            "mark": flat("mark", count, torch.int32),   # per chunk: id of the K1 launch that met a tile for the literal fix-up (mtq_tile_stats_partial_begin / _end)
         })
         for f, pm in zip(self.pure_formats, b["pure_maps"]):
             pm.fill_(MIXED_TILE_FORMATS.index(f))
@@ -479,7 +480,14 @@ class GreedyPipeline:
                 e0 = torch.cuda.Event(enable_timing=True)
                 e1 = torch.cuda.Event(enable_timing=True)
                 e0.record(self.stream)
-                if lazy:
+                # bf16 storage in whole 32x128 units: K1 as the exact-integer kernel alone (it resets its own unit counters), its literal
+                # fix-up — usually nothing to do — on the search stream: nothing sits between two K1 launches on this stream
+                two_launch = x3d.dtype == torch.bfloat16 and (k1_mask & 1) == 0 and rows % 32 == 0 and cols % 128 == 0 and os.environ.get("MTQ_K1_TWO_LAUNCH", "1") != "0"
+                k1_id = None
+                if two_launch:
+                    k1_id = hb.tile_stats_partial_begin(x3d[first:first + n], k1_mask, full_now if lazy else k1_mask, prev_bit if lazy else 0,
+                                                        b["dev"][first:first + n], b["mark"][ci:ci + 1])
+                elif lazy:
                     hb.tile_stats_partial(x3d[first:first + n], k1_mask, full_now, prev_bit, out=b["dev"][first:first + n])
                 else:
                     hb.tile_stats_batched(x3d[first:first + n], k1_mask, out=b["dev"][first:first + n])
@@ -498,6 +506,8 @@ class GreedyPipeline:
                 b["seeds_dev"][first:first + n].copy_(b["seeds_host"][first:first + n], non_blocking=True)
                 recs = b["dev"][first:first + n]
                 maps = b["maps_dev"][first:first + n]
+                if k1_id is not None:
+                    hb.tile_stats_partial_end(x3d[first:first + n], k1_mask, recs, b["mark"][ci:ci + 1], k1_id)
                 if shared and first > 0:
                     scan_stream.wait_event(orders_ready)
                 args = (recs, dec_mask, self.tile_formats, self.metric, self.threshold, float(n_el), b["seeds_dev"][first:first + n], maps,

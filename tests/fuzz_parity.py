@@ -51,12 +51,57 @@ def eq(a, b):
                           np.where(both, 0, b.view(np.uint64 if b.dtype == np.float64 else np.uint32)))
 
 
+def zero_denominator(full, formats, thr, numel, seed) -> bool:
+    """Does the host scan meet its zero-denominator branch (mixed_tile_greedy.py:186-189) on these records?  The slim records (no Σ|x−y|)
+    refuse exactly such a search."""
+    keep = [0, 1] + [2 + 5 * s_ + k for s_ in range(4) for k in range(3)]
+    try:
+        hb.greedy_run(np.ascontiguousarray(full[:, keep]), 0xF | hb.MASK_SLIM, formats, "pcc", thr, numel, seed)
+        return False
+    except hb.MtqError as exc:
+        if "zero-variance" not in str(exc):
+            raise
+        return True
+
+
+def search_variants(xd, a, thr, seed) -> bool:
+    """The device search with the launch's shared orders, and (bf16 storage, whole 32x128 units) split in phases on partial records
+    with the listed completion in between, against the oracle's map `a` (status 0 expected: the caller has excluded degenerate tensors)."""
+    L = hb.lib()
+    x3 = xd[None].contiguous()
+    rows, cols = xd.shape
+    ident = xd.dtype == torch.bfloat16
+    k1 = 0xE if ident else 0xF
+    dec = k1 | hb.MASK_BF16_IDENTITY if ident else k1
+    recs = hb.tile_stats_batched(x3, k1)
+    T = recs.shape[1]
+    sd = torch.tensor([seed], dtype=torch.int64, device="cuda")
+    scratch = torch.empty((int(L.mtq_greedy_scan_scratch_bytes(1, T)),), dtype=torch.uint8, device="cuda")
+    maps = torch.empty((1, T), dtype=torch.int8, device="cuda")
+    status = torch.empty((1,), dtype=torch.int32, device="cuda")
+    orders = hb.scan_orders_device(seed, T, 2)
+    hb.greedy_scan_device_ex(recs, dec, ALL, "pcc", thr, float(rows * cols), sd, maps, status, scratch, orders=orders)
+    ok = int(status.cpu()[0]) == 0 and np.array_equal(maps.cpu().numpy().reshape(a.shape), a)
+    if ident and rows % 32 == 0 and cols % 128 == 0:
+        part = hb.tile_stats_partial(x3, 0xE, 0x2, 0x4)
+        listed = torch.empty((T,), dtype=torch.int32, device="cuda")
+        nl = torch.zeros((1,), dtype=torch.int32, device="cuda")
+        carry = torch.empty((int(L.mtq_scan_carry_bytes(1)),), dtype=torch.uint8, device="cuda")
+        maps.fill_(-1)
+        hb.greedy_scan_device_ex(part, dec, ALL, "pcc", thr, float(rows * cols), sd, maps, status, scratch, orders=orders, phase=1, listed=listed, n_listed=nl, carry=carry)
+        hb.tile_stats_listed(x3, 0xE, 0x8, 0x4, listed, nl, part, scratch=torch.empty((T + 1,), dtype=torch.int32, device="cuda"))
+        hb.greedy_scan_device_ex(part, dec, ALL, "pcc", thr, float(rows * cols), sd, maps, status, scratch, phase=2, carry=carry)
+        ok &= int(status.cpu()[0]) == 0 and np.array_equal(maps.cpu().numpy().reshape(a.shape), a)
+    return bool(ok)
+
+
 def run(cases: int, seed: int) -> int:
     """→ number of mismatching cases (each one is printed)."""
     rng = np.random.default_rng(seed)
     hb.require_gpu()
     t0 = time.time()
     bad = 0
+    compared = handed_back = specials = specials_back = 0
     for c in range(cases):
         aligned = rng.random() < 0.4
         rows = int(rng.integers(1, 6)) * 32 if aligned else int(rng.integers(1, 200))
@@ -87,9 +132,19 @@ def run(cases: int, seed: int) -> int:
                 sd = torch.tensor([7], dtype=torch.int64, device="cuda")
                 cnt = torch.zeros((1, 4), dtype=torch.int32, device="cuda")
                 dm, ds = hb.greedy_scan_device(recs_d, 0xF, ALL, "pcc", thr, float(x.size), sd, counts_out=cnt)
-                if int(ds.cpu()[0]) == 0:   # status 1 (zero denominator met) hands the tensor to the host scan
+                # status 1 (zero denominator met) hands the tensor to the host scan — exactly when the host scan itself meets that branch
+                # (slim records refuse such a tensor): a device scan that handed everything back would otherwise pass unnoticed
+                degenerate = zero_denominator(full, ALL, thr, float(x.size), 7)
+                compared += 1
+                handed_back += int(ds.cpu()[0]) != 0
+                ok_g &= (int(ds.cpu()[0]) != 0) == degenerate
+                if int(ds.cpu()[0]) == 0:
                     ok_g &= np.array_equal(dm.cpu().numpy().reshape(a.shape), a)
                     ok_g &= cnt.cpu().numpy()[0].tolist() == [int(np.sum(a == k)) for k in range(4)]
+                # round 3: the launch's shared visiting orders (helper wave), and — bf16 storage in whole 32x128 units — the search in
+                # phases on partial records with the listed completion in between (what the streamed driver runs)
+                if not degenerate:
+                    ok_g &= search_variants(xd, a, thr, 7)
                 # the mae search on the device against the host scan on the same records
                 thr_m = float(rng.choice([1e-5, 1e-4, 1e-3])) * max(float(np.abs(x).mean()) / 0.016, 1e-6)
                 gm, _cm, _om = hb.greedy_run(full, 0xF, ALL, "mae", thr_m, float(x.size), 7)
@@ -104,6 +159,10 @@ def run(cases: int, seed: int) -> int:
                 gh, _ch, _oh = hb.greedy_run(full, 0xF, order, "pcc", thr, float(x.size), s2)
                 sd[0] = s2
                 dm, ds = hb.greedy_scan_device(recs_d, 0xF, order, "pcc", thr, float(x.size), sd)
+                degenerate = zero_denominator(full, order, thr, float(x.size), s2)
+                compared += 1
+                handed_back += int(ds.cpu()[0]) != 0
+                ok_g &= (int(ds.cpu()[0]) != 0) == degenerate
                 if int(ds.cpu()[0]) == 0:
                     ok_g &= np.array_equal(dm.cpu().numpy()[0], gh)
                 # the record layouts of the streamed driver: slim (3 doubles per format), slim + identity bf16, chain records
@@ -129,6 +188,8 @@ def run(cases: int, seed: int) -> int:
                 gh, _ch, _oh = hb.greedy_run(full, 0xF, ALL, "pcc", thr, float(x.size), 7)
                 sd = torch.tensor([7], dtype=torch.int64, device="cuda")
                 dm, ds = hb.greedy_scan_device(torch.from_numpy(full).cuda()[None], 0xF, ALL, "pcc", thr, float(x.size), sd)
+                specials += 1
+                specials_back += int(ds.cpu()[0]) != 0
                 if int(ds.cpu()[0]) == 0:
                     ok_g = np.array_equal(dm.cpu().numpy()[0], gh)
                 for met, th2 in (("mae", 1e-4), ("atol", 1e-2)):   # status 0 must mean the host scan's map, whatever the input holds
@@ -139,7 +200,11 @@ def run(cases: int, seed: int) -> int:
         if not (ok and ok_q and ok_a and ok_g and ok_t):
             bad += 1
             print(f"MISMATCH case {c}: shape {(rows, cols)} bf16 {bf16} mask {mask:#x} fmt {fmt}: stats {ok} quantize {ok_q} apply {ok_a} greedy {ok_g}", flush=True)
-    print(f"{cases} cases, {bad} mismatches, {time.time() - t0:.1f} s")
+    print(f"{cases} cases, {bad} mismatches, {time.time() - t0:.1f} s; device pcc searches compared {compared}, handed back {handed_back} "
+          f"(each checked against the host scan's zero-denominator branch); special-value inputs {specials}, handed back {specials_back}")
+    if compared and handed_back > compared // 2:
+        print("more than half of the device searches were handed back: the comparison is not comparing")
+        bad += 1
     return bad
 
 

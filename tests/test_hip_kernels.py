@@ -996,9 +996,12 @@ def test_lazy_pipeline_equals_whole_record_pipeline(monkeypatch):
     g = torch.Generator(device="cuda")
     g.manual_seed(3)
     xs = (torch.randn((6, 256, 512), generator=g, device="cuda") * 0.02).to(torch.bfloat16)
+    xs[1, 32:64, 128:256] *= 1e-28          # groups below the exact route's exponent window: marked by K1, recomputed by the fix-up launch on the search stream
+    xs[4, 200, 300] = 2.0e18                # … and one above it (its square still fits float32)
     got = {}
     for lazy in ("1", "0"):
         monkeypatch.setenv("MTQ_LAZY", lazy)
+        monkeypatch.setenv("MTQ_K1_TWO_LAUNCH", lazy)   # the whole-record run also takes K1 and its fix-up as one call
         for seeds in (None, [2**63 + 1, 5, 5, 2**64 - 1, 9, 123]):
             with GreedyPipeline(ALL, "pcc", 0.999, 2**63 + 12345, chunk=4, workers=2) as pipe:
                 assert (pipe.lazy_plan(xs) is not None) == (lazy == "1")
@@ -1009,7 +1012,7 @@ def test_lazy_pipeline_equals_whole_record_pipeline(monkeypatch):
     for key in (True, False):
         for a, b in zip(got[("1", key)], got[("0", key)]):
             assert np.array_equal(a.assignment, b.assignment) and a.counts == b.counts
-            assert (a.pcc, a.mae, a.atol) == (b.pcc, b.mae, b.atol)
+            assert np.array_equal(np.array([a.pcc, a.mae, a.atol]).view(np.uint64), np.array([b.pcc, b.mae, b.atol]).view(np.uint64))
     x0 = xs[0].float().cpu().numpy()
     a, counts, _st = orc.greedy(x0, ALL, "pcc", 0.999, 2**63 + 12345)
     assert np.array_equal(got[("1", True)][0].assignment, a) and got[("1", True)][0].counts == counts
