@@ -431,6 +431,12 @@ __device__ inline int visit_pass(TileAt tile_at, const double *delta, int nc, in
     int pprev = 0;
     uint32_t pt = 0;
     bool accept_mode = true;
+#ifdef MTQ_SCAN_PROFILE   // tools: ticks of block 0 inside the visit rounds, slots 8 (window fetch), 9 (staging + prefix chains), 10 (pcc), 11 (decision + map), 15 (rounds)
+    unsigned long long vt_ = clock64();
+#define MTQ_VISIT_TICK(slot) do { const unsigned long long now_ = clock64(); if (blockIdx.x == 0 && lane == 0) g_scan_ticks[slot] += now_ - vt_; vt_ = now_; } while (0)
+#else
+#define MTQ_VISIT_TICK(slot) do { } while (0)
+#endif
     int span = 16;   // visits an accept-mode round stages: its three serial chains cost per visit staged, and a run of acceptances is short
                      // where rejections are frequent — 16 after a rejection, 64 after a round that accepted all of its visits
     while (k < nc) {
@@ -455,6 +461,7 @@ __device__ inline int visit_pass(TileAt tile_at, const double *delta, int nc, in
             pprev = (int)__double_as_longlong(ld_l2(d + 3));
             pt = tile_at((uint32_t)(pk + lane));
         }
+        MTQ_VISIT_TICK(8);
         double cy, cy2, cxy;
         if (accept_mode) {   // lane i: the running sums after visits 0..i, added one after the other as the sequential scan adds them
             lds_d[lane * 4 + 0] = dy; lds_d[lane * 4 + 1] = dy2; lds_d[lane * 4 + 2] = dxy;
@@ -470,10 +477,12 @@ __device__ inline int visit_pass(TileAt tile_at, const double *delta, int nc, in
         } else {             // lane i: the running sums plus its own delta
             cy = Sy + dy; cy2 = Sy2 + dy2; cxy = Sxy + dxy;
         }
+        MTQ_VISIT_TICK(9);
         bool special = false;
         const bool good = mae ? cy / n <= thr : pcc_good(n, mean_x, am2, thr, cy, cy2, cxy, special);   // mae: is_good(cab / N) (:293-294)
         const uint64_t act = below(m);
         const uint64_t okm = __ballot(good && active) & act, spm = __ballot(special && active) & act;
+        MTQ_VISIT_TICK(10);
         int j, take = -1;
         if (accept_mode) {
             const uint64_t rej = ~okm & act;
@@ -492,6 +501,10 @@ __device__ inline int visit_pass(TileAt tile_at, const double *delta, int nc, in
             else k += m;
         }
         if (take >= 0) { Sy = readlane_f64(cy, take); Sy2 = readlane_f64(cy2, take); Sxy = readlane_f64(cxy, take); }   // take is wave-uniform
+        MTQ_VISIT_TICK(11);
+#ifdef MTQ_SCAN_PROFILE
+        if (blockIdx.x == 0 && lane == 0) g_scan_ticks[15] += 1;
+#endif
     }
     mem_wait();
     return 0;
@@ -564,7 +577,7 @@ __device__ void scan_tensor(const ScanArgs &a, const Order &ord, int b, unsigned
     int status = 0;
     bool done = false;            // the search is over before the launch's last pass: nothing but the finish is left
 #ifdef MTQ_SCAN_PROFILE
-    if (b == 0 && lane == 0) for (int q = 12; q < 16; ++q) g_scan_ticks[q] = 0;
+    if (b == 0 && lane == 0) for (int q = 8; q < 16; ++q) g_scan_ticks[q] = 0;
     unsigned long long tick_s = clock64();
 #endif
     for (int i = lane; i < kTagSlots / 4; i += 64) cnt[i] = 0u;
