@@ -356,6 +356,26 @@ __device__ inline void prefix_chain(const double *lds_d, double *lds_p, int lane
     }
 }
 
+// The same chain run by EVERY lane (lane l ≥ 3 repeats a fourth, unused column: rows are [4] wide): no exec-masked region, so that the
+// compiler can interleave its dependent additions with independent work of the same basic block (visit_pass, the accepting run).
+__device__ inline void prefix_chain_all(const double *lds_d, double *lds_p, int col, double s)
+{
+    double v[16], w[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) v[u] = lds_d[u * 4 + col];
+#pragma unroll
+    for (int i0 = 0; i0 < 64; i0 += 16) {
+        if (i0 + 16 < 64) {
+#pragma unroll
+            for (int u = 0; u < 16; ++u) w[u] = lds_d[(i0 + 16 + u) * 4 + col];
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) { s = s + v[u]; lds_p[(i0 + u) * 4 + col] = s; }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) v[u] = w[u];
+    }
+}
+
 // pcc_hoisted of csrc/mtq_host.cpp (mixed_tile_greedy.py:176-190 with the x-only terms hoisted): the same operations in the
 // same order.  special: zero denominator.
 __device__ inline bool pcc_good(double n, double mean_x, double am2, double thr, double sy, double sy2, double sxy, bool &special)
@@ -439,7 +459,61 @@ __device__ inline int visit_pass(TileAt tile_at, const double *delta, int nc, in
 #endif
     int span = 16;   // visits an accept-mode round stages: its three serial chains cost per visit staged, and a run of acceptances is short
                      // where rejections are frequent — 16 after a rejection, 64 after a round that accepted all of its visits
+    double *lds_d2 = lds_p + 64 * 4 + 64 * 5, *lds_p2 = lds_d2 + 64 * 4;   // second staging / prefix blocks (behind lds_i) for the accepting run
+    const int col = min(lane, 3);
+    auto load_window = [&](int k0, double &wy, double &wy2, double &wxy, int &wprev, uint32_t &wt) {
+        const double *d = delta + (int64_t)(k0 + lane) * 4;
+        wy = ld_l2(d); wy2 = ld_l2(d + 1); wxy = ld_l2(d + 2);
+        wprev = (int)__double_as_longlong(ld_l2(d + 3));
+        wt = tile_at((uint32_t)(k0 + lane));
+    };
     while (k < nc) {
+        // ---- the accepting run: while whole rounds of 64 visits are accepted — all of pass 1 as a rule, and pass 2 until the metric reaches
+        // the threshold — the prefix chains of round r+1 (started from round r's last prefix, i.e. on the assumption that round r accepts
+        // everything) are computed beside round r's 64 pcc evaluations: two chains of dependent float64 operations in one basic block instead
+        // of one after the other.  A round is only ever committed whole from here; at the first rejection (or zero denominator) nothing of the
+        // round has been applied and the general code below takes it again, visit by visit as before.  Same operations, same order.
+        if (accept_mode && span == 64 && nc - k >= 64) {
+            double c_y, c_y2, c_xy, n_y = 0.0, n_y2 = 0.0, n_xy = 0.0, f_y = 0.0, f_y2 = 0.0, f_xy = 0.0;
+            int c_prev, n_prev = 0, f_prev = 0;
+            uint32_t c_t, n_t = 0, f_t = 0;
+            if (pk == k) { c_y = pdy; c_y2 = pdy2; c_xy = pdxy; c_prev = pprev; c_t = pt; }
+            else load_window(k, c_y, c_y2, c_xy, c_prev, c_t);
+            bool has_next = nc - (k + 64) >= 64;
+            if (has_next) load_window(k + 64, n_y, n_y2, n_xy, n_prev, n_t);
+            double *dA = lds_d, *pA = lds_p, *dB = lds_d2, *pB = lds_p2;
+            dA[lane * 4 + 0] = c_y; dA[lane * 4 + 1] = c_y2; dA[lane * 4 + 2] = c_xy;
+            compiler_fence();
+            prefix_chain_all(dA, pA, col, col == 0 ? Sy : (col == 1 ? Sy2 : Sxy));
+            compiler_fence();
+            bool bailed = false;
+            for (;;) {
+                const bool has_far = has_next && nc - (k + 128) >= 64;
+                if (has_far) load_window(k + 128, f_y, f_y2, f_xy, f_prev, f_t);   // two rounds ahead: consumed one iteration from now
+                dB[lane * 4 + 0] = n_y; dB[lane * 4 + 1] = n_y2; dB[lane * 4 + 2] = n_xy;   // (zeros when there is no next round: the chain below then runs for nothing,
+                compiler_fence();                                                  //  but unconditionally — a branch would put it in a basic block of its own)
+                const double start = pA[63 * 4 + col];                             // the sums after this round's 64th visit, if all are accepted
+                const double cy = pA[lane * 4 + 0], cy2 = pA[lane * 4 + 1], cxy = pA[lane * 4 + 2];
+                prefix_chain_all(dB, pB, col, start);
+                bool special = false;
+                const bool good = mae ? cy / n <= thr : pcc_good(n, mean_x, am2, thr, cy, cy2, cxy, special);
+                const uint64_t okm = __ballot(good), spm = __ballot(special);
+                compiler_fence();
+                if (okm != ~0ull || spm != 0ull) { bailed = true; break; }          // not a whole accepted round: the general code takes it
+                map[c_t] = (int8_t)f;                                              // accepted (:264-276), all 64 of them
+                Sy = readlane_f64(cy, 63); Sy2 = readlane_f64(cy2, 63); Sxy = readlane_f64(cxy, 63);
+                k += 64;
+                if (!has_next) break;
+                c_y = n_y; c_y2 = n_y2; c_xy = n_xy; c_prev = n_prev; c_t = n_t;
+                n_y = f_y; n_y2 = f_y2; n_xy = f_xy; n_prev = f_prev; n_t = f_t;
+                has_next = has_far;
+                double *tq = dA; dA = dB; dB = tq; tq = pA; pA = pB; pB = tq;
+            }
+            if (bailed) { pk = k; pdy = c_y; pdy2 = c_y2; pdxy = c_xy; pprev = c_prev; pt = c_t; }   // the round in hand is the general code's next window
+            else pk = -1;
+            if (k >= nc) break;
+            if (!bailed) continue;
+        }
         const int m = min(accept_mode ? span : 64, nc - k);
         const bool active = lane < m;
         double dy = 0.0, dy2 = 0.0, dxy = 0.0;
@@ -521,8 +595,8 @@ __device__ void scan_tensor(const ScanArgs &a, const Order &ord, int b, unsigned
     double *delta2 = a.delta2 + (int64_t)b * a.tiles * 4;
     double *lds_d = reinterpret_cast<double *>(lds);                 // [64][4] deltas / staging
     double *lds_p = lds_d + 64 * 4;                                    // [64][4] prefixes
-    double *lds_i = lds_p + 64 * 4;                                    // [64][5] initial-sum staging
-    uint32_t *cnt = reinterpret_cast<uint32_t *>(lds_i + 64 * 5);   // [kTagSlots / 4] byte counters of the shuffle's conflict detection
+    double *lds_i = lds_p + 64 * 4;                                    // [64][5] initial-sum staging; behind it [64][4] + [64][4]: visit_pass's second staging / prefix blocks
+    uint32_t *cnt = reinterpret_cast<uint32_t *>(lds_i + 64 * 5 + 64 * 4 + 64 * 4);   // [kTagSlots / 4] byte counters of the shuffle's conflict detection
     uint32_t *helper_flag = cnt + kTagSlots / 4;                       // [2] set by the helper wave when the deltas of pass 1 / pass 2 are in memory
     constexpr bool mae = kMae;   // compiled per metric (a run-time flag cost the pcc scan 9 %): one running sum, Σ|x−y| (:280-301), carried where the pcc search carries Σy; Σy², Σxy idle
     const int base = a.fmt[0];
@@ -604,45 +678,59 @@ __device__ void scan_tensor(const ScanArgs &a, const Order &ord, int b, unsigned
         // ---- initial sums in tile order (:147-174): chains Σx, Σx², Σy, Σy², Σxy on lanes 0..4
         const int off5[5] = {0, 1, mae ? a.oab[base] : a.oy[base], a.oy2[base], a.oxy[base]};
         double acc = 0.0;
-        double nx[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
-        if (lane < T) {
-            const double *rt = st + (int64_t)lane * rec;
+        // the records of four blocks of 64 tiles are in flight ahead of the chain (they come from HBM or the Infinity Cache — K1 wrote them a
+        // batch ago — and one block of look-ahead left the chain waiting for them: 21 cycles per tile against ≈ 10 for the additions)
+        constexpr int kAhead = 4;
+        double nx[kAhead][5];
 #pragma unroll
-            for (int c = 0; c < 5; ++c) nx[c] = rec_at(rt, (uint32_t)off5[c]);
+        for (int r = 0; r < kAhead; ++r) {
+#pragma unroll
+            for (int c = 0; c < 5; ++c) nx[r][c] = 0.0;
+            if (64 * r + lane < T) {
+                const double *rt = st + (int64_t)(64 * r + lane) * rec;
+#pragma unroll
+                for (int c = 0; c < 5; ++c) nx[r][c] = rec_at(rt, (uint32_t)off5[c]);
+            }
         }
-        for (int t0 = 0; t0 < T; t0 += 64) {
-            const int m = min(64, T - t0);
-            if (lane < m) {
+        for (int t00 = 0; t00 < T; t00 += 64 * kAhead) {
 #pragma unroll
-                for (int c = 0; c < 5; ++c) lds_i[lane * 5 + c] = nx[c];
-            }
-            if (t0 + 64 + lane < T) {   // the next block's records are on their way while this block's chain runs
-                const double *rt = st + (int64_t)(t0 + 64 + lane) * rec;
+            for (int r = 0; r < kAhead; ++r) {
+                const int t0 = t00 + 64 * r;
+                if (t0 < T) {
+                    const int m = min(64, T - t0);
+                    if (lane < m) {
 #pragma unroll
-                for (int c = 0; c < 5; ++c) nx[c] = rec_at(rt, (uint32_t)off5[c]);
-            }
-            compiler_fence();
-            if (lane < 5) {
-                if (m == 64) {   // sixteen staged values ahead: the additions stay one dependent chain in tile order, the LDS reads do not wait for it
-                    double v[16], w[16];
-#pragma unroll
-                    for (int u = 0; u < 16; ++u) v[u] = lds_i[u * 5 + lane];
-#pragma unroll
-                    for (int i0 = 0; i0 < 64; i0 += 16) {
-                        if (i0 + 16 < 64) {
-#pragma unroll
-                            for (int u = 0; u < 16; ++u) w[u] = lds_i[(i0 + 16 + u) * 5 + lane];
-                        }
-#pragma unroll
-                        for (int u = 0; u < 16; ++u) acc = acc + v[u];
-#pragma unroll
-                        for (int u = 0; u < 16; ++u) v[u] = w[u];
+                        for (int c = 0; c < 5; ++c) lds_i[lane * 5 + c] = nx[r][c];
                     }
-                } else {
-                    for (int i = 0; i < m; ++i) acc = acc + lds_i[i * 5 + lane];
+                    if (t0 + 64 * kAhead + lane < T) {   // the block four ahead takes this block's registers
+                        const double *rt = st + (int64_t)(t0 + 64 * kAhead + lane) * rec;
+#pragma unroll
+                        for (int c = 0; c < 5; ++c) nx[r][c] = rec_at(rt, (uint32_t)off5[c]);
+                    }
+                    compiler_fence();
+                    if (lane < 5) {
+                        if (m == 64) {   // sixteen staged values ahead: the additions stay one dependent chain in tile order, the LDS reads do not wait for it
+                            double v[16], w[16];
+#pragma unroll
+                            for (int u = 0; u < 16; ++u) v[u] = lds_i[u * 5 + lane];
+#pragma unroll
+                            for (int i0 = 0; i0 < 64; i0 += 16) {
+                                if (i0 + 16 < 64) {
+#pragma unroll
+                                    for (int u = 0; u < 16; ++u) w[u] = lds_i[(i0 + 16 + u) * 5 + lane];
+                                }
+#pragma unroll
+                                for (int u = 0; u < 16; ++u) acc = acc + v[u];
+#pragma unroll
+                                for (int u = 0; u < 16; ++u) v[u] = w[u];
+                            }
+                        } else {
+                            for (int i = 0; i < m; ++i) acc = acc + lds_i[i * 5 + lane];
+                        }
+                    }
+                    compiler_fence();
                 }
             }
-            compiler_fence();
         }
         sum_x = shfl_f64(acc, 0); sum_x2 = shfl_f64(acc, 1);
         Sy = shfl_f64(acc, 2); Sy2 = shfl_f64(acc, 3); Sxy = shfl_f64(acc, 4);
@@ -823,7 +911,7 @@ __global__ __launch_bounds__(128) void greedy_scan_pcc_global(ScanArgs a)
     else scan_tensor<false>(a, ord, blockIdx.x, lds, lane, wave, blockDim.x == 128);
 }
 
-constexpr size_t kFixedLds = (64 * 4 + 64 * 4 + 64 * 5) * sizeof(double) + kTagSlots + 16;
+constexpr size_t kFixedLds = (64 * 4 + 64 * 4 + 64 * 5 + 64 * 4 + 64 * 4) * sizeof(double) + kTagSlots + 16;
 
 // The launch's shared orders: block w (one wave) computes order w+1.  Block 0: the base pass's draws, then pass 1's permutation of
 // range(T); block 1: the draws of the base pass and of pass 1, then pass 2's permutation of range(T).
