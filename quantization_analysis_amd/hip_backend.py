@@ -680,15 +680,18 @@ def tile_scores_device(stats_dev, mask: int, metric: str):
     return out
 
 
-def threshold_assign_device_raw(stats_dev, mask: int, formats, metric: str, threshold: float, band: float = 2e-6):
+def threshold_assign_device_raw(stats_dev, mask: int, formats, metric: str, threshold: float, band: float = 2e-6, out=None):
     """K4 on device-resident records [T, rec] (any number of tensors' tiles back to back) → device int8 [2, T]: row 0 the
     map, row 1 the knife-edge masks (bit c: format code c scored inside the band; 0 for most tiles); asynchronous on the
-    current stream."""
+    current stream.  `out`: a pair of contiguous int8 device vectors of T entries each (map, masks) to write instead."""
     torch = _torch()
     require_gpu()
     T = stats_dev.shape[0]
     fm = (ctypes.c_int * len(formats))(*[MIXED_TILE_FORMATS.index(f) for f in formats])
-    both = torch.empty((2, T), dtype=torch.int8, device=stats_dev.device)
+    both = torch.empty((2, T), dtype=torch.int8, device=stats_dev.device) if out is None else out
+    for row in (both[0], both[1]):
+        if row.dtype != torch.int8 or row.numel() != T or not row.is_contiguous() or not row.is_cuda:
+            raise ValueError("threshold_assign_device_raw: out must be two contiguous int8 device vectors of one entry per tile")
     check(lib().mtq_threshold_assign_device(stats_dev.data_ptr(), T, mask, fm, len(formats), METRIC_CODE[metric], float(threshold), float(band),
                                             both[0].data_ptr(), both[1].data_ptr(), _stream_ptr()))
     return both

@@ -907,6 +907,8 @@ class ThresholdPipeline:
         self.chunk = int(chunk)
         self.quantizer = Quantizer("hip")
         self.knife_tiles = 0
+        self._side = torch.cuda.Stream()      # the knife-edge tiles' fetch and way home, beside the main stream's K1
+        self.knife_cap = int(os.environ.get("MTQ_KNIFE_CAP", "128"))   # knife-edge tiles per chunk fetched without a round trip (more: one extra trip)
         self._pin = {}
 
     def close(self) -> None:
@@ -929,44 +931,49 @@ class ThresholdPipeline:
             self._pin[name] = t
         return t[:numel]
 
-    def _rescore(self, xc, maps: np.ndarray, near: np.ndarray, jj: np.ndarray, tt: np.ndarray, tiles_w: int) -> None:
-        """The knife-edge tiles of a whole batch at once: ONE indexed gather on the device, every format of the search quantised for
-        them by K2 in one go, one copy home; then the reference's literal float32 tile score (tile_utils.py:46-57, here
-        tile_utils.pearson_corr_tiles: the per-tile call's bits at a third of its cost) for exactly the (tile, format) pairs inside
-        the band (mixed_tile_threshold.decide_knife_tiles); maps patched in place (reference :117-123).  Round 2 did this per chunk
-        with a device round trip per format: with ~3 knife tiles per tensor it cost more than K1 and K4 together."""
-        from .compression_algorithms.mixed_tile_threshold import decide_knife_tiles
-        from .compression_algorithms.tile_utils import tile_metrics
-
+    def _knife_tiles_device(self, xc, idx, tiles: int, tiles_w: int):
+        """The knife-edge tiles' values and every format's reconstruction of them, on the device: `idx` holds flat (tensor·tiles + tile)
+        indices (device int64; entries < 0 are padding and read tile 0).  ONE indexed gather, K2 once per format → float32
+        (1 + formats, len(idx), 32, 32), plane 0 the tile itself (pads of ragged edge tiles zero, as the reference's padded view has them)."""
         torch = self.torch
         n, h, w = xc.shape
         dev = xc.device
-        k = int(jj.size)
-        idx = torch.from_numpy(np.stack([jj, tt]).astype(np.int64)).to(dev, non_blocking=True)
-        j, t = idx[0], idx[1]
+        k = int(idx.numel())
+        flat_idx = idx.clamp(min=0)
+        j, t = flat_idx // tiles, flat_idx % tiles
         ar = torch.arange(32, device=dev)
         rows = (t // tiles_w)[:, None] * 32 + ar
         cols = (t % tiles_w)[:, None] * 32 + ar
         vals = xc[j[:, None, None], rows.clamp(max=h - 1)[:, :, None], cols.clamp(max=w - 1)[:, None, :]].float()
-        inside = (rows < h)[:, :, None] & (cols < w)[:, None, :]
-        x_dev = torch.where(inside, vals, torch.zeros((), dtype=torch.float32, device=dev)).contiguous()   # (k, 32, 32), pads zero
-        fmts = list(self.tile_formats)
-        both = torch.empty((1 + len(fmts), k, 32, 32), dtype=torch.float32, device=dev)
-        both[0] = x_dev
-        flat = x_dev.reshape(k * 32, 32)
-        for i, f in enumerate(fmts):
+        if h % 32 or w % 32:
+            inside = (rows < h)[:, :, None] & (cols < w)[:, None, :]
+            vals = torch.where(inside, vals, torch.zeros((), dtype=torch.float32, device=dev))
+        both = torch.empty((1 + len(self.tile_formats), k, 32, 32), dtype=torch.float32, device=dev)
+        both[0] = vals
+        flat = both[0].reshape(k * 32, 32)
+        for i, f in enumerate(self.tile_formats):
             hb.quantize(flat, f, out=both[1 + i].reshape(k * 32, 32))
-        host = both.cpu().numpy()                                                                          # the one wait of the rescoring
-        x_tiles = host[0]
+        return both
+
+    def _decide(self, host_tiles: np.ndarray, old: np.ndarray, near: np.ndarray) -> np.ndarray:
+        """The reference's literal float32 tile score (tile_utils.py:46-57, here tile_utils.pearson_corr_tiles: the per-tile call's bits
+        at a third of its cost) for exactly the (tile, format) pairs inside the band, and the map values that follow
+        (mixed_tile_threshold.decide_knife_tiles, reference :117-123)."""
+        from .compression_algorithms.mixed_tile_threshold import decide_knife_tiles
+        from .compression_algorithms.tile_utils import tile_metrics
+
+        fmts = list(self.tile_formats)
+        x_tiles = host_tiles[0]
 
         def literal_scores(fmt: str, sel: np.ndarray) -> np.ndarray:
-            return tile_metrics(x_tiles[sel], host[1 + fmts.index(fmt)][sel], self.metric)
+            return tile_metrics(x_tiles[sel], host_tiles[1 + fmts.index(fmt)][sel], self.metric)
 
-        maps[jj, tt] = decide_knife_tiles(maps[jj, tt], near[jj, tt].astype(np.uint8), self.tile_formats, self.metric, self.threshold, literal_scores)
+        return decide_knife_tiles(old, near.astype(np.uint8), self.tile_formats, self.metric, self.threshold, literal_scores)
 
     def run(self, x3d, numel: int | None = None) -> list[TensorResult]:
         torch = self.torch
         count, rows, cols = x3d.shape
+        dev = x3d.device
         th, tw = hb.tiles_hw(rows, cols)
         tiles, numel = th * tw, (rows * cols if numel is None else int(numel))
         identity = x3d.dtype == torch.bfloat16 and (self.mask & 1) and (self.mask & 0xE)
@@ -975,46 +982,73 @@ class ThresholdPipeline:
         scratch_n = int(hb.lib().mtq_columns_scratch_doubles())
         P = 1 + len(self.pure_formats)
         nf = len(MIXED_TILE_FORMATS)
-        # pinned mirrors of what comes back (2 B per tile, then 7 sums and 4 counts per tensor): kernels store into them (hb.device_copy),
-        # the driver waits twice per batch — a pageable `.to("cpu")` per chunk blocked until the chunk's kernels had run, with the GPU idle
-        # until the next chunk was launched
-        both_host = self._pinned("both", 2 * count * tiles, torch.int8)
+        planes = 1 + len(self.tile_formats)
+        chunks = [(first, min(self.chunk, count - first)) for first in range(0, count, self.chunk)]
+        cap = min(self.knife_cap, self.chunk * tiles)
+        # pinned mirrors of what comes back (2 B per tile, each chunk's knife-edge list and tiles, then 7 sums and 4 counts per tensor):
+        # kernels store into them (hb.device_copy) and the driver waits on events, it never blocks in a pageable copy with the GPU idle
+        both_host = self._pinned("both", 2 * count * tiles, torch.int8).view(2, count * tiles)
+        idx_host = self._pinned("idx", len(chunks) * (cap + 1), torch.int64).view(len(chunks), cap + 1)
+        knife_host = self._pinned("knife", len(chunks) * planes * cap * 1024, torch.float32).view(len(chunks), planes, cap, 32, 32)
         sums_host = self._pinned("sums", P * count * 7, torch.float64).view(P, count, 7)
         counts_host = self._pinned("counts", count * nf, torch.int64).view(count, nf)
-        results: list[TensorResult] = []
-        launched = []  # (first, n, records, map + flags on the device, their pinned mirror)
-        for first in range(0, count, self.chunk):
-            n = min(self.chunk, count - first)
+        both_dev = torch.empty((2, count * tiles), dtype=torch.int8, device=dev)             # row 0 the maps, row 1 the knife-edge masks
+        idx_dev = torch.empty((len(chunks), cap + 1), dtype=torch.int64, device=dev)
+        launched = []  # (first, n, records, chunk's tile range, map-landed event, knife-tiles-landed event)
+        for c, (first, n) in enumerate(chunks):
             recs = hb.tile_stats_batched(x3d[first:first + n], k1_mask)                       # [n, tiles, rec] on the device
-            both = hb.threshold_assign_device_raw(recs.view(n * tiles, -1), dec_mask, self.tile_formats, self.metric, self.threshold, self.band)
-            mirror = both_host[2 * first * tiles:2 * (first + n) * tiles].view(2, n * tiles)
-            hb.device_copy(mirror, both)
-            launched.append((first, n, recs, both, mirror))
-        torch.cuda.current_stream().synchronize()
-        codes = torch.arange(nf, dtype=torch.int8, device=x3d.device)
-        # maps and knife-edge masks of the whole batch; the knife-edge (tensor, tile) pairs (few) are decided together, once
+            part = slice(first * tiles, (first + n) * tiles)
+            hb.threshold_assign_device_raw(recs.view(n * tiles, -1), dec_mask, self.tile_formats, self.metric, self.threshold, self.band,
+                                           out=(both_dev[0, part], both_dev[1, part]))
+            hb.device_copy(both_host[:, part], both_dev[:, part])
+            decided = torch.cuda.Event()
+            decided.record()
+            # the chunk's knife-edge tiles are found, fetched and quantised in every format on the device, before the driver has seen
+            # its map — on a stream of their own, so that their way home (2.6 MB) lies beside the next chunk's K1, not before it: what
+            # the host does later is the literal float32 score of a few dozen tiles, while the GPU works on the chunks behind
+            capc = min(cap, n * tiles)
+            with torch.cuda.stream(self._side):
+                self._side.wait_event(decided)
+                idx_dev[c, cap] = torch.count_nonzero(both_dev[1, part])
+                if capc:
+                    idx_dev[c, :capc] = torch.nonzero_static(both_dev[1, part], size=capc, fill_value=-1).view(-1)   # ascending, as np.flatnonzero
+                    fetched = self._knife_tiles_device(x3d[first:first + n], idx_dev[c, :capc], tiles, tw)
+                    if capc == cap:
+                        hb.device_copy(knife_host[c], fetched)
+                    else:                                                                      # a last, short chunk: plane by plane
+                        for q in range(planes):
+                            hb.device_copy(knife_host[c, q, :capc], fetched[q])
+                hb.device_copy(idx_host[c], idx_dev[c])
+                landed = torch.cuda.Event()
+                landed.record()
+            launched.append((first, n, recs, part, decided, landed))
         maps_all = np.empty((count, tiles), dtype=np.int8)
-        near_all = np.empty((count, tiles), dtype=np.int8)
-        for first, n, recs, both, mirror in launched:
-            host = mirror.numpy()
-            maps_all[first:first + n] = host[0].reshape(n, tiles)                              # the mirror is reused by the next batch
-            near_all[first:first + n] = host[1].reshape(n, tiles)                              # per tile: mask of format codes inside the band
-        jj, tt = np.divmod(np.flatnonzero(near_all.view(np.bool_)), tiles)
-        dirty = np.zeros(count, dtype=bool)
-        if jj.size:
-            self._rescore(x3d, maps_all, near_all, jj, tt, tw)
-            self.knife_tiles += int(jj.size)
-            dirty[jj] = True
-        for first, n, recs, both, mirror in launched:
-            if dirty[first:first + n].any():
-                dmaps = torch.from_numpy(maps_all[first:first + n]).to(x3d.device, non_blocking=True).contiguous()
-            else:
-                dmaps = both[0].view(n, tiles)
-            scratch = torch.empty((P, n, scratch_n), dtype=torch.float64, device=x3d.device)
+        codes = torch.arange(nf, dtype=torch.int8, device=dev)
+        for c, (first, n, recs, part, decided, landed) in enumerate(launched):
+            decided.synchronize()
+            landed.synchronize()
+            maps_all[first:first + n] = both_host[0, part].numpy().reshape(n, tiles)           # the mirror is reused by the next batch
+            k = int(idx_host[c, cap])
+            if k:
+                near = both_host[1, part].numpy()
+                if k <= min(cap, n * tiles):
+                    flat, host_tiles = idx_host[c, :k].numpy().copy(), knife_host[c, :, :k].numpy()
+                    where = idx_dev[c, :k]
+                else:                                                                          # more than the list holds: the same steps, one more trip
+                    flat = np.flatnonzero(near).astype(np.int64)
+                    where = torch.from_numpy(flat).to(dev)
+                    host_tiles = self._knife_tiles_device(x3d[first:first + n], where, tiles, tw).cpu().numpy()
+                mchunk = maps_all[first:first + n].reshape(-1)
+                new = self._decide(host_tiles, mchunk[flat], near[flat])
+                mchunk[flat] = new
+                both_dev[0, part].index_put_((where,), torch.from_numpy(np.ascontiguousarray(new, dtype=np.int8)).to(dev, non_blocking=True))
+                self.knife_tiles += k
+            dmaps = both_dev[0, part].view(n, tiles)
+            scratch = torch.empty((P, n, scratch_n), dtype=torch.float64, device=dev)
             hb.check(hb.lib().mtq_column_sums_device_batched(recs.data_ptr(), n, tiles, dec_mask, dmaps.data_ptr(), scratch[0].data_ptr(), hb._stream_ptr()))
-            for k, f in enumerate(self.pure_formats):   # wq's `none` rows from the same records
-                pm = torch.full((n, tiles), MIXED_TILE_FORMATS.index(f), dtype=torch.int8, device=x3d.device)
-                hb.check(hb.lib().mtq_column_sums_device_batched(recs.data_ptr(), n, tiles, dec_mask, pm.data_ptr(), scratch[1 + k].data_ptr(), hb._stream_ptr()))
+            for q, f in enumerate(self.pure_formats):   # wq's `none` rows from the same records
+                pm = torch.full((n, tiles), MIXED_TILE_FORMATS.index(f), dtype=torch.int8, device=dev)
+                hb.check(hb.lib().mtq_column_sums_device_batched(recs.data_ptr(), n, tiles, dec_mask, pm.data_ptr(), scratch[1 + q].data_ptr(), hb._stream_ptr()))
             for q in range(P):
                 hb.device_copy(sums_host[q, first:first + n], scratch[q, :, :7])
             hb.device_copy(counts_host[first:first + n], (dmaps.unsqueeze(-1) == codes).sum(dim=1))   # counts ≡ np.bincount per tensor
@@ -1024,6 +1058,7 @@ class ThresholdPipeline:
         cols = columns_from_sums_batch(sums[0], float(numel))
         pure_cols = [columns_from_sums_batch(sums[1 + i], float(numel)) for i in range(len(self.pure_formats))]
         bc = counts_host.numpy()
+        results: list[TensorResult] = []
         for j in range(count):
             counts = {f: int(bc[j, i]) for i, f in enumerate(MIXED_TILE_FORMATS)}
             pure = {f: tuple(float(v) for v in pure_cols[i][j]) for i, f in enumerate(self.pure_formats)} or None

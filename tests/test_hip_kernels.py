@@ -436,11 +436,14 @@ def test_threshold_pipeline_matches_oracle():
     columns within 1e-6 of the float32 reference columns; a threshold placed on a tile score exercises the knife-edge path."""
     from quantization_analysis_amd.pipeline import ThresholdPipeline
 
-    for kind, shape, bf16 in (("normal_bf16", (128, 256), True), ("heavy_f32", (96, 160), False)):
+    for kind, shape, bf16, cap in (("normal_bf16", (128, 256), True, None), ("heavy_f32", (96, 160), False, None), ("normal_bf16", (100, 72), True, None),
+                                   ("heavy_f32", (96, 160), False, 0), ("normal_bf16", (128, 256), True, 1)):
         xs = np.stack([gen(kind, 60 + i, shape) for i in range(5)])
         s4 = orc.threshold_scores(xs[0], ALL, "pcc")["bfp4"]
         for thr in (0.99, float(np.sort(s4)[len(s4) // 2])):          # the second one IS a tile's float32 score
             pipe = ThresholdPipeline(ALL, "pcc", thr, chunk=2)
+            if cap is not None:
+                pipe.knife_cap = cap          # a knife-edge list too short for the batch: the extra round trip, same maps
             res = pipe.run(dev(xs, bf16=bf16))
             assert [r.index for r in res] == list(range(5))
             for i, r in enumerate(res):
