@@ -94,14 +94,17 @@ __global__ __launch_bounds__(256) void tile_stats_redo_flagged(const T *__restri
 constexpr int64_t kRedoBlocks = 512;
 
 // The fix-up as a launch of its own (mtq_tile_stats_partial_end): the same search for marked records, decided by the caller's word.
-__global__ __launch_bounds__(256) void tile_stats_redo_marked(const uint16_t *__restrict__ x, int64_t count, int64_t stride, int64_t rows, int64_t cols, int64_t ld,
+// Its waves must fit into the holes a running K1 leaves (one retiring K1 wave frees 112 VGPRs; a 184-VGPR wave waited for the whole of
+// the next K1, and the search behind it with it — r3 trace): one wave per block, and a register budget below K1's.  The budget spills
+// the literal route (taken by tiles with non-finite values only) and costs the usual launch, which finds no mark and returns, nothing.
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void tile_stats_redo_marked(const uint16_t *__restrict__ x, int64_t count, int64_t stride, int64_t rows, int64_t cols, int64_t ld,
                                                               int tiles_w, int64_t tiles, uint32_t fmt_mask, int rec, double *__restrict__ stats, int vec_ok,
                                                               const unsigned *__restrict__ mark, unsigned launch_id)
 {
     if (*mark != launch_id) return;                                     // no tile of that launch was marked (the usual case)
     const int lane = threadIdx.x & 63;
     const int64_t total = count * tiles;
-    for (int64_t first = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 64; first < total; first += (int64_t)gridDim.x * 4 * 64) {
+    for (int64_t first = (int64_t)blockIdx.x * 64; first < total; first += (int64_t)gridDim.x * 64) {
         const int64_t mine = first + lane;
         bool flagged = false;
         if (mine < total) flagged = (unsigned long long)__double_as_longlong(stats[mine * rec]) == kRedoMagicGeneric;
@@ -642,7 +645,7 @@ extern "C" int mtq_tile_stats_partial_end(const void *x, int in_dtype, int64_t c
     const int rec = (int)mtq_stats_record_doubles(layout_mask);
     const int vec_ok = aligned16(x) && (ld * 2) % 16 == 0 && (stride_elems * 2) % 16 == 0;
     const int64_t waves = (count * tiles + 63) / 64;
-    hipLaunchKernelGGL(tile_stats_redo_marked, dim3((unsigned)std::min<int64_t>((waves + 3) / 4, kRedoBlocks)), dim3(256), 0, static_cast<hipStream_t>(stream),
+    hipLaunchKernelGGL(tile_stats_redo_marked, dim3((unsigned)std::min<int64_t>(waves, 4 * kRedoBlocks)), dim3(64), 0, static_cast<hipStream_t>(stream),
                        static_cast<const uint16_t *>(x), count, stride_elems, rows, cols, ld, (int)tw, tiles, layout_mask, rec, stats, vec_ok, mark, launch_id);
     return check_launch("mtq_tile_stats_partial_end");
 }

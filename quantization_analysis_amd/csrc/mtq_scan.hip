@@ -893,9 +893,14 @@ __global__ __launch_bounds__(256) void greedy_atol(ScanArgs a)
 }
 
 // One block per tensor: wave 0 searches; wave 1 (launched when the tensors share their visiting orders) gathers deltas ahead of it.
+#ifndef MTQ_SCAN_SETPRIO
+#define MTQ_SCAN_SETPRIO 0
+#endif
+
 __global__ __launch_bounds__(128) void greedy_scan_pcc_lds(ScanArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    if (MTQ_SCAN_SETPRIO) __builtin_amdgcn_s_setprio(MTQ_SCAN_SETPRIO);
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     OrderLds ord{reinterpret_cast<uint16_t *>(lds)};
     if (a.metric == MTQ_METRIC_MAE) scan_tensor<true>(a, ord, blockIdx.x, lds + 2 * ((a.tiles + 7) & ~(int64_t)7), lane, wave, blockDim.x == 128);
@@ -905,6 +910,7 @@ __global__ __launch_bounds__(128) void greedy_scan_pcc_lds(ScanArgs a)
 __global__ __launch_bounds__(128) void greedy_scan_pcc_global(ScanArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    if (MTQ_SCAN_SETPRIO) __builtin_amdgcn_s_setprio(MTQ_SCAN_SETPRIO);
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     OrderGlobal ord{a.order_g + (int64_t)blockIdx.x * a.tiles};
     if (a.metric == MTQ_METRIC_MAE) scan_tensor<true>(a, ord, blockIdx.x, lds, lane, wave, blockDim.x == 128);

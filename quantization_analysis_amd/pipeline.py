@@ -518,17 +518,13 @@ class GreedyPipeline:
                     listed, nl = b["listed"][first * tiles:(first + n) * tiles], b["n_listed"][ci:ci + 1]
                     carry = b["carry"][first * per_carry:(first + n) * per_carry]
                     nl.zero_()
-                    if "phase1" not in os.environ.get("MTQ_ABLATE", ""):
-                        hb.greedy_scan_device_ex(*args, counts_out=b["counts_dev"][first:first + n], orders=orders, phase=1, listed=listed, n_listed=nl, carry=carry)
-                    if "listed" not in os.environ.get("MTQ_ABLATE", ""):
-                        hb.tile_stats_listed(xs, k1_mask, last_bit, prev_bit, listed, nl, recs, scratch=b["lscr"][first * tiles + ci:(first + n) * tiles + ci + 1])
-                    if "phase2" not in os.environ.get("MTQ_ABLATE", ""):
-                        hb.greedy_scan_device_ex(*args, counts_out=b["counts_dev"][first:first + n], phase=2, carry=carry)
+                    hb.greedy_scan_device_ex(*args, counts_out=b["counts_dev"][first:first + n], orders=orders, phase=1, listed=listed, n_listed=nl, carry=carry)
+                    hb.tile_stats_listed(xs, k1_mask, last_bit, prev_bit, listed, nl, recs, scratch=b["lscr"][first * tiles + ci:(first + n) * tiles + ci + 1])
+                    hb.greedy_scan_device_ex(*args, counts_out=b["counts_dev"][first:first + n], phase=2, carry=carry)
                 else:
                     hb.greedy_scan_device_ex(*args, counts_out=b["counts_dev"][first:first + n], orders=orders)
-                if "colsum" not in os.environ.get("MTQ_ABLATE", ""):
-                    hb.check(hb.lib().mtq_column_sums_device_batched(recs.data_ptr(), n, tiles, dec_mask, maps.data_ptr(),
-                                                                     b["sums_dev"][0, first:first + n].data_ptr(), scan_stream.cuda_stream))
+                hb.check(hb.lib().mtq_column_sums_device_batched(recs.data_ptr(), n, tiles, dec_mask, maps.data_ptr(),
+                                                                 b["sums_dev"][0, first:first + n].data_ptr(), scan_stream.cuda_stream))
                 for k, pm in enumerate(b["pure_maps"]):
                     hb.check(hb.lib().mtq_column_sums_device_batched(recs.data_ptr(), n, tiles, dec_mask, pm[first:first + n].data_ptr(),
                                                                      b["sums_dev"][1 + k, first:first + n].data_ptr(), scan_stream.cuda_stream))

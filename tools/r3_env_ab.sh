@@ -6,7 +6,7 @@ for round in 1 2; do
   i=0
   for envs in "$@"; do
     i=$((i+1))
-    env $envs python bench.py --steps "$steps" --warmup 5 --cpu-sample 0 > "$out/v${i}_r${round}.json" 2>> "$out/err.txt" || { echo "variant $i failed"; tail -3 "$out/err.txt"; }
+    env $envs python bench.py --steps "$steps" --warmup 5 --cpu-sample 0 --legs none > "$out/v${i}_r${round}.json" 2>> "$out/err.txt" || { echo "variant $i failed"; tail -3 "$out/err.txt"; }
     python - "$out/v${i}_r${round}.json" "$envs" <<'PY'
 import json, sys
 d = json.load(open(sys.argv[1])); r = d["roofline"]
