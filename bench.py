@@ -385,23 +385,28 @@ def run_legs(sample, device) -> dict:
     return out
 
 
-def k1_profile_blocks(tiles_per_launch: float, k_ms: float):
-    """traffic / VALU blocks of the roofline object from the committed PMC passes (profiles/k1_traffic.json, k1_valu.json)."""
+def k1_profile_blocks(tiles_per_launch: float, k_ms: float, lazy: bool = True):
+    """traffic / VALU blocks of the roofline object from the committed PMC passes (profiles/k1_traffic.json, k1_valu.json): the lazy
+    route's kernel (partial records) at the top level of either file, the whole-record kernel under `whole_records`."""
     traffic = traffic_source = valu = None
     tfile = ROOT / "profiles" / "k1_traffic.json"  # HBM bytes per launch from a separate rocprofv3 --pmc pass
     if tfile.exists():
         try:
             t = json.loads(tfile.read_text())
-            traffic = t.get("hbm_bytes_per_tile") * tiles_per_launch  # measured B/tile x tiles of this run's launches
+            per_tile = t["hbm_bytes_per_tile"] if lazy else t["whole_records"]["hbm_bytes_per_tile"]
+            traffic = per_tile * tiles_per_launch  # measured B/tile x tiles of this run's launches
             traffic_source = t.get("source", "profiles/k1_traffic.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, B/tile x this run's tiles per launch)")
+            if not lazy:
+                traffic_source += "; this run: " + t["whole_records"]["kernel"]
         except Exception:
-            traffic = None
+            traffic = traffic_source = None
     vfile = ROOT / "profiles" / "k1_valu.json"   # VALU instructions per tile from a separate rocprofv3 --pmc pass
     if vfile.exists():
         try:
             v = json.loads(vfile.read_text())
-            valu = {"valu_insts_per_tile": v["valu_insts_per_tile"], "avg_issue_cycles_per_inst": v["avg_issue_cycles_per_inst"],
-                    "valu_frac": v["valu_insts_per_tile"] * tiles_per_launch / v["simds"] * v["avg_issue_cycles_per_inst"] / (k_ms * 1e-3 * v["clock_hz"]),
+            w = v if lazy else v["whole_records"]
+            valu = {"valu_insts_per_tile": w["valu_insts_per_tile"], "avg_issue_cycles_per_inst": w["avg_issue_cycles_per_inst"],
+                    "valu_frac": w["valu_insts_per_tile"] * tiles_per_launch / v["simds"] * w["avg_issue_cycles_per_inst"] / (k_ms * 1e-3 * v["clock_hz"]),
                     "note": "share of the launch during which every SIMD's VALU issue port is taken (instructions per SIMD x issue cost / launch "
                             "time at 2.4 GHz): the kernel is VALU-issue bound, not HBM bound", "source": "profiles/k1_valu.json"}
         except Exception:
@@ -610,8 +615,8 @@ def run_m1_workload(args, dist, rank, world, device, barrier, numa) -> None:
         k_ms = kt.kernel_ms / max(kt.launches, 1)
         tiles_per_launch = kt.tiles / max(kt.launches, 1)
         achieved = BYTES_PER_TILE_READ * tiles_per_launch / (k_ms * 1e-3) / 1e9
-        traffic, traffic_source, valu = k1_profile_blocks(tiles_per_launch, k_ms)
         lazy = pipe.lazy_plan(batch[: args.chunk]) is not None
+        traffic, traffic_source, valu = k1_profile_blocks(tiles_per_launch, k_ms, lazy)
         total_steps = args.steps * len(regions)
         out = {
             "metric": METRIC_NAME,

@@ -84,7 +84,9 @@ if fetch and write:
     t["hbm_bytes_per_tile"] = t["hbm_bytes_per_launch"] / tiles
     full = per_dispatch(fetch, "tile_stats_bf16_rolled<7u, 7u")
     if full.get("FETCH_SIZE"):
-        t["tile_stats_bf16_rolled<7,7> (whole records, same tool)"] = {"FETCH_SIZE_KB": steady(full["FETCH_SIZE"]), "WRITE_SIZE_KB": steady(per_dispatch(write, "tile_stats_bf16_rolled<7u, 7u")["WRITE_SIZE"])}
+        fw, ww = steady(full["FETCH_SIZE"]), steady(per_dispatch(write, "tile_stats_bf16_rolled<7u, 7u")["WRITE_SIZE"])
+        t["whole_records"] = {"kernel": "tile_stats_bf16_rolled<7,7> (MTQ_LAZY=0: every statistic of every format; same tool, same passes)", "FETCH_SIZE_KB": fw, "WRITE_SIZE_KB": ww,
+                              "hbm_bytes_per_tile": (2.0 * 1024.0 * fw + 1024.0 * ww) / tiles}
     (P / "k1_traffic.json").write_text(json.dumps(t, indent=1) + "\n")
     print(f"traffic: {t['hbm_bytes_per_tile']:.1f} B/tile (2048 + 136 algorithmic)")
 if sq:
@@ -98,12 +100,13 @@ if sq:
         out[name] = {"valu_insts_per_tile": steady(c["SQ_INSTS_VALU"]) / tiles, "issuing": steady(c["SQ_ACTIVE_INST_ANY"]) / wc,
                      "waiting_for_issue": steady(c["SQ_WAIT_INST_ANY"]) / wc, "waiting_for_memory": steady(c["SQ_WAIT_ANY"]) / wc}
     if "lazy" in out:
-        # issue cost of the lazy kernel's static mix (ISA listing of tile_stats_bf16_rolled<3,1>: 37 % plain 32-bit forms at ~2.7 cycles, 63 % packed / dot / sad / min-max / fp64 forms at ~4.4)
-        v = {"valu_insts_per_tile": round(out["lazy"]["valu_insts_per_tile"], 1), "avg_issue_cycles_per_inst": 3.77, "simds": 1024, "clock_hz": 2400000000.0,
+        # issue cost of the lazy kernel's static mix (tools/isa_mix.py on the listing of tile_stats_bf16_rolled<3,1>: 36 % plain 32-bit forms at ~2.7 cycles,
+        # 64 % packed / dot / sad / min-max / fp64 / convert forms at ~4.4 -> 3.78; the whole-record kernel <7,7>: 35 % / 65 % -> 3.81)
+        v = {"valu_insts_per_tile": round(out["lazy"]["valu_insts_per_tile"], 1), "avg_issue_cycles_per_inst": 3.78, "simds": 1024, "clock_hz": 2400000000.0,
              "wave_cycle_shares": {k: round(x, 3) for k, x in out["lazy"].items() if k != "valu_insts_per_tile"},
-             "whole_record_kernel": {k: round(x, 3) for k, x in out.get("whole", {}).items()},
+             "whole_records": dict({k: round(x, 3) for k, x in out.get("whole", {}).items()}, avg_issue_cycles_per_inst=3.81),
              "source": f"rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVES on tools/k1_partial_bench.py 32 3 0xE 0x2 0x4 "
-                       f"(profiles/r3_{suf}_pmc_sq_k1.csv): the lazy route's K1, tile_stats_bf16_rolled<3,1>; issue cost = the kernel's static mix (profiles/r1_f_valu_issue_rates.txt)"}
+                       f"(profiles/r3_{suf}_pmc_sq_k1.csv): the lazy route's K1, tile_stats_bf16_rolled<3,1>; issue cost = the kernel's static mix (tools/isa_mix.py; issue rates profiles/r1_f_valu_issue_rates.txt)"}
         (P / "k1_valu.json").write_text(json.dumps(v, indent=1) + "\n")
         print("valu:", json.dumps(out))
 sqf = newest("pmc_sq_f32/*/*_counter_collection.csv", False)
