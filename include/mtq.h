@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define MTQ_VERSION 140 /* 0.1.4.0: + partial / listed K1 (mtq_tile_stats_partial, mtq_tile_stats_listed), the search in phases with shared visiting orders, mtq_shutdown */
+#define MTQ_VERSION 141 /* 0.1.4.1: + partial / listed K1 (mtq_tile_stats_partial, mtq_tile_stats_listed), the search in phases with shared visiting orders, mtq_shutdown, mtq_knife_tiles_device */
 
 typedef enum {
     MTQ_OK = 0,
@@ -350,6 +350,17 @@ int mtq_greedy_scan_device_ex(const double *stats, int64_t count, int64_t tiles,
  * `orders` (mtq_scan_orders_bytes(tiles) bytes, device).  Depends on nothing but seed and tiles: it can run beside K1. */
 size_t mtq_scan_orders_bytes(int64_t tiles);
 int mtq_scan_orders_device(uint64_t seed, int64_t tiles, int n_orders, void *orders, size_t orders_bytes, void *stream);
+
+/* The knife-edge tiles of the threshold rule, prepared on the device for the host's literal float32 score (replaces the gather of
+ * tiles and the per-format Quantizer.quantize calls of mixed_tile_threshold.py:97-110 for the tiles whose float64 score fell inside
+ * the noise band — `near` is the mask array mtq_threshold_assign_device wrote, one int8 per tile of `count` equally shaped tensors):
+ * list[0 .. cap) receives the flat ids (tensor * tiles + tile) of flagged tiles in no particular order, list[cap] their total number
+ * (which may exceed cap: the caller then handles the batch another way); tiles_out[(p * cap + slot) * 1024 + r * 32 + c], p = 0 the
+ * tile's own values as float32 (pads of ragged edge tiles +0.0, tile_utils.py:109-113), p = 1 + i the reconstruction in formats[i]
+ * (codes 0..3, n_formats <= 4), for slot < min(list[cap], cap).  Asynchronous on `stream`; list and tiles_out are device memory
+ * (tiles_out 16-byte aligned). */
+int mtq_knife_tiles_device(const void *x, int in_dtype, int64_t count, int64_t stride_elems, int64_t rows, int64_t cols, int64_t ld,
+                           const int8_t *near, const int *formats, int n_formats, int64_t cap, int64_t *list, float *tiles_out, void *stream);
 
 /* Results home without a copy engine (no reference counterpart: the reference's arrays are host arrays).  A kernel copies `rows` rows
  * of `width_bytes` bytes from src (pitch src_pitch) to dst (pitch dst_pitch) on `stream`; dst may be pinned host memory

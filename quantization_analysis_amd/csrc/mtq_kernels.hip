@@ -438,6 +438,77 @@ extern "C" int mtq_device_copy_2d(void *dst, size_t dst_pitch, const void *src, 
     return check_launch("mtq_device_copy_2d");
 }
 
+// ---------------------------------------------------------------------------------------------
+// The knife-edge tiles of the threshold rule, ready for the host's literal float32 score (mixed_tile_threshold.py:97-123 scores a
+// tile from its float32 values and each format's reconstruction of them, tile_utils.py:46-57): a list of the flagged tiles
+// (any order: every entry carries its tile id) and, per listed tile, its 32x32 values and every requested format's y as float32
+// (pads of ragged edge tiles +0.0, as in the reference's padded view).  Two launches, no host round trip.
+// ---------------------------------------------------------------------------------------------
+namespace {
+__global__ __launch_bounds__(256) void knife_list(const int8_t *__restrict__ near, int64_t total, int64_t cap, long long *__restrict__ list)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total || near[i] == 0) return;
+    const unsigned long long slot = atomicAdd(reinterpret_cast<unsigned long long *>(list + cap), 1ull);   // list[cap]: how many were flagged
+    if ((int64_t)slot < cap) list[slot] = i;
+}
+
+template <typename T>
+__global__ __launch_bounds__(64) void knife_tiles(const T *__restrict__ x, int64_t stride, int64_t rows, int64_t cols, int64_t ld, int tiles_w, int64_t tiles,
+                                                  const long long *__restrict__ list, int64_t cap, int4 fmts, int n_fmts, float *__restrict__ out, int vec_ok)
+{
+    const int64_t listed = list[cap] < cap ? list[cap] : cap;
+    const int64_t b = blockIdx.x;
+    if (b >= listed) return;
+    const int64_t id = list[b], j = id / tiles, t = id - j * tiles;
+    const int lane = threadIdx.x;
+    const int64_t r = lane >> 1, c0 = (int64_t)(lane & 1) * kGroup;
+    const int64_t row = (t / tiles_w) * kTile + r, col0 = (t % tiles_w) * kTile + c0;
+    uint32_t u[kGroup];
+    Loader<T>::group(x + j * stride, row, col0, rows, cols, ld, vec_ok != 0, u);
+    const uint32_t shared = group_shared_exp(u);
+    const int f4[4] = {fmts.x, fmts.y, fmts.z, fmts.w};
+    for (int p = 0; p <= n_fmts; ++p) {
+        uint4 *q = reinterpret_cast<uint4 *>(out + ((int64_t)p * cap + b) * (kTile * kTile) + r * kTile + c0);
+        uint32_t o[kGroup];
+#pragma unroll
+        for (int i = 0; i < kGroup; ++i) o[i] = p == 0 ? u[i] : quant_elem_bits_mixed(f4[p - 1], u[i], shared);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) q[i] = make_uint4(o[4 * i], o[4 * i + 1], o[4 * i + 2], o[4 * i + 3]);
+    }
+}
+} // namespace
+
+extern "C" int mtq_knife_tiles_device(const void *x, int in_dtype, int64_t count, int64_t stride_elems, int64_t rows, int64_t cols, int64_t ld,
+                                      const int8_t *near, const int *formats, int n_formats, int64_t cap, int64_t *list, float *tiles_out, void *stream)
+{
+    if (int rc = check_matrix(x, in_dtype, rows, cols, ld)) return rc;
+    if (!near || !list || !formats) return fail(MTQ_ERR_INVALID, "null argument");
+    if (count <= 0 || cap < 0 || (cap > 0 && !tiles_out)) return fail(MTQ_ERR_INVALID, "count must be positive, cap non-negative, tiles_out set when cap > 0");
+    if (n_formats < 1 || n_formats > 4) return fail(MTQ_ERR_INVALID, "n_formats must be 1..4");
+    for (int i = 0; i < n_formats; ++i)
+        if (formats[i] < 0 || formats[i] > 3) return fail(MTQ_ERR_INVALID, "format codes are 0..3 (bf16, bfp8, bfp4, bfp2)");
+    if (!aligned16(tiles_out)) return fail(MTQ_ERR_INVALID, "tiles_out must be 16-byte aligned");
+    if (int rc = require_device()) return rc;
+    const int64_t th = (rows + kTile - 1) / kTile, tw = (cols + kTile - 1) / kTile, tiles = th * tw, total = count * tiles;
+    if (tw > INT32_MAX || total > ((int64_t)1 << 40) || cap > (1 << 22)) return fail(MTQ_ERR_INVALID, "too many tiles for one launch");
+    const int64_t esz = in_dtype == MTQ_DTYPE_BF16 ? 2 : 4;
+    const int vec_ok = aligned16(x) && (ld * esz) % 16 == 0 && (stride_elems * esz) % 16 == 0;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (hipMemsetAsync(list + cap, 0, sizeof(int64_t), s) != hipSuccess) return fail(MTQ_ERR_HIP, "hipMemsetAsync failed");
+    hipLaunchKernelGGL(knife_list, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, near, total, cap, reinterpret_cast<long long *>(list));
+    if (int rc = check_launch("mtq_knife_tiles_device (list)")) return rc;
+    if (cap == 0) return MTQ_OK;
+    int4 f = make_int4(formats[0], n_formats > 1 ? formats[1] : 0, n_formats > 2 ? formats[2] : 0, n_formats > 3 ? formats[3] : 0);
+    if (in_dtype == MTQ_DTYPE_BF16)
+        hipLaunchKernelGGL(knife_tiles<uint16_t>, dim3((unsigned)cap), dim3(64), 0, s, static_cast<const uint16_t *>(x), stride_elems, rows, cols, ld, (int)tw, tiles,
+                           reinterpret_cast<const long long *>(list), cap, f, n_formats, tiles_out, vec_ok);
+    else
+        hipLaunchKernelGGL(knife_tiles<float>, dim3((unsigned)cap), dim3(64), 0, s, static_cast<const float *>(x), stride_elems, rows, cols, ld, (int)tw, tiles,
+                           reinterpret_cast<const long long *>(list), cap, f, n_formats, tiles_out, vec_ok);
+    return check_launch("mtq_knife_tiles_device");
+}
+
 extern "C" int mtq_selftest_slot_ring(void)
 {
     MockOps::created = MockOps::waits = 0;

@@ -31,7 +31,7 @@ EXPORTS = [
     "mtq_greedy_run_chain", "mtq_greedy_run_chain_batch", "mtq_pack_chain_records", "mtq_tile_scores", "mtq_threshold_assign", "mtq_columns_from_stats", "mtq_columns_from_sums", "mtq_tile_scores_device",
     "mtq_threshold_assign_device", "mtq_columns_scratch_doubles", "mtq_column_sums_device", "mtq_column_sums_device_batched",
     "mtq_rng_create", "mtq_rng_permutation", "mtq_rng_integers", "mtq_rng_destroy", "mtq_greedy_run", "mtq_greedy_run_batch",
-    "mtq_selftest_slot_ring", "mtq_device_copy_2d", "mtq_greedy_scan_scratch_bytes", "mtq_greedy_scan_device", "mtq_greedy_scan_device_ex", "mtq_scan_carry_bytes",
+    "mtq_selftest_slot_ring", "mtq_device_copy_2d", "mtq_knife_tiles_device", "mtq_greedy_scan_scratch_bytes", "mtq_greedy_scan_device", "mtq_greedy_scan_device_ex", "mtq_scan_carry_bytes",
     "mtq_scan_orders_bytes", "mtq_scan_orders_device", "mtq_debug_scan_ticks",
 ]
 
@@ -124,7 +124,8 @@ def lib() -> ctypes.CDLL:
     L.mtq_shutdown.restype = ci
     L.mtq_selftest_slot_ring.restype = ci
     L.mtq_device_copy_2d.argtypes = [vp, ctypes.c_size_t, vp, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_size_t, vp]
-    if L.mtq_version() < 140:
+    L.mtq_knife_tiles_device.argtypes = [vp, ci, i64, i64, i64, i64, i64, vp, vp, ci, i64, vp, vp, vp]
+    if L.mtq_version() < 141:
         raise MtqError("libmtq_hip.so is older than this package")
     _lib = L
     # torch registered its exit hooks when it was imported above; a hook registered now runs BEFORE them: the library's threads,
@@ -695,6 +696,28 @@ def threshold_assign_device_raw(stats_dev, mask: int, formats, metric: str, thre
     check(lib().mtq_threshold_assign_device(stats_dev.data_ptr(), T, mask, fm, len(formats), METRIC_CODE[metric], float(threshold), float(band),
                                             both[0].data_ptr(), both[1].data_ptr(), _stream_ptr()))
     return both
+
+
+def knife_tiles_device(x3d, near, formats, cap: int, list_out, tiles_out) -> None:
+    """The threshold rule's knife-edge tiles, prepared on the device (mtq_knife_tiles_device): `near` = the int8 masks of
+    threshold_assign_device_raw for the (count, rows, cols) batch x3d; list_out int64 [cap + 1] ← flat tile ids (any order) and,
+    last, how many were flagged; tiles_out float32 [1 + len(formats), cap, 32, 32] ← their values and every format's reconstruction.
+    Asynchronous on the current stream."""
+    torch = _torch()
+    require_gpu()
+    count, rows, cols = x3d.shape
+    if x3d.stride(2) != 1 or not x3d.is_cuda:
+        raise ValueError("knife_tiles_device needs a device tensor with contiguous rows")
+    th, tw = tiles_hw(rows, cols)
+    if near.dtype != torch.int8 or near.numel() != count * th * tw or not near.is_contiguous():
+        raise ValueError("near must be a contiguous int8 vector of one entry per tile")
+    if list_out.dtype != torch.int64 or list_out.numel() != cap + 1 or not list_out.is_contiguous():
+        raise ValueError("list_out must be a contiguous int64 vector of cap + 1 entries")
+    if cap and (tiles_out.dtype != torch.float32 or tiles_out.numel() != (1 + len(formats)) * cap * 1024 or not tiles_out.is_contiguous()):
+        raise ValueError("tiles_out must be a contiguous float32 tensor of (1 + formats) x cap x 32 x 32")
+    fm = (ctypes.c_int * len(formats))(*[MIXED_TILE_FORMATS.index(f) for f in formats])
+    check(lib().mtq_knife_tiles_device(x3d.data_ptr(), _dtype_code(x3d), count, x3d.stride(0) if count > 1 else rows * x3d.stride(1), rows, cols, x3d.stride(1),
+                                       near.data_ptr(), fm, len(formats), int(cap), list_out.data_ptr(), tiles_out.data_ptr() if cap else None, _stream_ptr()))
 
 
 def threshold_assign_device(stats_dev, mask: int, formats, metric: str, threshold: float, band: float = 2e-6, with_near: bool = False):

@@ -990,6 +990,7 @@ class ThresholdPipeline:
         counts_host = self._pinned("counts", count * nf, torch.int64).view(count, nf)
         both_dev = torch.empty((2, count * tiles), dtype=torch.int8, device=dev)             # row 0 the maps, row 1 the knife-edge masks
         idx_dev = torch.empty((len(chunks), cap + 1), dtype=torch.int64, device=dev)
+        knife_dev = torch.empty((len(chunks), planes, cap, 32, 32), dtype=torch.float32, device=dev)
         launched = []  # (first, n, records, chunk's tile range, map-landed event, knife-tiles-landed event)
         for c, (first, n) in enumerate(chunks):
             recs = hb.tile_stats_batched(x3d[first:first + n], k1_mask)                       # [n, tiles, rec] on the device
@@ -999,22 +1000,16 @@ class ThresholdPipeline:
             hb.device_copy(both_host[:, part], both_dev[:, part])
             decided = torch.cuda.Event()
             decided.record()
-            # the chunk's knife-edge tiles are found, fetched and quantised in every format on the device, before the driver has seen
-            # its map — on a stream of their own, so that their way home (2.6 MB) lies beside the next chunk's K1, not before it: what
-            # the host does later is the literal float32 score of a few dozen tiles, while the GPU works on the chunks behind
-            capc = min(cap, n * tiles)
+            # the chunk's knife-edge tiles are found, fetched and quantised in every format on the device (mtq_knife_tiles_device: two
+            # launches), before the driver has seen its map — on a stream of their own, so that their way home (2.6 MB) lies beside the
+            # next chunk's K1, not before it: what the host does later is the literal float32 score of a few dozen tiles, while the
+            # GPU works on the chunks behind.  (As ~25 small torch launches per chunk this cost the driver thread more than K1 took.)
             with torch.cuda.stream(self._side):
                 self._side.wait_event(decided)
-                idx_dev[c, cap] = torch.count_nonzero(both_dev[1, part])
-                if capc:
-                    idx_dev[c, :capc] = torch.nonzero_static(both_dev[1, part], size=capc, fill_value=-1).view(-1)   # ascending, as np.flatnonzero
-                    fetched = self._knife_tiles_device(x3d[first:first + n], idx_dev[c, :capc], tiles, tw)
-                    if capc == cap:
-                        hb.device_copy(knife_host[c], fetched)
-                    else:                                                                      # a last, short chunk: plane by plane
-                        for q in range(planes):
-                            hb.device_copy(knife_host[c, q, :capc], fetched[q])
+                hb.knife_tiles_device(x3d[first:first + n], both_dev[1, part], self.tile_formats, cap, idx_dev[c], knife_dev[c])
                 hb.device_copy(idx_host[c], idx_dev[c])
+                if cap:
+                    hb.device_copy(knife_host[c], knife_dev[c])
                 landed = torch.cuda.Event()
                 landed.record()
             launched.append((first, n, recs, part, decided, landed))
@@ -1027,8 +1022,8 @@ class ThresholdPipeline:
             k = int(idx_host[c, cap])
             if k:
                 near = both_host[1, part].numpy()
-                if k <= min(cap, n * tiles):
-                    flat, host_tiles = idx_host[c, :k].numpy().copy(), knife_host[c, :, :k].numpy()
+                if k <= cap:
+                    flat, host_tiles = idx_host[c, :k].numpy().copy(), knife_host[c, :, :k].numpy()   # the list is in no particular order: ids travel with their tiles
                     where = idx_dev[c, :k]
                 else:                                                                          # more than the list holds: the same steps, one more trip
                     flat = np.flatnonzero(near).astype(np.int64)

@@ -431,6 +431,40 @@ def test_device_decisions_equal_host_decisions(golden_dir):
         hb.columns_from_stats_device(hb.tile_stats(xb[:64, :128], 0x2), 0x2, np.full(8, 3, dtype=np.int8), 8192.0)
 
 
+def test_knife_tiles_device_lists_fetches_and_quantises():
+    """mtq_knife_tiles_device against the steps it replaces (an indexed gather of the flagged tiles and K2 per format on them): the listed
+    ids are exactly the flagged tiles, every listed tile's values and reconstructions are the same bits; ragged shapes (zero pads), bf16
+    and float32 storage, a list shorter than the number of flagged tiles (the count still says how many there were)."""
+    import torch
+
+    from quantization_analysis_amd.pipeline import ThresholdPipeline
+
+    rng = np.random.default_rng(5)
+    for kind, shape, bf16 in (("normal_bf16", (128, 256), True), ("heavy_f32", (100, 72), False), ("heavy_bf16", (96, 160), True)):
+        xs = dev(np.stack([gen(kind, 80 + i, shape) for i in range(3)]), bf16=bf16)
+        th, tw = hb.tiles_hw(*shape)
+        tiles = th * tw
+        near = (rng.random(3 * tiles) < 0.2).astype(np.int8) * rng.integers(1, 15, 3 * tiles).astype(np.int8)
+        flagged = np.flatnonzero(near)
+        near_dev = torch.from_numpy(near).cuda()
+        pipe = ThresholdPipeline(ALL, "pcc", 0.99)
+        for cap in (flagged.size + 5, max(flagged.size - 3, 1), 0):
+            lst = torch.full((cap + 1,), -7, dtype=torch.int64, device="cuda")
+            out = torch.full((1 + len(ALL), cap, 32, 32), float("nan"), dtype=torch.float32, device="cuda")
+            hb.knife_tiles_device(xs, near_dev, ALL, cap, lst, out)
+            got = lst.cpu().numpy()
+            assert got[cap] == flagged.size
+            k = min(cap, flagged.size)
+            ids = got[:k]
+            assert len(set(ids.tolist())) == k and set(ids.tolist()) <= set(flagged.tolist())
+            if cap >= flagged.size:
+                assert np.array_equal(np.sort(ids), flagged)
+            if k:
+                want = pipe._knife_tiles_device(xs, torch.from_numpy(ids).cuda(), tiles, tw).cpu().numpy()
+                assert np.array_equal(out[:, :k].cpu().numpy().view(np.uint32), want.view(np.uint32)), (kind, cap)
+        pipe.close()
+
+
 def test_threshold_pipeline_matches_oracle():
     """ThresholdPipeline (records never leave the GPU): maps and counts equal the oracle's threshold search tensor by tensor,
     columns within 1e-6 of the float32 reference columns; a threshold placed on a tile score exercises the knife-edge path."""
