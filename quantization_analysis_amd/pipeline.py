@@ -185,6 +185,11 @@ class GreedyPipeline:
         self.lazy = (os.environ.get("MTQ_LAZY", "1") != "0" and self.metric == "pcc" and len(self.tile_formats) >= 3 and self.tile_formats[0] == "bf16"
                      and len(set(self.tile_formats)) == len(self.tile_formats) and not self.pure_formats)
         self.listed_tiles = 0                    # tiles the lazy route evaluated late (diagnostics)
+        # The lazy route pays when few tiles reach the last pass: K1 <3,1> costs 469 instructions per tile and the listed kernel 432 per
+        # listed tile, against 652 for the whole record — break-even at 42 % listed, less the phases' launches.  A batch that listed more
+        # switches the route off for tensors of its tile count (the batches already in flight finish as they were enqueued).
+        self.lazy_max_listed = float(os.environ.get("MTQ_LAZY_MAX_LISTED", "0.35"))
+        self.lazy_off = {}                       # tiles per tensor -> the listed fraction that switched the lazy route off
         self.host_fallbacks = 0                  # tensors the device scan handed back (zero denominator)
         self.host_seconds = {"enqueue": 0.0, "wait": 0.0, "wrap": 0.0}   # driver-thread time: launching, waiting for results, wrapping them
         self._devbufs = {}
@@ -216,6 +221,8 @@ class GreedyPipeline:
         th, tw = hb.tiles_hw(rows, cols)
         k1_mask = self._layout(x3d)[0]
         if not (self.lazy and self._use_device_scan(th * tw) and x3d.dtype == torch.bfloat16 and (k1_mask & 1) == 0 and rows % 32 == 0 and cols % 128 == 0):
+            return None
+        if th * tw in self.lazy_off:
             return None
         bit = lambda f: 1 << MIXED_TILE_FORMATS.index(f)
         last_bit, prev_bit = bit(self.tile_formats[-1]), bit(self.tile_formats[-2])
@@ -590,7 +597,10 @@ class GreedyPipeline:
                 cj = cols[j]
                 results.append(TensorResult(first + j, maps[j], c, mixed_tile_total_bytes(c), cj[0], cj[1], cj[2], cj[k], pure))
             if enq.get("lazy"):
-                self.listed_tiles += int(b["n_listed_host"][first // self.chunk])
+                listed = int(b["n_listed_host"][first // self.chunk])
+                self.listed_tiles += listed
+                if listed > self.lazy_max_listed * n * th * tw:
+                    self.lazy_off.setdefault(th * tw, listed / float(n * th * tw))
             for j in bad:   # handed back by the device scan: the host scan on this tensor's records
                 self.host_fallbacks += 1
                 if enq.get("lazy"):   # the records hold only what the search had asked for so far: the whole record of this one tensor now

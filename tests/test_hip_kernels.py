@@ -1053,3 +1053,15 @@ def test_lazy_pipeline_equals_whole_record_pipeline(monkeypatch):
     x0 = xs[0].float().cpu().numpy()
     a, counts, _st = orc.greedy(x0, ALL, "pcc", 0.999, 2**63 + 12345)
     assert np.array_equal(got[("1", True)][0].assignment, a) and got[("1", True)][0].counts == counts
+    # a threshold most tiles pass down to the last format: the first batch lists nearly every tile, and the route switches itself off for that
+    # tile count — same results from the lazy batch, the whole-record batches after it and the oracle
+    monkeypatch.setenv("MTQ_LAZY", "1")
+    with GreedyPipeline(ALL, "pcc", 0.9, 77, chunk=6, workers=2) as pipe:
+        assert pipe.lazy_plan(xs) is not None
+        first = pipe.run(xs)
+        assert pipe.lazy_off and pipe.lazy_plan(xs) is None and pipe.lazy_plan(xs[:, :128]) is not None
+        second = pipe.run(xs)
+    for r1, r2 in zip(first, second):
+        assert np.array_equal(r1.assignment, r2.assignment) and r1.counts == r2.counts and (r1.pcc, r1.mae, r1.atol) == (r2.pcc, r2.mae, r2.atol)
+    a, counts, _st = orc.greedy(x0, ALL, "pcc", 0.9, 77)
+    assert np.array_equal(first[0].assignment, a) and first[0].counts == counts
