@@ -45,6 +45,17 @@ def test_argument_errors_are_reported():
     assert L.mtq_quantize(buf.ctypes.data, 0, 32, 32, 32, 9, buf.ctypes.data, 32, None) == -4
     h = ctypes.c_void_p()
     assert L.mtq_greedy_create(ctypes.byref(h), buf.ctypes.data, 1, 0b0010, 0, 0.9, 1.0, 0) == -1  # base not in mask
+    # round 3's device entry points check their arguments before they look for a device
+    p = buf.ctypes.data
+    fm = (ctypes.c_int * 4)(0, 1, 2, 3)
+    assert L.mtq_knife_tiles_device(p, 0, 1, 1024, 32, 32, 32, None, fm, 4, 8, p, p, None) == -1           # no masks
+    assert L.mtq_knife_tiles_device(p, 0, 1, 1024, 32, 32, 32, p, fm, 5, 8, p, p, None) == -1              # more formats than exist
+    bad = (ctypes.c_int * 4)(0, 1, 2, 7)
+    assert L.mtq_knife_tiles_device(p, 0, 1, 1024, 32, 32, 32, p, bad, 4, 8, p, p, None) == -1 and b"format codes" in L.mtq_last_error()
+    assert L.mtq_knife_tiles_device(p, 0, 1, 1024, 32, 32, 32, p, fm, 4, 8, p, None, None) == -1           # a list without room for the tiles
+    assert L.mtq_scan_orders_device(1, 16, 3, p, 1 << 20, None) < 0 and L.mtq_scan_orders_device(1, 16, 1, None, 0, None) < 0
+    assert int(L.mtq_scan_orders_bytes(16384)) >= 128 + 2 * 4 * 16384 and int(L.mtq_scan_carry_bytes(3)) == 3 * int(L.mtq_scan_carry_bytes(1))
+    assert int(L.mtq_greedy_scan_scratch_bytes(2, 100)) >= 2 * (100 * 8 * 8 + 100 * 4)
 
 
 def test_no_gpu_means_error_not_fallback():
