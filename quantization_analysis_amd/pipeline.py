@@ -10,6 +10,7 @@ are the outputs the north star names); use compression_algorithms.* for the drop
 from __future__ import annotations
 
 import concurrent.futures as cf
+import contextlib
 import os
 import time
 from dataclasses import dataclass, field
@@ -990,6 +991,7 @@ class ThresholdPipeline:
         nf = len(MIXED_TILE_FORMATS)
         planes = 1 + len(self.tile_formats)
         chunks = [(first, min(self.chunk, count - first)) for first in range(0, count, self.chunk)]
+        single = len(chunks) == 1
         cap = min(self.knife_cap, self.chunk * tiles)
         # pinned mirrors of what comes back (2 B per tile, each chunk's knife-edge list and tiles, then 7 sums and 4 counts per tensor):
         # kernels store into them (hb.device_copy) and the driver waits on events, it never blocks in a pageable copy with the GPU idle
@@ -1011,14 +1013,17 @@ class ThresholdPipeline:
             decided = torch.cuda.Event()
             decided.record()
             # the chunk's knife-edge tiles are found, fetched and quantised in every format on the device (mtq_knife_tiles_device: two
-            # launches), before the driver has seen its map — on a stream of their own, so that their way home (2.6 MB) lies beside the
-            # next chunk's K1, not before it: what the host does later is the literal float32 score of a few dozen tiles, while the
-            # GPU works on the chunks behind.  (As ~25 small torch launches per chunk this cost the driver thread more than K1 took.)
-            with torch.cuda.stream(self._side):
-                self._side.wait_event(decided)
+            # launches), before the driver has seen its map — on a stream of their own, beside the next chunk's K1, not before it: what
+            # the host does later is the literal float32 score of a few dozen tiles, while the GPU works on the chunks behind.  (As ~25
+            # small torch launches per chunk this cost the driver thread more than K1 took.)  A batch of one chunk has nothing to
+            # overlap with: its steps stay on the main stream (a cross-stream wait is a barrier packet, ≈ 0.1 ms per call all told)
+            # and only the list comes home; the listed tiles follow when the host has seen that there are any.
+            with (contextlib.nullcontext() if single else torch.cuda.stream(self._side)):
+                if not single:
+                    self._side.wait_event(decided)
                 hb.knife_tiles_device(x3d[first:first + n], both_dev[1, part], self.tile_formats, cap, idx_dev[c], knife_dev[c])
                 hb.device_copy(idx_host[c], idx_dev[c])
-                if cap:
+                if cap and not single:
                     hb.device_copy(knife_host[c], knife_dev[c])
                 landed = torch.cuda.Event()
                 landed.record()
@@ -1026,14 +1031,21 @@ class ThresholdPipeline:
         maps_all = np.empty((count, tiles), dtype=np.int8)
         codes = torch.arange(nf, dtype=torch.int8, device=dev)
         for c, (first, n, recs, part, decided, landed) in enumerate(launched):
-            decided.synchronize()
-            landed.synchronize()
+            landed.synchronize()      # the chunk's list is home ...
+            decided.synchronize()     # ... and its map (recorded earlier: passed by now unless the list took the side stream)
             maps_all[first:first + n] = both_host[0, part].numpy().reshape(n, tiles)           # the mirror is reused by the next batch
             k = int(idx_host[c, cap])
             if k:
                 near = both_host[1, part].numpy()
                 if k <= cap:
-                    flat, host_tiles = idx_host[c, :k].numpy().copy(), knife_host[c, :, :k].numpy()   # the list is in no particular order: ids travel with their tiles
+                    flat = idx_host[c, :k].numpy().copy()                                      # the list is in no particular order: ids travel with their tiles
+                    if single:                                                                 # the tiles were not sent with the list
+                        home = knife_host[c].reshape(-1)[:planes * k * 1024].view(planes, k, 32, 32)
+                        hb.device_copy(home, knife_dev[c, :, :k].contiguous())
+                        torch.cuda.current_stream().synchronize()
+                        host_tiles = home.numpy()
+                    else:
+                        host_tiles = knife_host[c, :, :k].numpy()
                     where = idx_dev[c, :k]
                 else:                                                                          # more than the list holds: the same steps, one more trip
                     flat = np.flatnonzero(near).astype(np.int64)

@@ -480,6 +480,9 @@ def test_threshold_pipeline_matches_oracle():
                 pipe.knife_cap = cap          # a knife-edge list too short for the batch: the extra round trip, same maps
             res = pipe.run(dev(xs, bf16=bf16))
             assert [r.index for r in res] == list(range(5))
+            pipe.chunk = 8                    # the whole batch as one chunk: main stream only, the listed tiles fetched after the list
+            for r1, r2 in zip(res, pipe.run(dev(xs, bf16=bf16))):
+                assert np.array_equal(r1.assignment, r2.assignment) and r1.counts == r2.counts and (r1.pcc, r1.mae, r1.atol) == (r2.pcc, r2.mae, r2.atol)
             for i, r in enumerate(res):
                 a, counts, _sc = orc.threshold(xs[i], ALL, "pcc", thr)
                 assert np.array_equal(r.assignment, a) and r.counts == counts, (kind, thr, i)
