@@ -355,7 +355,7 @@ def leg_llama(device) -> dict:
     load_s = time.perf_counter() - t0
     xs = [x for _p, x in batches]
     tiles = sum(tiles_of(x) for x in xs)
-    with GreedyPipeline(FORMATS, METRIC, THRESHOLD, SEED, chunk=1 << 30, workers=default_workers(), scan_streams=8) as pipe:
+    with GreedyPipeline(FORMATS, METRIC, THRESHOLD, SEED, chunk=1 << 30, workers=default_workers()) as pipe:
         pipe.SLOTS = max(pipe.SLOTS, min(len(xs), 8))
         pipe.prepare(xs)
         ms_, all_ms = timed(lambda: pipe.run_batches(xs), reps=5)
@@ -493,7 +493,7 @@ def run_llama_workload(args, dist, rank, world, device, barrier, numa) -> None:
     load_s = time.perf_counter() - t0
     xs = [x for _p, x in batches]
     my_tiles = sum(tiles_of(x) for x in xs)
-    pipe = GreedyPipeline(FORMATS, METRIC, THRESHOLD, SEED, chunk=1 << 30, workers=args.workers, scan=args.scan, scan_streams=8)
+    pipe = GreedyPipeline(FORMATS, METRIC, THRESHOLD, SEED, chunk=1 << 30, workers=args.workers, scan=args.scan)
     pipe.SLOTS = max(pipe.SLOTS, min(len(xs), 8))
     pipe.prepare(xs)
     gc.collect()
