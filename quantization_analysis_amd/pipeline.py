@@ -172,7 +172,7 @@ class GreedyPipeline:
         # milliseconds (latency-bound), so consecutive chunks' scans must overlap each other: a ring of streams
         # How many: as many as scans of consecutive batches overlap.  Steps of one shape (bench.py: a 2.0 ms scan launch per 2.5 ms step)
         # overlap two — three streams; with eight, K1's launch measured 2.5 % longer and the step 3 % (806 against 829 M tiles/s:
-        # more hardware queues in play).  A model's shape groups (streamed.py) keep every batch of a window in flight and ask for eight.
+        # more hardware queues in play).  A model's shape groups (streamed.py) keep every batch of a window in flight and asked for eight in round 2.
         # Round 3 (a step's chain is three search launches and the listed K1 now, four record slots): three streams again — with four,
         # K1's launch is 3 % longer and the 20-step figure 3 % lower (916–927 against 947–956 M tiles/s, tools/r3_env_ab.sh); two starve.
         n_scan = int(os.environ.get("MTQ_SCAN_STREAMS", str(3 if scan_streams is None else scan_streams)))
