@@ -5,7 +5,7 @@ from quantization_analysis_amd import hip_backend as hb, pipeline as pl
 import bench
 hb.require_gpu(); hb.bind_to_gpu_numa_node(0)
 batch = bench.make_batch(128, 0, torch.device('cuda', 0))
-pipe = pl.GreedyPipeline(bench.FORMATS, bench.METRIC, bench.THRESHOLD, bench.SEED, chunk=32, workers=16)
+pipe = pl.GreedyPipeline(bench.FORMATS, bench.METRIC, bench.THRESHOLD, bench.SEED, chunk=128, workers=16)   # the bench configuration: one K1 launch per step, the lazy route
 pipe.reserve(batch)
 ref = None
 for rnd in range(6):
