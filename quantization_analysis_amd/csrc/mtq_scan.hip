@@ -896,8 +896,13 @@ __global__ __launch_bounds__(256) void greedy_atol(ScanArgs a)
 #ifndef MTQ_SCAN_SETPRIO
 #define MTQ_SCAN_SETPRIO 0
 #endif
+#ifdef MTQ_SCAN_WAVES_PER_EU   // experiments: a register budget for the search kernels (3 → 168 VGPRs, 4 → 128), tools/r3_env_ab.sh with MTQ_LIB
+#define MTQ_SCAN_BUDGET __attribute__((amdgpu_waves_per_eu(MTQ_SCAN_WAVES_PER_EU, MTQ_SCAN_WAVES_PER_EU)))
+#else
+#define MTQ_SCAN_BUDGET
+#endif
 
-__global__ __launch_bounds__(128) void greedy_scan_pcc_lds(ScanArgs a)
+__global__ __launch_bounds__(128) MTQ_SCAN_BUDGET void greedy_scan_pcc_lds(ScanArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     if (MTQ_SCAN_SETPRIO) __builtin_amdgcn_s_setprio(MTQ_SCAN_SETPRIO);
@@ -907,7 +912,7 @@ __global__ __launch_bounds__(128) void greedy_scan_pcc_lds(ScanArgs a)
     else scan_tensor<false>(a, ord, blockIdx.x, lds + 2 * ((a.tiles + 7) & ~(int64_t)7), lane, wave, blockDim.x == 128);
 }
 
-__global__ __launch_bounds__(128) void greedy_scan_pcc_global(ScanArgs a)
+__global__ __launch_bounds__(128) MTQ_SCAN_BUDGET void greedy_scan_pcc_global(ScanArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     if (MTQ_SCAN_SETPRIO) __builtin_amdgcn_s_setprio(MTQ_SCAN_SETPRIO);
