@@ -249,3 +249,11 @@ def test_literal_metrics_equal_reference_expression(tmp_path, monkeypatch):
     assert strip_time("\n".join(lit[1:]) + "\n") == strip_time((run_dir(tmp_path / "emu") / "table.txt").read_text())
     assert cli.run(["synthetic:tiny", "--compression-config", cfg, "--backend", "hip", "--results-dir", str(tmp_path / "mom"), "--no-plots"]) == 0
     assert (run_dir(tmp_path / "mom") / "table.txt").read_text().splitlines()[0] == cli.HIP_COLUMNS_NOTE
+    # … and at a size where the float64-moment column and the reference's float32 BLAS value differ in the fifth digit:
+    # Llama-3-8B's k_proj of layer 0 (1024 x 4096 bf16, 4 096 tiles) — under --literal-metrics the text is the host backend's again
+    big = ["synthetic:llama3-8b", "model.layers.0.self_attn.k_proj", "--compression-config", cfg, "--no-plots"]
+    assert cli.run(big + ["--backend", "hip", "--literal-metrics", "--results-dir", str(tmp_path / "lit_big")]) == 0
+    assert cli.run(big + ["--backend", "emulation", "--results-dir", str(tmp_path / "emu_big")]) == 0
+    lit = (run_dir(tmp_path / "lit_big") / "table.txt").read_text().splitlines()
+    assert lit[0] == cli.HIP_LITERAL_NOTE
+    assert strip_time("\n".join(lit[1:]) + "\n") == strip_time((run_dir(tmp_path / "emu_big") / "table.txt").read_text())
