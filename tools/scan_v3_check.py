@@ -98,55 +98,65 @@ del big
 # ---- timing on the headline shape
 x = (torch.randn((n, 4096, 4096), generator=g, device='cuda') * 0.02).to(torch.bfloat16)
 run_case(x, ALL, 0.999, 123, label=f"{n}x4096x4096")
-recs = hb.tile_stats_batched(x, 0xE)
-T = recs.shape[1]
-numel = float(4096 * 4096)
-sd = torch.full((n,), 123, dtype=torch.int64, device='cuda')
-scratch = torch.empty((int(L.mtq_greedy_scan_scratch_bytes(n, T)),), dtype=torch.uint8, device='cuda')
-maps = torch.empty((n, T), dtype=torch.int8, device='cuda'); status = torch.empty((n,), dtype=torch.int32, device='cuda')
-orders = hb.scan_orders_device(123, T, 2)
-listed = torch.empty((n * T,), dtype=torch.int32, device='cuda'); nl = torch.zeros((1,), dtype=torch.int32, device='cuda')
-carry = torch.empty((int(L.mtq_scan_carry_bytes(n)),), dtype=torch.uint8, device='cuda')
-part = hb.tile_stats_partial(x, 0xE, 0x2, 0x4)
-lscr = torch.empty((n * T + 1,), dtype=torch.int32, device='cuda')
+def timing(x):
+    n = x.shape[0]
+    rows_, cols_ = x.shape[1], x.shape[2]
+    recs = hb.tile_stats_batched(x, 0xE)
+    T = recs.shape[1]
+    numel = float(rows_ * cols_)
+    sd = torch.full((n,), 123, dtype=torch.int64, device='cuda')
+    scratch = torch.empty((int(L.mtq_greedy_scan_scratch_bytes(n, T)),), dtype=torch.uint8, device='cuda')
+    maps = torch.empty((n, T), dtype=torch.int8, device='cuda'); status = torch.empty((n,), dtype=torch.int32, device='cuda')
+    orders = hb.scan_orders_device(123, T, 2)
+    listed = torch.empty((n * T,), dtype=torch.int32, device='cuda'); nl = torch.zeros((1,), dtype=torch.int32, device='cuda')
+    carry = torch.empty((int(L.mtq_scan_carry_bytes(n)),), dtype=torch.uint8, device='cuda')
+    part = hb.tile_stats_partial(x, 0xE, 0x2, 0x4)
+    lscr = torch.empty((n * T + 1,), dtype=torch.int32, device='cuda')
 
 
-def timeit(fn):
-    fn(); torch.cuda.synchronize()
-    ts = []
-    for _ in range(reps):
-        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
-        e0.record(); fn(); e1.record(); e1.synchronize()
-        ts.append(e0.elapsed_time(e1))
-    ts.sort()
-    return ts[len(ts) // 2]
+    def timeit(fn):
+        fn(); torch.cuda.synchronize()
+        ts = []
+        for _ in range(reps):
+            e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+            e0.record(); fn(); e1.record(); e1.synchronize()
+            ts.append(e0.elapsed_time(e1))
+        ts.sort()
+        return ts[len(ts) // 2]
 
 
-print(f"timing, {n} tensors x {T} tiles (ms per launch, median of {reps}):")
-print(f"  orders kernel (once per launch, beside K1)      {timeit(lambda: hb.scan_orders_device(123, T, 2, out=orders)):.3f}")
-print(f"  search, own shuffles (round-2 form)             {timeit(lambda: hb.greedy_scan_device_ex(recs, DEC, ALL, 'pcc', 0.999, numel, sd, maps, status, scratch)):.3f}")
-print(f"  search, shared orders + helper wave             {timeit(lambda: hb.greedy_scan_device_ex(recs, DEC, ALL, 'pcc', 0.999, numel, sd, maps, status, scratch, orders=orders)):.3f}")
+    print(f"timing, {n} tensors x {T} tiles (ms per launch, median of {reps}):")
+    print(f"  orders kernel (once per launch, beside K1)      {timeit(lambda: hb.scan_orders_device(123, T, 2, out=orders)):.3f}")
+    print(f"  search, own shuffles (round-2 form)             {timeit(lambda: hb.greedy_scan_device_ex(recs, DEC, ALL, 'pcc', 0.999, numel, sd, maps, status, scratch)):.3f}")
+    print(f"  search, shared orders + helper wave             {timeit(lambda: hb.greedy_scan_device_ex(recs, DEC, ALL, 'pcc', 0.999, numel, sd, maps, status, scratch, orders=orders)):.3f}")
 
 
-def phase1():
-    nl.zero_()
-    hb.greedy_scan_device_ex(part, DEC, ALL, 'pcc', 0.999, numel, sd, maps, status, scratch, orders=orders, phase=1, listed=listed, n_listed=nl, carry=carry)
+    def phase1():
+        nl.zero_()
+        hb.greedy_scan_device_ex(part, DEC, ALL, 'pcc', 0.999, numel, sd, maps, status, scratch, orders=orders, phase=1, listed=listed, n_listed=nl, carry=carry)
 
 
-print(f"  split: phase 1 (shared orders)                  {timeit(phase1):.3f}")
-phase1()
-print(f"  split: listed K1 ({int(nl.item())} tiles)                {timeit(lambda: hb.tile_stats_listed(x, 0xE, 0x8, 0x4, listed, nl, part, scratch=lscr)):.3f}")
-
-
-def chain():
+    print(f"  split: phase 1 (shared orders)                  {timeit(phase1):.3f}")
     phase1()
-    hb.tile_stats_listed(x, 0xE, 0x8, 0x4, listed, nl, part, scratch=lscr)
-    hb.greedy_scan_device_ex(part, DEC, ALL, 'pcc', 0.999, numel, sd, maps, status, scratch, phase=2, carry=carry)
+    print(f"  split: listed K1 ({int(nl.item())} tiles)                {timeit(lambda: hb.tile_stats_listed(x, 0xE, 0x8, 0x4, listed, nl, part, scratch=lscr)):.3f}")
 
 
-print(f"  split: phase 1 + listed K1 + phase 2             {timeit(chain):.3f}")
-print(f"  split: listed K1, one wave per tile (no scratch) {timeit(lambda: hb.tile_stats_listed(x, 0xE, 0x8, 0x4, listed, nl, part)):.3f}")
-print(f"  K1 partial (bfp8 full, bfp4 sums)               {timeit(lambda: hb.tile_stats_partial(x, 0xE, 0x2, 0x4, out=part)):.3f}")
-print(f"  K1 full 0xE                                      {timeit(lambda: hb.tile_stats_batched(x, 0xE, out=recs)):.3f}")
+    def chain():
+        phase1()
+        hb.tile_stats_listed(x, 0xE, 0x8, 0x4, listed, nl, part, scratch=lscr)
+        hb.greedy_scan_device_ex(part, DEC, ALL, 'pcc', 0.999, numel, sd, maps, status, scratch, phase=2, carry=carry)
+
+
+    print(f"  split: phase 1 + listed K1 + phase 2             {timeit(chain):.3f}")
+    print(f"  split: listed K1, one wave per tile (no scratch) {timeit(lambda: hb.tile_stats_listed(x, 0xE, 0x8, 0x4, listed, nl, part)):.3f}")
+    print(f"  K1 partial (bfp8 full, bfp4 sums)               {timeit(lambda: hb.tile_stats_partial(x, 0xE, 0x2, 0x4, out=part)):.3f}")
+    print(f"  K1 full 0xE                                      {timeit(lambda: hb.tile_stats_batched(x, 0xE, out=recs)):.3f}")
+
+
+timing(x)
+del x
+# the large shape of BASELINE configs[3] (Llama-3-8B gate / up projections: 57 344 tiles per tensor), one tensor and a shape group's worth
+for cnt in (1, 32):
+    timing((torch.randn((cnt, 14336, 4096), generator=g, device='cuda') * 0.02).to(torch.bfloat16))
 print("MISMATCHES:", bad)
 sys.exit(1 if bad else 0)
