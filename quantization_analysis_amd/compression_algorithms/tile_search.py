@@ -181,6 +181,30 @@ def gather_tiles(ts: TileStats, tile_ids: np.ndarray) -> np.ndarray:
     return out
 
 
+def literal_inputs(ts: TileStats, tile_ids: np.ndarray, fmt: str, quantizer) -> tuple[np.ndarray, np.ndarray, np.ndarray]:
+    """(x tiles, y tiles, ids) of the named tiles as zero-padded (k,32,32) float32 host arrays, `ids` naming the tile of every row
+    (a permutation of tile_ids): what the reference's literal float32 tile score takes (tile_utils.py:46-57 on y = Quantizer.quantize
+    of the tiles).  On the hip backend both come from one device call (mtq_knife_tiles_device: the tiles fetched and quantised where the
+    tensor lives, 8 KB per tile home, in the order the device listed them) instead of tiles down, tiles up, K2, y down."""
+    ids = np.asarray(tile_ids, dtype=np.int64).reshape(-1)
+    if ts.backend == "hip" and ids.size and fmt in MIXED_TILE_FORMATS and ts.x2d.stride(-1) == 1:
+        from .. import hip_backend as hb
+
+        torch = __import__("torch")
+        dev = ts.x2d.device
+        flags = torch.zeros((ts.tiles,), dtype=torch.int8, device=dev)
+        flags[torch.from_numpy(ids).to(dev)] = 1
+        k = int(ids.size)
+        lst = torch.empty((k + 1,), dtype=torch.int64, device=dev)
+        out = torch.empty((2, k, TILE, TILE), dtype=torch.float32, device=dev)
+        hb.knife_tiles_device(ts.x2d[None], flags, [fmt], k, lst, out)
+        host = out.cpu().numpy()
+        return host[0], host[1], lst[:k].cpu().numpy()
+    xt = gather_tiles(ts, ids)
+    yt = np.asarray(quantizer.quantize(xt.reshape(xt.shape[0] * TILE, TILE), fmt), dtype=np.float32).reshape(xt.shape[0], TILE, TILE)
+    return xt, yt, ids
+
+
 def columns_from_stats(ts: TileStats, assignment: np.ndarray) -> dict:
     """Tensor-level pcc / mae / atol of the reconstruction, from the float64 raw sums — summed on the device when the records
     live there and have not been brought to the host anyway (1 B/tile up, seven doubles back)."""

@@ -10,9 +10,9 @@ from __future__ import annotations
 
 import numpy as np
 
-from .compression_algorithms.mixed_tile_threshold import KNIFE_BAND, _quantize_tiles, knife_width
+from .compression_algorithms.mixed_tile_threshold import KNIFE_BAND, knife_width
 from .compression_algorithms.quantizer import Quantizer
-from .compression_algorithms.tile_search import columns_from_stats, compute_tile_stats, gather_tiles, tile_scores
+from .compression_algorithms.tile_search import columns_from_stats, compute_tile_stats, literal_inputs, tile_scores
 from .compression_algorithms.tile_utils import MIXED_TILE_BYTES_PER_ELEM, MIXED_TILE_FORMATS, mixed_tile_total_bytes, tile_metrics
 
 
@@ -82,8 +82,8 @@ def sweep_tensor(xf, formats: list[str], metric: str, lowest_metric_val: float, 
         # in bounded chunks (4 KB per tile through the host)
         for c0 in range(0, cand.size, LITERAL_CHUNK_TILES):
             part = cand[c0:c0 + LITERAL_CHUNK_TILES]
-            xt = gather_tiles(ts, part)
-            s32[hi, part] = tile_metrics(xt, np.asarray(_quantize_tiles(xt, highest, quantizer), dtype=np.float32), metric)
+            xt, yt, got = literal_inputs(ts, part, highest, quantizer)
+            s32[hi, got] = tile_metrics(xt, yt, metric)
         literal_hi[cand] = True
         start = float(np.max(s32[hi])) if metric == "pcc" else float(np.min(s32[hi]))
     thresholds = np.linspace(start, lowest_metric_val, max(1, steps))
@@ -103,8 +103,8 @@ def sweep_tensor(xf, formats: list[str], metric: str, lowest_metric_val: float, 
             ids = np.where(near)[0]
             for c0 in range(0, ids.size, LITERAL_CHUNK_TILES):
                 part = ids[c0:c0 + LITERAL_CHUNK_TILES]
-                xt = gather_tiles(ts, part)
-                s32[fi, part] = tile_metrics(xt, np.asarray(_quantize_tiles(xt, f, quantizer), dtype=np.float32), metric)
+                xt, yt, got = literal_inputs(ts, part, f, quantizer)
+                s32[fi, got] = tile_metrics(xt, yt, metric)
 
     baselines = []
     for f in formats:                                                                 # :688-715
