@@ -51,6 +51,25 @@ def pareto_frontier(points: list[dict], metric: str) -> list[dict]:
     return sorted([p for p, keep in zip(points, pareto_mask(points, metric)) if keep], key=lambda p: p["size"])
 
 
+def _literal_scores(ts, ids: np.ndarray, fmt: str, quantizer: Quantizer, metric: str):
+    """(tile ids, their literal float32 scores under fmt) chunk by chunk (LITERAL_CHUNK_TILES tiles each: 128 MiB of x and y tiles on
+    the host).  With several chunks — identity-like formats put all 10^5 tiles of a large tensor inside the band — a few threads work on
+    different chunks: the score is NumPy reductions and BLAS dot products over a chunk's tiles, which run without the interpreter lock,
+    and a chunk's tiles come home while another chunk is scored.  Same calls per chunk, same bits."""
+    chunks = [ids[c0:c0 + LITERAL_CHUNK_TILES] for c0 in range(0, ids.size, LITERAL_CHUNK_TILES)]
+
+    def one(part):
+        xt, yt, got = literal_inputs(ts, part, fmt, quantizer)
+        return got, tile_metrics(xt, yt, metric)
+
+    if len(chunks) <= 1:
+        return [one(c) for c in chunks]
+    import concurrent.futures as cf
+
+    with cf.ThreadPoolExecutor(max_workers=min(4, len(chunks))) as pool:
+        return list(pool.map(one, chunks))
+
+
 def sweep_tensor(xf, formats: list[str], metric: str, lowest_metric_val: float, steps: int, quantizer: Quantizer):
     """→ (rows, baseline_points, thresholds).  rows: dicts with the CSV columns of reference :793
     (step, threshold, size_bytes, pcc, mae, atol, <fmt>_tiles)."""
@@ -80,10 +99,8 @@ def sweep_tensor(xf, formats: list[str], metric: str, lowest_metric_val: float, 
         # are 1 ± a few ulp and the reference's start value is their exact maximum (a 2-ulp outlier among 10^5 tiles decides it, so a
         # sample is not enough: golden-size check tests/test_configs_gpu.py::test_config4_sweep_deepseek_layer0) — all of them are scored,
         # in bounded chunks (4 KB per tile through the host)
-        for c0 in range(0, cand.size, LITERAL_CHUNK_TILES):
-            part = cand[c0:c0 + LITERAL_CHUNK_TILES]
-            xt, yt, got = literal_inputs(ts, part, highest, quantizer)
-            s32[hi, got] = tile_metrics(xt, yt, metric)
+        for got, scores in _literal_scores(ts, cand, highest, quantizer, metric):
+            s32[hi, got] = scores
         literal_hi[cand] = True
         start = float(np.max(s32[hi])) if metric == "pcc" else float(np.min(s32[hi]))
     thresholds = np.linspace(start, lowest_metric_val, max(1, steps))
@@ -101,10 +118,8 @@ def sweep_tensor(xf, formats: list[str], metric: str, lowest_metric_val: float, 
             if fi == hi:
                 near &= ~literal_hi
             ids = np.where(near)[0]
-            for c0 in range(0, ids.size, LITERAL_CHUNK_TILES):
-                part = ids[c0:c0 + LITERAL_CHUNK_TILES]
-                xt, yt, got = literal_inputs(ts, part, f, quantizer)
-                s32[fi, got] = tile_metrics(xt, yt, metric)
+            for got, scores in _literal_scores(ts, ids, f, quantizer, metric):
+                s32[fi, got] = scores
 
     baselines = []
     for f in formats:                                                                 # :688-715
