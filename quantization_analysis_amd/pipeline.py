@@ -1,11 +1,14 @@
-"""Streamed multi-tensor driver of the mixed-tile-greedy hot path on one GPU.
+"""Streamed multi-tensor drivers of the mixed-tile search on one GPU.
 
-A model's matched tensors are independent (reference wq:655 loop), so a rank streams its share:
-  K1 (batched launch over a chunk of equally shaped tensors, HIP stream A)
-    → stats D2H into pinned host memory (stream B, event)
-    → per-tensor sequential greedy scan on host worker threads (C++ scan pool in libmtq_hip.so, GIL released)
-while the next chunk's K1 is already running; `run_steps` also overlaps consecutive batches (three record slots).  y is not materialised here (assignment maps + pcc/mae/atol
-are the outputs the north star names); use compression_algorithms.* for the drop-in run() that returns y.
+A model's matched tensors are independent (reference wq:655 loop), so a rank streams its share.  GreedyPipeline, device route (the
+default): K1 over a batch of equally shaped tensors on the K1 stream (the lazy route evaluates what the search reads
+first) → on one of three search streams the launch's visiting orders, K1's fix-up, the search (in two phases around the listed K1 on the
+lazy route), the column sums and a copy kernel that stores maps, counts and seven sums per tensor into pinned host memory — while the
+next batches' K1 is already running (`run_steps` / `run_batches`: four record slots).  Host route (`scan="host"`, repeated formats):
+K1 per chunk → records D2H into pinned memory on a copy stream → per-tensor sequential scans on host worker threads (C++ scan pool in
+libmtq_hip.so, GIL released).  ThresholdPipeline: K1 → the threshold rule, the knife-edge tiles' list / fetch / quantisation and the
+column sums on the device; the host scores the knife-edge tiles literally.  y is not materialised here (assignment maps + pcc / mae /
+atol are the outputs the north star names); use compression_algorithms.* for the drop-in run() that returns y.
 """
 from __future__ import annotations
 
@@ -99,7 +102,7 @@ def _scan_chunk_chain(first, chain, base, tiles_hw, numel, tile_formats, thresho
 def _sleep_until(event, tick: float = 1e-4) -> None:
     """Wait for a HIP event without burning the core: hipEventSynchronize spins on this runtime even for events created with the
     blocking flag (the driver thread showed 100 % CPU while 'waiting'), so the event is polled between short sleeps.  The pipeline
-    has a whole step of slack on this wait (three record slots)."""
+    has a whole step of slack on this wait (several record slots)."""
     import time
 
     while not event.query():
