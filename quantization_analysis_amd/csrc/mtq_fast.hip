@@ -252,6 +252,158 @@ __device__ __forceinline__ void fast_group(const uint32_t w[8], GroupOut &G, Rel
 }
 
 // ---------------------------------------------------------------------------------------------
+// The same group in the FLOAT domain (round 4; -DMTQ_K1_INTDOM selects the packed-integer form above instead).
+//
+// Nothing is decoded: the bf16 pair is widened to two float32 values (one shift, one and) and every BFP rounding is done where the
+// value stands.  With P = 2^(E−127) (the group maximum's power of two), a format of M mantissa bits has the step q = P·2^(1−M):
+//     r = x + C,  C = 1.5·2^23·q      r is x rounded to the nearest multiple of q, ties to the even multiple (C is an even multiple
+//     y = r − C   (exact)             of q and |x| < 2P ≪ C/3, so r stays in C's binade) — the reference's RNE of the aligned mantissa
+//     y = med3(y, −(2^M−1)·q, (2^M−1)·q)   its saturating round-up (quantization_formats.py:133-141)
+// (bf16 input has 8 significant bits, so the alignment shift of :126-131 loses nothing for d = E−e ≤ 16 and values further down
+// round to 0 either way.)  Which float32 accumulations are EXACT — a sum of ≤ 16 integers below 2^24 times one power of two, hence equal
+// to the float64 sum of include/mtq.h's order — with u = 2^(E−148), every main-class value (d ≤ 14) an integer multiple of u below 2^22·u:
+//     Σy (≤ 2^(M+4) steps), Σy² (≤ 2^(2M+4) steps²): always;
+//     bfp8: y ≠ 0 ⇒ d ≤ 7 ⇒ δ = x − y is a multiple of 2^7·u, |δ| ≤ 2^15·u ⇒ Σδ·y ≤ 2^19 units of 2^22·u²: exact, and
+//           Σxy = Σy² + Σδ·y (both exact, joined in float64; Σx·y itself may need 26 bits);
+//     bfp4, bfp2: y ≠ 0 ⇒ d ≤ 3 (1) ⇒ x·y is a multiple of 2^30 (2^34)·u² below 2^44·u² ⇒ Σx·y ≤ 18 bits: exact directly;
+//     Σ|x−y|: |δ| ≤ 2^15·u (bfp8), 2^19·u (bfp4), 2^21·u (bfp2), integers in u ⇒ sums of 16 ≤ 2^19, 2^23 — bfp2 needs 2^25 and
+//           is kept in two accumulators of 8 elements (≤ 2^24 each) joined in float64;
+//     max|x−y|: a maximum is exact.
+// Σx and Σx² need up to 26 / 48 bits: they are float64 chains over the elements (v_cvt_f64_f32, v_add_f64, v_fma_f64 — x² is exact in
+// float64, so the fused form equals the literal add of the float32 product), exact for the main class (< 2^53·u²).
+// A lane whose group holds a non-zero TAIL element (d ≥ 15: |x| < P·2^−14; about 6e-5 of Gaussian elements) redoes Σx, Σx² and
+// Σ|x−y| of that group in the contract's main + tail form in a divergent loop (the maxima and the y-side sums are unaffected: y = 0
+// there).  Groups with E outside [80,180] or a NaN mark the tile for the literal fix-up, all-zero groups contribute ±0, as above.
+// ---------------------------------------------------------------------------------------------
+typedef float f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float u2f(uint32_t v) { return __uint_as_float(v); }
+__device__ __forceinline__ uint32_t f2u(float v) { return __float_as_uint(v); }
+__device__ __forceinline__ void max3_abs(float &m, float a, float b) { asm("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(m) : "v"(a), "v"(b)); }
+__device__ __forceinline__ void min3_abs(float &m, float a, float b) { asm("v_min3_f32 %0, %0, |%1|, |%2|" : "+v"(m) : "v"(a), "v"(b)); }
+
+template <int M> struct FmtF {   // per-group constants of one BFP format as multiples of P = 2^(E−127)
+    static constexpr float kC = M == 7 ? 196608.0f : (M == 3 ? 3145728.0f : 12582912.0f);   // 1.5·2^(24−M)
+    static constexpr float kHi = M == 7 ? 1.984375f : (M == 3 ? 1.75f : 1.0f);              // (2^M − 1)·2^(1−M)
+};
+
+struct FAcc {   // float32 group sums of one BFP format (packed: element 2i in .x, 2i+1 in .y)
+    f2 sy, sy2, sxy;     // Σy, Σy², bfp8: Σδ·y, bfp4 / bfp2: Σx·y
+    float sad, sad2;     // Σ|x−y| (bfp2: elements 0..7 and 8..15)
+    float mx;            // max|x−y|
+};
+
+template <int M, bool kSum, bool kErr>
+__device__ __forceinline__ void f32_step(f2 x, float C, float hi, int i, FAcc &A)
+{
+    const f2 r = (x + C) - C;
+    f2 y;
+    y.x = __builtin_amdgcn_fmed3f(r.x, -hi, hi);
+    y.y = __builtin_amdgcn_fmed3f(r.y, -hi, hi);
+    if constexpr (kSum) {
+        A.sy += y;
+        A.sy2 = __builtin_elementwise_fma(y, y, A.sy2);
+    }
+    if constexpr (kErr || (kSum && M == 7)) {
+        const f2 d = x - y;
+        if constexpr (kSum && M == 7) A.sxy = __builtin_elementwise_fma(d, y, A.sxy);
+        if constexpr (kErr) {
+            if (M == 1 && i >= 4) { A.sad2 += __builtin_fabsf(d.x); A.sad2 += __builtin_fabsf(d.y); }
+            else { A.sad += __builtin_fabsf(d.x); A.sad += __builtin_fabsf(d.y); }
+            max3_abs(A.mx, d.x, d.y);
+        }
+    }
+    if constexpr (kSum && M != 7) A.sxy = __builtin_elementwise_fma(x, y, A.sxy);
+}
+
+// the group's terms of one format from its float32 sums
+template <int M, bool kSum, bool kErr>
+__device__ __forceinline__ void f32_terms(const FAcc &A, double *t, float &mx)
+{
+    if constexpr (kSum) {
+        const double sy2 = (double)(A.sy2.x + A.sy2.y), sxy = (double)(A.sxy.x + A.sxy.y);
+        t[0] = (double)(A.sy.x + A.sy.y);
+        t[1] = sy2;
+        t[2] = M == 7 ? sy2 + sxy : sxy;
+    }
+    if constexpr (kErr) {
+        t[3] = M == 1 ? (double)A.sad + (double)A.sad2 : (double)A.sad;
+        mx = A.mx;
+    }
+}
+
+template <uint32_t SUMS, uint32_t ERRS, bool XS, typename Reload>
+__device__ __forceinline__ void fast_group_f32(const uint32_t w[8], GroupOut &G, Reload reload)
+{
+    constexpr uint32_t ANY = SUMS | ERRS;
+    f2 x[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { x[i].x = u2f(w[i] << 16); x[i].y = u2f(w[i] & 0xFFFF0000u); }
+    float amax = 0.0f, amin = __builtin_inff();
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { max3_abs(amax, x[i].x, x[i].y); min3_abs(amin, x[i].x, x[i].y); }
+    const uint32_t E = f2u(amax) >> 23;                           // shared exponent (quantization_formats.py:118-119); 255 for Inf (and NaN, should the maximum keep one)
+    const bool zero_group = f2u(amax) == 0u, out_of_range = (E - 80u) > 100u;
+    const float P = u2f((out_of_range ? 127u : E) << 23);          // finite constants whatever E is: a marked tile's numbers are never used
+    const float c8 = P * FmtF<7>::kC, c4 = P * FmtF<3>::kC, c2 = P * FmtF<1>::kC;
+    const float h8 = P * FmtF<7>::kHi, h4 = P * FmtF<3>::kHi, h2 = P;
+    const float thr = P * 0x1p-14f;                                // smallest main-class magnitude
+
+    double sx = 0.0, sx2 = 0.0;
+    FAcc A8 = {{0.0f, 0.0f}, {0.0f, 0.0f}, {0.0f, 0.0f}, 0.0f, 0.0f, 0.0f}, A4 = A8, A2 = A8;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        if constexpr (XS) {
+            const double x0 = (double)x[i].x, x1 = (double)x[i].y;
+            sx += x0; sx2 = __builtin_fma(x0, x0, sx2);
+            sx += x1; sx2 = __builtin_fma(x1, x1, sx2);
+        }
+        if constexpr (ANY & 1u) f32_step<7, (SUMS & 1u) != 0, (ERRS & 1u) != 0>(x[i], c8, h8, i, A8);
+        if constexpr (ANY & 2u) f32_step<3, (SUMS & 2u) != 0, (ERRS & 2u) != 0>(x[i], c4, h4, i, A4);
+        if constexpr (ANY & 4u) f32_step<1, (SUMS & 4u) != 0, (ERRS & 4u) != 0>(x[i], c2, h2, i, A2);
+    }
+#pragma unroll
+    for (int s = 0; s < kSums; ++s) G.term[s] = 0.0;
+    G.mx[0] = G.mx[1] = G.mx[2] = 0.0f;
+    if constexpr (XS) { G.term[0] = sx; G.term[1] = sx2; }
+    if constexpr (ANY & 1u) f32_terms<7, (SUMS & 1u) != 0, (ERRS & 1u) != 0>(A8, G.term + 2, G.mx[0]);
+    if constexpr (ANY & 2u) f32_terms<3, (SUMS & 2u) != 0, (ERRS & 2u) != 0>(A4, G.term + 6, G.mx[1]);
+    if constexpr (ANY & 4u) f32_terms<1, (SUMS & 4u) != 0, (ERRS & 4u) != 0>(A2, G.term + 10, G.mx[2]);
+    // a NaN element: max3 / min3 pass it over, every sum it enters does not — probe one such sum per instantiation
+    double probe = 0.0;
+    if constexpr (XS) probe = sx;
+    else if constexpr (ERRS != 0u) probe = G.term[(ERRS & 1u) ? 5 : ((ERRS & 2u) ? 9 : 13)];
+    else probe = G.term[(SUMS & 1u) ? 4 : ((SUMS & 2u) ? 8 : 12)];
+    G.bad = (out_of_range && !zero_group) || probe != probe;
+
+    // tail class present (a zero element alone also gets here — the loop then changes nothing but a sum's order of exact terms)
+    if (__builtin_expect(amin < thr && !zero_group && !out_of_range, 0)) {
+        double mx_ = 0.0, mx2 = 0.0, tx = 0.0, tx2 = 0.0, tab = 0.0, m8 = 0.0, m4 = 0.0, m2 = 0.0;
+        uint32_t w2[8];
+        reload(w2);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const float xv = h == 0 ? u2f(w2[i] << 16) : u2f(w2[i] & 0xFFFF0000u);
+                const double xd = (double)xv;
+                if (__builtin_fabsf(xv) < thr) {                   // tail (zeros included): y = 0 in every BFP format, |x − y| = |x|
+                    tx += xd; tx2 = __builtin_fma(xd, xd, tx2); tab += __builtin_fabs(xd);
+                } else {
+                    mx_ += xd; mx2 = __builtin_fma(xd, xd, mx2);
+                    if constexpr (ERRS & 1u) m8 += (double)__builtin_fabsf(xv - __builtin_amdgcn_fmed3f((xv + c8) - c8, -h8, h8));
+                    if constexpr (ERRS & 2u) m4 += (double)__builtin_fabsf(xv - __builtin_amdgcn_fmed3f((xv + c4) - c4, -h4, h4));
+                    if constexpr (ERRS & 4u) m2 += (double)__builtin_fabsf(xv - __builtin_amdgcn_fmed3f((xv + c2) - c2, -h2, h2));
+                }
+            }
+        }
+        if constexpr (XS) { G.term[0] = mx_ + tx; G.term[1] = mx2 + tx2; }
+        if constexpr (ERRS & 1u) G.term[5] = m8 + tab;
+        if constexpr (ERRS & 2u) G.term[9] = m4 + tab;
+        if constexpr (ERRS & 4u) G.term[13] = m2 + tab;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // The kernel.  The 4 groups of a lane run in a ROLLED loop that reads each group from the LDS image just
 // before use (a fully unrolled, software-pipelined form needed 230 VGPRs and ran no faster: the kernel is
 // VALU-issue bound).  The reduce scratch and the record image
@@ -277,8 +429,16 @@ __host__ __device__ constexpr int rolled_waves(uint32_t sums, uint32_t errs)
 {
 #ifdef MTQ_ROLLED_WAVES_PER_SIMD_FORCE
     return MTQ_ROLLED_WAVES_PER_SIMD_FORCE;
-#else
+#elif defined(MTQ_K1_INTDOM)
     return (sums == 7u && errs == 7u) ? 3 : 4;
+#else
+    // float-domain form: the registers an instantiation wants without a cap (hipcc 7.2: <1,0> 95, <2,2> 126, <1,1> 142, <3,1> 149,
+    // <3,3> 172, <7,7> 203) decide; 8 KiB of LDS per wave allows 5
+    const uint32_t any = sums | errs;
+    const int n = (int)((any & 1u) + ((any >> 1) & 1u) + ((any >> 2) & 1u));
+    if (n == 3) return 2;
+    if (n == 2 || (errs & 1u)) return 3;
+    return errs == 0u ? 5 : 4;
 #endif
 }
 
@@ -440,7 +600,11 @@ __global__ __launch_bounds__(kFastWaves * 64, rolled_waves(SUMS, ERRS)) void til
             const uint4 hi = *reinterpret_cast<const uint4 *>(rowp + ((c0 ^ (kl | 1u)) << 4));
             const uint32_t w[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
             GroupOut G;
+#ifdef MTQ_K1_INTDOM
             fast_group<SUMS, ERRS, XS>(w, G, [&](uint32_t w2[8]) {
+#else
+            fast_group_f32<SUMS, ERRS, XS>(w, G, [&](uint32_t w2[8]) {
+#endif
                 const uint4 l2 = *reinterpret_cast<const uint4 *>(rowp + ((c0 ^ kl) << 4));
                 const uint4 h2 = *reinterpret_cast<const uint4 *>(rowp + ((c0 ^ (kl | 1u)) << 4));
                 w2[0] = l2.x; w2[1] = l2.y; w2[2] = l2.z; w2[3] = l2.w; w2[4] = h2.x; w2[5] = h2.y; w2[6] = h2.z; w2[7] = h2.w;
