@@ -63,13 +63,15 @@ def cpu_model() -> str:
     return "unknown"
 
 
-def cpu_baseline(sample: torch.Tensor, threads: int) -> dict:
+def cpu_baseline(sample: torch.Tensor, threads: int, gpu_results=None) -> dict:
     """Three CPU figures on rank 0's host, each timed like wq:680-682 times algo.run (perf_counter around the whole search):
       cpu_baseline            the C port (oracle/mtq_oracle.c), 1 thread, `len(sample)` tensors            kind "port"
       cpu_baseline_threads    the same port, one tensor per thread on `threads` threads (the rank's CPU quota) kind "port"
       cpu_baseline_emulation  the package's NumPy host backend (`--backend emulation`: how the reference executes — single-threaded
                               NumPy, quantize per format + per-tile sums + sequential scan, wq:680-682), one tensor  kind "emulation"
-    All three produce the same maps (asserted)."""
+    All three produce the same maps (asserted).  `gpu_results` (the timed steps' own TensorResults of the same tensors): the GPU's maps and
+    counts must equal the oracle's and its pcc / mae / atol columns the oracle's columns_from_stats to 1e-12 — "parity_on_bench_inputs" in
+    the line; a mismatch raises, so a bench line is only ever printed for results the checker agrees with (wq:679-706)."""
     import concurrent.futures as cf
 
     import numpy as np
@@ -81,13 +83,33 @@ def cpu_baseline(sample: torch.Tensor, threads: int) -> dict:
     t0 = time.perf_counter()
     tiles = 0
     maps = []
+    states = []
     for x in xs:
-        a, _c, _s = orc.greedy(x, FORMATS, METRIC, THRESHOLD, SEED)
+        a, c, st = orc.greedy(x, FORMATS, METRIC, THRESHOLD, SEED)
         tiles += a.size
         maps.append(a)
+        states.append((c, st))
     dt = time.perf_counter() - t0
+    parity = None
+    if gpu_results is not None:
+        slots = orc.mask_slots(orc.fmt_mask(FORMATS))
+        worst = 0.0
+        for i, (a, (c, st)) in enumerate(zip(maps, states)):
+            r = gpu_results[i]
+            if not np.array_equal(r.assignment, a) or any(int(r.counts[f]) != int(c[f]) for f in c):
+                raise SystemExit(f"bench: the GPU's map of tensor {i} differs from the oracle's ({int((r.assignment != a).sum())} tiles)")
+            cols = orc.columns_from_stats(st["stats"], slots, a, xs[i].size)
+            for got, want in zip((r.pcc, r.mae, r.atol), cols):
+                worst = max(worst, abs(got - want))
+            if worst > 1e-12:
+                raise SystemExit(f"bench: the GPU's pcc / mae / atol of tensor {i} are {worst:.3e} off the oracle's columns_from_stats")
+        parity = {"maps_equal_oracle": f"{len(maps)}/{len(maps)}", "counts_equal_oracle": True, "columns_max_abs_diff": worst,
+                  "checked": "the timed region's last step: assignment maps and counts of the --cpu-sample tensors against oracle/mtq_oracle greedy, "
+                             "pcc / mae / atol against its columns_from_stats (tolerance 1e-12)"}
     out = {"cpu_baseline": {"value": tiles / dt, "unit": "tiles/s", "cores": 1, "kind": "port", "cpu": cpu_model(),
                             "sample": f"{len(xs)} of the step's 4096x4096 bf16 tensors, oracle/mtq_oracle.c greedy (1 thread), {dt:.1f} s"}}
+    if parity is not None:
+        out["parity_on_bench_inputs"] = parity
     if threads > 1:
         reps = max(1, -(-2 * threads // len(xs)))          # at least two tensors per thread
         work = (xs * reps)[: max(2 * threads, len(xs))]
@@ -652,7 +674,9 @@ def run_m1_workload(args, dist, rank, world, device, barrier, numa) -> None:
                         "counts_bf16_bfp8_bfp4_bfp2": [int(all_rows[:, 6 + i].sum()) for i in range(4)]},
         }
         if args.cpu_sample > 0 and world == 1:   # the CPU legs are a N = 1 report: the other ranks would wait in the barrier below
-            out.update(cpu_baseline(batch[: min(args.cpu_sample, args.tensors)], cpu_budget()))
+            k = min(args.cpu_sample, args.tensors)
+            by_index = {r.index: r for r in res}
+            out.update(cpu_baseline(batch[:k], cpu_budget(), [by_index[i] for i in range(k)]))
     pipe.close()
     if rank == 0:
         if args.legs == "all" and world == 1:

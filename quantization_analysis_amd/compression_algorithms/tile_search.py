@@ -192,14 +192,18 @@ def literal_inputs(ts: TileStats, tile_ids: np.ndarray, fmt: str, quantizer) -> 
 
         torch = __import__("torch")
         dev = ts.x2d.device
-        flags = torch.zeros((ts.tiles,), dtype=torch.int8, device=dev)
-        flags[torch.from_numpy(ids).to(dev)] = 1
-        k = int(ids.size)
-        lst = torch.empty((k + 1,), dtype=torch.int64, device=dev)
-        out = torch.empty((2, k, TILE, TILE), dtype=torch.float32, device=dev)
-        hb.knife_tiles_device(ts.x2d[None], flags, [fmt], k, lst, out)
-        host = out.cpu().numpy()
-        return host[0], host[1], lst[:k].cpu().numpy()
+        # torch's current device / stream and HIP's current device are per THREAD and a new thread starts on device 0: the sweep calls
+        # this from pool threads (sweep._literal_scores), so the tensor's own device is made current here — the launches then go to a
+        # stream of the device the pointers live on, whatever rank / thread this is
+        with torch.cuda.device(dev):
+            flags = torch.zeros((ts.tiles,), dtype=torch.int8, device=dev)
+            flags[torch.from_numpy(ids).to(dev)] = 1
+            k = int(ids.size)
+            lst = torch.empty((k + 1,), dtype=torch.int64, device=dev)
+            out = torch.empty((2, k, TILE, TILE), dtype=torch.float32, device=dev)
+            hb.knife_tiles_device(ts.x2d[None], flags, [fmt], k, lst, out)
+            host = out.cpu().numpy()
+            return host[0], host[1], lst[:k].cpu().numpy()
     xt = gather_tiles(ts, ids)
     yt = np.asarray(quantizer.quantize(xt.reshape(xt.shape[0] * TILE, TILE), fmt), dtype=np.float32).reshape(xt.shape[0], TILE, TILE)
     return xt, yt, ids

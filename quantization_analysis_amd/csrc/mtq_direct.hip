@@ -279,8 +279,11 @@ __global__ __launch_bounds__(kDirectWaves * 64, MTQ_DIRECT_WAVES_PER_SIMD) void 
 // statistic k of Σy, Σy², Σxy, Σ|x−y|, max|x−y|) are written, at the format's slot offset in the record layout (its byte of `obase`);
 // Σx, Σx² and every other slot of the record are left as they are.  A tile the exact route cannot take (a group outside its exponent
 // range) is evaluated on the spot by the literal route: no follow-up kernel.
-template <typename T, uint32_t FM>
-__global__ __launch_bounds__(kDirectWaves * 64, MTQ_DIRECT_WAVES_PER_SIMD) void tile_stats_listed(
+// W = waves per block: kDirectWaves for a list that fills the chip; 1 — compiled for 5 waves per SIMD, i.e. 96 registers, the literal
+// branch spilling — for the few-or-none tiles the LDS-staged listed kernel hands back: that launch sits in the search chain of every
+// batch, and a 152-register wave is only placed where K1's blocks leave that much of a SIMD (0.26 ms per step in the round-4 trace).
+template <typename T, uint32_t FM, int W = kDirectWaves>
+__global__ __launch_bounds__(W * 64, W == 1 ? 5 : MTQ_DIRECT_WAVES_PER_SIMD) void tile_stats_listed(
     const T *__restrict__ x, int64_t stride, int64_t rows, int64_t cols, int64_t ld, uint32_t tiles_w, uint32_t tiles,
     const uint32_t *__restrict__ list, const uint32_t *__restrict__ n_list, uint32_t cap, double *__restrict__ stats, int vec_ok, int rec,
     uint32_t obase, uint32_t wmask)
@@ -291,7 +294,7 @@ __global__ __launch_bounds__(kDirectWaves * 64, MTQ_DIRECT_WAVES_PER_SIMD) void 
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     double *part = reinterpret_cast<double *>(lds) + wave * (64 * pad);          // [64 groups][pad]
     const uint32_t n = min(*n_list, cap);
-    const uint32_t step = gridDim.x * kDirectWaves;
+    const uint32_t step = gridDim.x * W;
 
     auto fetch = [&](uint32_t gt, uint32_t (&u)[kGroup]) {
         const uint32_t b = gt / tiles, t = gt - b * tiles;
@@ -300,7 +303,7 @@ __global__ __launch_bounds__(kDirectWaves * 64, MTQ_DIRECT_WAVES_PER_SIMD) void 
                          cols, ld, vec_ok != 0, u);
     };
 
-    uint32_t k = blockIdx.x * kDirectWaves + wave;
+    uint32_t k = blockIdx.x * W + wave;
     uint32_t gt = k < n ? list[k] : 0u;
     uint32_t nxt[kGroup];
     if (k < n) fetch(gt, nxt);
@@ -370,14 +373,14 @@ __global__ __launch_bounds__(kDirectWaves * 64, MTQ_DIRECT_WAVES_PER_SIMD) void 
     }
 }
 
-template <typename T>
+template <typename T, int W = kDirectWaves>
 static void launch_listed(uint32_t fm, dim3 grid, hipStream_t st, const T *x, int64_t stride, int64_t rows, int64_t cols, int64_t ld,
                           uint32_t tiles_w, uint32_t tiles, const uint32_t *list, const uint32_t *n_list, uint32_t cap, double *stats, int vec_ok,
                           int rec, uint32_t obase, uint32_t wmask)
 {
-    const dim3 block(kDirectWaves * 64);
+    const dim3 block(W * 64);
 #define MTQ_LAUNCH_LISTED(M) \
-    case M: hipLaunchKernelGGL((tile_stats_listed<T, M>), grid, block, (size_t)kDirectWaves * 64 * direct_pad(M) * sizeof(double), st, x, \
+    case M: hipLaunchKernelGGL((tile_stats_listed<T, M, W>), grid, block, (size_t)W * 64 * direct_pad(M) * sizeof(double), st, x, \
                                stride, rows, cols, ld, tiles_w, tiles, list, n_list, cap, stats, vec_ok, rec, obase, wmask); break;
     switch (fm) { // BFP subsets only: the bf16 slot has no use for a late evaluation
         MTQ_LAUNCH_LISTED(2u) MTQ_LAUNCH_LISTED(4u) MTQ_LAUNCH_LISTED(6u) MTQ_LAUNCH_LISTED(8u) MTQ_LAUNCH_LISTED(10u)
@@ -494,6 +497,7 @@ extern "C" int mtq_tile_stats_listed(const void *x, int in_dtype, int64_t count,
     dim3 grid((unsigned)(need < max_blocks ? need : max_blocks));
     hipStream_t st = static_cast<hipStream_t>(stream);
     const uint32_t cap = (uint32_t)(capacity < (int64_t)UINT32_MAX ? capacity : (int64_t)UINT32_MAX);
+    bool handed_back = false;
     if (in_dtype == MTQ_DTYPE_BF16 && vec_ok && scratch && getenv("MTQ_LISTED_DIRECT") == nullptr) {
         // scratch[0]: the redo list's length, scratch[1..]: the list
         if (hipMemsetAsync(scratch, 0, sizeof(uint32_t), st) != hipSuccess) return fail(MTQ_ERR_HIP, "hipMemsetAsync failed");
@@ -503,10 +507,14 @@ extern "C" int mtq_tile_stats_listed(const void *x, int in_dtype, int64_t count,
         if (rc == 0) {   // what is left for the kernel above: the tiles the exact route handed back — few or none: a small grid strides through them
             listed = scratch + 1;
             n_listed = scratch;
-            grid = dim3(grid.x < 64u ? grid.x : 64u);
+            grid = dim3(grid.x < 128u ? grid.x : 128u);
+            handed_back = true;
         }
     }
-    if (in_dtype == MTQ_DTYPE_BF16)
+    if (handed_back)
+        launch_listed<uint16_t, 1>(fm, grid, st, static_cast<const uint16_t *>(x), stride_elems, rows, cols, ld, (uint32_t)tw, (uint32_t)tiles, listed,
+                                   n_listed, cap, stats, vec_ok, rec, obase, wmask);
+    else if (in_dtype == MTQ_DTYPE_BF16)
         launch_listed<uint16_t>(fm, grid, st, static_cast<const uint16_t *>(x), stride_elems, rows, cols, ld, (uint32_t)tw, (uint32_t)tiles, listed,
                                 n_listed, cap, stats, vec_ok, rec, obase, wmask);
     else

@@ -288,11 +288,12 @@ template <int M> struct FmtF {   // per-group constants of one BFP format as mul
 
 struct FAcc {   // float32 group sums of one BFP format (packed: element 2i in .x, 2i+1 in .y)
     f2 sy, sy2, sxy;     // Σy, Σy², bfp8: Σδ·y, bfp4 / bfp2: Σx·y
+    f2 sd;               // bfp8 beside Σx: Σδ (Σx = Σy + Σδ, both exact: |Σδ| ≤ 2^19·u)
     float sad, sad2;     // Σ|x−y| (bfp2: elements 0..7 and 8..15)
     float mx;            // max|x−y|
 };
 
-template <int M, bool kSum, bool kErr>
+template <int M, bool kSum, bool kErr, bool kSd = false>
 __device__ __forceinline__ void f32_step(f2 x, float C, float hi, int i, FAcc &A)
 {
     const f2 r = (x + C) - C;
@@ -305,6 +306,7 @@ __device__ __forceinline__ void f32_step(f2 x, float C, float hi, int i, FAcc &A
     }
     if constexpr (kErr || (kSum && M == 7)) {
         const f2 d = x - y;
+        if constexpr (kSd) A.sd += d;
         if constexpr (kSum && M == 7) A.sxy = __builtin_elementwise_fma(d, y, A.sxy);
         if constexpr (kErr) {
             if (M == 1 && i >= 4) { A.sad2 += __builtin_fabsf(d.x); A.sad2 += __builtin_fabsf(d.y); }
@@ -335,6 +337,7 @@ template <uint32_t SUMS, uint32_t ERRS, bool XS, typename Reload>
 __device__ __forceinline__ void fast_group_f32(const uint32_t w[8], GroupOut &G, Reload reload)
 {
     constexpr uint32_t ANY = SUMS | ERRS;
+    constexpr bool XSD = XS && (SUMS & 1u) != 0;                   // Σx from bfp8's Σy + Σδ instead of a float64 chain
     f2 x[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) { x[i].x = u2f(w[i] << 16); x[i].y = u2f(w[i] & 0xFFFF0000u); }
@@ -346,53 +349,56 @@ __device__ __forceinline__ void fast_group_f32(const uint32_t w[8], GroupOut &G,
     const float P = u2f((out_of_range ? 127u : E) << 23);          // finite constants whatever E is: a marked tile's numbers are never used
     const float c8 = P * FmtF<7>::kC, c4 = P * FmtF<3>::kC, c2 = P * FmtF<1>::kC;
     const float h8 = P * FmtF<7>::kHi, h4 = P * FmtF<3>::kHi, h2 = P;
-    const float thr = P * 0x1p-14f;                                // smallest main-class magnitude
+    const float thr = P * 0x1p-14f;                                // smallest main-class magnitude (formed again inside the tail branch)
 
     double sx = 0.0, sx2 = 0.0;
-    FAcc A8 = {{0.0f, 0.0f}, {0.0f, 0.0f}, {0.0f, 0.0f}, 0.0f, 0.0f, 0.0f}, A4 = A8, A2 = A8;
+    FAcc A8 = {{0.0f, 0.0f}, {0.0f, 0.0f}, {0.0f, 0.0f}, {0.0f, 0.0f}, 0.0f, 0.0f, 0.0f}, A4 = A8, A2 = A8;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         if constexpr (XS) {
             const double x0 = (double)x[i].x, x1 = (double)x[i].y;
-            sx += x0; sx2 = __builtin_fma(x0, x0, sx2);
-            sx += x1; sx2 = __builtin_fma(x1, x1, sx2);
+            if constexpr (!XSD) sx += x0;
+            sx2 = __builtin_fma(x0, x0, sx2);
+            if constexpr (!XSD) sx += x1;
+            sx2 = __builtin_fma(x1, x1, sx2);
         }
-        if constexpr (ANY & 1u) f32_step<7, (SUMS & 1u) != 0, (ERRS & 1u) != 0>(x[i], c8, h8, i, A8);
+        if constexpr (ANY & 1u) f32_step<7, (SUMS & 1u) != 0, (ERRS & 1u) != 0, XSD>(x[i], c8, h8, i, A8);
         if constexpr (ANY & 2u) f32_step<3, (SUMS & 2u) != 0, (ERRS & 2u) != 0>(x[i], c4, h4, i, A4);
         if constexpr (ANY & 4u) f32_step<1, (SUMS & 4u) != 0, (ERRS & 4u) != 0>(x[i], c2, h2, i, A2);
     }
 #pragma unroll
     for (int s = 0; s < kSums; ++s) G.term[s] = 0.0;
     G.mx[0] = G.mx[1] = G.mx[2] = 0.0f;
-    if constexpr (XS) { G.term[0] = sx; G.term[1] = sx2; }
+    if constexpr (XS) { G.term[0] = XSD ? (double)(A8.sy.x + A8.sy.y) + (double)(A8.sd.x + A8.sd.y) : sx; G.term[1] = sx2; }
     if constexpr (ANY & 1u) f32_terms<7, (SUMS & 1u) != 0, (ERRS & 1u) != 0>(A8, G.term + 2, G.mx[0]);
     if constexpr (ANY & 2u) f32_terms<3, (SUMS & 2u) != 0, (ERRS & 2u) != 0>(A4, G.term + 6, G.mx[1]);
     if constexpr (ANY & 4u) f32_terms<1, (SUMS & 4u) != 0, (ERRS & 4u) != 0>(A2, G.term + 10, G.mx[2]);
     // a NaN element: max3 / min3 pass it over, every sum it enters does not — probe one such sum per instantiation
     double probe = 0.0;
-    if constexpr (XS) probe = sx;
+    if constexpr (XS) probe = sx2;
     else if constexpr (ERRS != 0u) probe = G.term[(ERRS & 1u) ? 5 : ((ERRS & 2u) ? 9 : 13)];
     else probe = G.term[(SUMS & 1u) ? 4 : ((SUMS & 2u) ? 8 : 12)];
     G.bad = (out_of_range && !zero_group) || probe != probe;
 
-    // tail class present (a zero element alone also gets here — the loop then changes nothing but a sum's order of exact terms)
+    // tail class present (a zero element alone also gets here — the loop then changes nothing but the order of a sum of exact terms).
+    // A ROLLED loop over the group's words, read again from the LDS image one at a time, with the constants formed again from P: what the
+    // branch keeps alive beside the fast path's registers decides the kernel's occupancy (unrolled: 149 VGPRs for <3,1>, 126 without it).
     if (__builtin_expect(amin < thr && !zero_group && !out_of_range, 0)) {
         double mx_ = 0.0, mx2 = 0.0, tx = 0.0, tx2 = 0.0, tab = 0.0, m8 = 0.0, m4 = 0.0, m2 = 0.0;
-        uint32_t w2[8];
-        reload(w2);
-#pragma unroll
+#pragma nounroll
         for (int i = 0; i < 8; ++i) {
+            const uint32_t wi = reload(i);
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-                const float xv = h == 0 ? u2f(w2[i] << 16) : u2f(w2[i] & 0xFFFF0000u);
+                const float xv = h == 0 ? u2f(wi << 16) : u2f(wi & 0xFFFF0000u);
                 const double xd = (double)xv;
-                if (__builtin_fabsf(xv) < thr) {                   // tail (zeros included): y = 0 in every BFP format, |x − y| = |x|
+                if (__builtin_fabsf(xv) < P * 0x1p-14f) {          // tail (zeros included): y = 0 in every BFP format, |x − y| = |x|
                     tx += xd; tx2 = __builtin_fma(xd, xd, tx2); tab += __builtin_fabs(xd);
                 } else {
                     mx_ += xd; mx2 = __builtin_fma(xd, xd, mx2);
-                    if constexpr (ERRS & 1u) m8 += (double)__builtin_fabsf(xv - __builtin_amdgcn_fmed3f((xv + c8) - c8, -h8, h8));
-                    if constexpr (ERRS & 2u) m4 += (double)__builtin_fabsf(xv - __builtin_amdgcn_fmed3f((xv + c4) - c4, -h4, h4));
-                    if constexpr (ERRS & 4u) m2 += (double)__builtin_fabsf(xv - __builtin_amdgcn_fmed3f((xv + c2) - c2, -h2, h2));
+                    if constexpr (ERRS & 1u) m8 += (double)__builtin_fabsf(xv - __builtin_amdgcn_fmed3f((xv + P * FmtF<7>::kC) - P * FmtF<7>::kC, -(P * FmtF<7>::kHi), P * FmtF<7>::kHi));
+                    if constexpr (ERRS & 2u) m4 += (double)__builtin_fabsf(xv - __builtin_amdgcn_fmed3f((xv + P * FmtF<3>::kC) - P * FmtF<3>::kC, -(P * FmtF<3>::kHi), P * FmtF<3>::kHi));
+                    if constexpr (ERRS & 4u) m2 += (double)__builtin_fabsf(xv - __builtin_amdgcn_fmed3f((xv + P * FmtF<1>::kC) - P * FmtF<1>::kC, -P, P));
                 }
             }
         }
@@ -432,12 +438,14 @@ __host__ __device__ constexpr int rolled_waves(uint32_t sums, uint32_t errs)
 #elif defined(MTQ_K1_INTDOM)
     return (sums == 7u && errs == 7u) ? 3 : 4;
 #else
-    // float-domain form: the registers an instantiation wants without a cap (hipcc 7.2: <1,0> 95, <2,2> 126, <1,1> 142, <3,1> 149,
-    // <3,3> 172, <7,7> 203) decide; 8 KiB of LDS per wave allows 5
+    // float-domain form: the registers an instantiation wants without a cap (hipcc 7.2: <1,0> 89, <1,1> 101, <6,6> 127, <3,1> 130,
+    // <3,3> 143, <7,7> 174) decide; 8 KiB of LDS per wave allows 5
     const uint32_t any = sums | errs;
     const int n = (int)((any & 1u) + ((any >> 1) & 1u) + ((any >> 2) & 1u));
-    if (n == 3) return 2;
-    if (n == 2 || (errs & 1u)) return 3;
+    // <3,1> fits 128 registers (4 waves) — and then runs no faster alone (1.31 against 1.33 ms per 128 x 4096^2) and costs the streamed
+    // search 15 %: a search wave (176 registers, csrc/mtq_scan.hip) is placed where ONE retiring K1 wave leaves room beside three
+    // waves of <= 168, but needs two to retire at once beside four of 128 (bench: 1134 against 982 M tiles/s)
+    if (n >= 2) return 3;
     return errs == 0u ? 5 : 4;
 #endif
 }
@@ -602,13 +610,15 @@ __global__ __launch_bounds__(kFastWaves * 64, rolled_waves(SUMS, ERRS)) void til
             GroupOut G;
 #ifdef MTQ_K1_INTDOM
             fast_group<SUMS, ERRS, XS>(w, G, [&](uint32_t w2[8]) {
-#else
-            fast_group_f32<SUMS, ERRS, XS>(w, G, [&](uint32_t w2[8]) {
-#endif
                 const uint4 l2 = *reinterpret_cast<const uint4 *>(rowp + ((c0 ^ kl) << 4));
                 const uint4 h2 = *reinterpret_cast<const uint4 *>(rowp + ((c0 ^ (kl | 1u)) << 4));
                 w2[0] = l2.x; w2[1] = l2.y; w2[2] = l2.z; w2[3] = l2.w; w2[4] = h2.x; w2[5] = h2.y; w2[6] = h2.z; w2[7] = h2.w;
             });
+#else
+            fast_group_f32<SUMS, ERRS, XS>(w, G, [&](int i) -> uint32_t {   // word i of the group, from the LDS image
+                return *reinterpret_cast<const uint32_t *>(rowp + ((c0 ^ (kl | (uint32_t)(i >> 2))) << 4) + 4 * (i & 3));
+            });
+#endif
 #pragma unroll
             for (int s = 0; s < kSums; ++s)
                 if (term_needed(SUMS, ERRS, XS, s)) acc[s] = acc[s] + G.term[s];   // 0.0 + t = t exactly: sequential ((g0+g1)+g2)+g3

@@ -647,7 +647,8 @@ __device__ void scan_tensor(const ScanArgs &a, const Order &ord, int b, unsigned
     const int p_end = a.phase == 1 ? a.n_formats - 1 : a.n_formats;
     const OrdersHdr *hdr = reinterpret_cast<const OrdersHdr *>(a.orders);
     int n_sh = 0;
-    if (hdr && a.phase != 2 && hdr->tiles == (uint32_t)T && hdr->ok[0]) n_sh = (hdr->n_orders >= 2 && hdr->ok[1]) ? 2 : 1;
+    // … if they were drawn for this tensor's tile count AND seed (include/mtq.h asks the caller for that; a tensor whose seed differs shuffles for itself)
+    if (hdr && a.phase != 2 && hdr->tiles == (uint32_t)T && hdr->seed == (uint64_t)a.seeds[b] && hdr->ok[0]) n_sh = (hdr->n_orders >= 2 && hdr->ok[1]) ? 2 : 1;
     n_sh = min(n_sh, p_end - 1);
     const uint32_t *P1 = reinterpret_cast<const uint32_t *>(a.orders + sizeof(OrdersHdr)), *P2 = P1 + orders_stride(T);
 

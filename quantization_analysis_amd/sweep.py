@@ -16,7 +16,19 @@ from .compression_algorithms.tile_search import columns_from_stats, compute_tile
 from .compression_algorithms.tile_utils import MIXED_TILE_BYTES_PER_ELEM, MIXED_TILE_FORMATS, mixed_tile_total_bytes, tile_metrics
 
 
-LITERAL_CHUNK_TILES = 16384   # tiles per literal re-scoring chunk (64 MiB of float32 tiles on the host)
+LITERAL_CHUNK_TILES = 4096    # tiles per literal re-scoring chunk (16 MiB of x and 16 MiB of y tiles on the host per chunk in flight)
+
+
+def _literal_threads() -> int:
+    """Host threads for the literal re-scoring of one rank: the rank's share of the CPU budget (cgroup quota), MTQ_SWEEP_THREADS overrides."""
+    import os
+
+    from .pipeline import cpu_budget
+
+    if "MTQ_SWEEP_THREADS" in os.environ:
+        return max(1, int(os.environ["MTQ_SWEEP_THREADS"]))
+    local = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")))
+    return max(1, cpu_budget() // max(local, 1))
 
 
 def compute_assignment(scores_stack: np.ndarray, metric: str, threshold: float) -> np.ndarray:
@@ -52,10 +64,11 @@ def pareto_frontier(points: list[dict], metric: str) -> list[dict]:
 
 
 def _literal_scores(ts, ids: np.ndarray, fmt: str, quantizer: Quantizer, metric: str):
-    """(tile ids, their literal float32 scores under fmt) chunk by chunk (LITERAL_CHUNK_TILES tiles each: 128 MiB of x and y tiles on
-    the host).  With several chunks — identity-like formats put all 10^5 tiles of a large tensor inside the band — a few threads work on
-    different chunks: the score is NumPy reductions and BLAS dot products over a chunk's tiles, which run without the interpreter lock,
-    and a chunk's tiles come home while another chunk is scored.  Same calls per chunk, same bits."""
+    """(tile ids, their literal float32 scores under fmt) chunk by chunk (LITERAL_CHUNK_TILES tiles each).  With several chunks —
+    identity-like formats put all 10^5 tiles of a large tensor inside the band — the rank's CPU share of threads (_literal_threads) works
+    on different chunks: the score is NumPy reductions and BLAS dot products over a chunk's tiles, which run without the interpreter
+    lock, and a chunk's tiles come home (the tensor's own device made current in the worker: tile_search.literal_inputs) while other
+    chunks are scored.  Same calls per tile, same bits, whatever the chunking."""
     chunks = [ids[c0:c0 + LITERAL_CHUNK_TILES] for c0 in range(0, ids.size, LITERAL_CHUNK_TILES)]
 
     def one(part):
@@ -66,7 +79,7 @@ def _literal_scores(ts, ids: np.ndarray, fmt: str, quantizer: Quantizer, metric:
         return [one(c) for c in chunks]
     import concurrent.futures as cf
 
-    with cf.ThreadPoolExecutor(max_workers=min(4, len(chunks))) as pool:
+    with cf.ThreadPoolExecutor(max_workers=min(_literal_threads(), len(chunks))) as pool:
         return list(pool.map(one, chunks))
 
 

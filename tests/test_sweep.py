@@ -145,6 +145,24 @@ def test_sweep_hip_backend(golden_dir):
 
 
 @pytest.mark.gpu
+def test_sweep_threaded_literal_chunks_equal_one_chunk(monkeypatch):
+    """The literal re-scoring in many small chunks on pool threads (each worker makes the tensor's device current: a new thread starts
+    on device 0 with its own current stream) gives the rows of the single-chunk, single-thread run."""
+    import torch
+
+    from quantization_analysis_amd import sweep
+
+    x = torch.from_numpy(gen("normal_bf16", 7, (512, 768))).cuda().to(torch.bfloat16)
+    q = Quantizer("hip")
+    monkeypatch.setattr(sweep, "LITERAL_CHUNK_TILES", 1 << 20)
+    want = sweep.sweep_tensor(x, ALL, "pcc", 0.9, 12, q)
+    monkeypatch.setattr(sweep, "LITERAL_CHUNK_TILES", 16)
+    monkeypatch.setenv("MTQ_SWEEP_THREADS", "6")
+    got = sweep.sweep_tensor(x, ALL, "pcc", 0.9, 12, q)
+    assert got[0] == want[0] and got[1] == want[1] and np.array_equal(got[2], want[2])
+
+
+@pytest.mark.gpu
 def test_sweep_and_reconstruct_scripts_hip(tmp_path):
     """The two scripts with --backend hip produce the same CSV rows / reconstruction as with the host backend (counts,
     thresholds and sizes exactly; float columns to 1e-6)."""
