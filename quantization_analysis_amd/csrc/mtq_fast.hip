@@ -57,7 +57,6 @@ constexpr int kInBytes = kTile * kUnitCols * 2;      // 8192 B of bf16 per unit
 constexpr unsigned long long kRedoMagic = 0x7FF8C0DE5EED0001ull;
 constexpr int kSums = 14;                            // Σx, Σx², 3 × (Σy, Σy², Σxy, Σ|d|)
 constexpr int kScratchStride = 17;                   // 16 lanes + 1 pad (doubles)
-constexpr int kScratchDoubles = kUnitTiles * 7 * kScratchStride;        // one pass of 7 statistics: 476 doubles
 constexpr int kRecDoubles = kUnitTiles * (2 + 5 * kNumFmt);             // 4 records of up to 22 doubles
 
 // bijection on 4 bits with bit0 = bit2^bit3: makes the XOR swizzle conflict-free for the lane groups
@@ -142,8 +141,9 @@ __host__ __device__ constexpr int term_at(uint32_t sums, uint32_t errs, bool xs,
     }
     return 0;
 }
-// One reduce pass takes up to 13 statistics (4 tiles × n × 17 doubles of scratch + the record image inside the 8 KiB input image)
-constexpr int kOnePassMax = 13;
+// One reduce pass takes up to 6 statistics: 4 tiles × 6 × 17 doubles of scratch + the record image (704 B) inside HALF the input image
+constexpr int kPassMax = 6;
+constexpr int kHalfBytes = kInBytes / 2;             // the rows 2j of a unit (16 x 256 B) / the rows 2j+1
 
 template <uint32_t SUMS, uint32_t ERRS, bool XS, typename Reload>
 __device__ __forceinline__ void fast_group(const uint32_t w[8], GroupOut &G, Reload reload)
@@ -487,27 +487,35 @@ __global__ __launch_bounds__(kFastWaves * 64, rolled_waves(SUMS, ERRS)) void til
     // of them that only get Σy, Σy², Σxy.  Slots of the layout that are not written hold NaN afterwards (mtq_tile_stats_partial).
     // LISTED: nothing but the statistics the instantiation forms is written, each straight to its place in the tile's record.
     constexpr int nsum = terms_needed(SUMS, ERRS, XS);
-    constexpr bool one_pass = nsum <= kOnePassMax;
-    constexpr int scratch_doubles = one_pass ? kUnitTiles * nsum * kScratchStride : kScratchDoubles;
-    static_assert((scratch_doubles + kRecDoubles) * 8 <= kInBytes, "reduce scratch + record image must fit in the input image");
+    // the reduce runs in passes of at most kPassMax statistics: its scratch and the record image overlay ONE HALF of the input image
+    constexpr int npass = (nsum + kPassMax - 1) / kPassMax, per = (nsum + npass - 1) / npass;
+    constexpr int scratch_doubles = kUnitTiles * per * kScratchStride;
+    static_assert((scratch_doubles + kRecDoubles) * 8 <= kHalfBytes, "reduce scratch + record image must fit in half the input image");
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     unsigned char *in = lds + wave * kRolledWaveLds;
-    double *scratch = reinterpret_cast<double *>(in);                       // overlays the image after the reads
-    double *recbuf = scratch + scratch_doubles;
     const uint32_t in_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)in;
     const uint32_t t = lane >> 4, j = lane & 15;
 
+    // The image is two halves of 4 KiB: the unit's rows 2j (16 row segments of 256 B, what a lane's groups 0 and 1 read) in one, the rows
+    // 2j+1 (groups 2 and 3) in the other — and the halves swap roles from unit to unit (`par`), so that the NEXT unit's even rows are
+    // fetched into the half the odd rows have just been read out of, while the reduce of this unit still works in the other half:
+    //     ... g2 g3 | DMA(next even rows -> B) | reduce in A, records out | DMA(next odd rows -> A) | next unit: g0 g1 read B ...
+    // The rows a unit needs first have then been under way since before the previous unit's reduce, the others since its end with two
+    // groups' arithmetic still ahead of them (round 3 issued all eight pieces at the end: a quarter of a wave's cycles went to waiting
+    // for them, SQ_WAIT_ANY).  Piece i (1 KiB, one LDS-DMA instruction): even (i < 4) or odd (i >= 4) rows 8(i&3) + 2*rho + (i>>2),
+    // rho = lane >> 4, at row slot 4(i&3) + rho of its half; chunk XOR-swizzled by the slot (= the j that reads it), as before.
     uint32_t dma_off[8], dma_tile[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const uint32_t rho = lane >> 4;
-        const uint32_t c = (lane & 15u) ^ swz(2u * i + (rho >> 1));
-        dma_off[i] = LISTED ? (uint32_t)((4 * i + rho) * ld * 2) + (c & 3u) * 16u : (uint32_t)((4 * i + rho) * ld * 2) + c * 16u;
+        const uint32_t c = (lane & 15u) ^ swz(4u * (i & 3) + rho);
+        const uint32_t row = 8u * (i & 3) + 2u * rho + (uint32_t)(i >> 2);
+        dma_off[i] = LISTED ? (uint32_t)(row * ld * 2) + (c & 3u) * 16u : (uint32_t)(row * ld * 2) + c * 16u;
         dma_tile[i] = c >> 2;                                                 // which of the unit's four tiles this lane's chunk belongs to
     }
-    const uint32_t rd_base = (j >> 1) * 1024u + (2u * (j & 1u)) * 256u;
+    const uint32_t rd_row = j * 256u;                                         // row slot j of either half
     const uint32_t c0 = (4u * t) ^ swz(j);                                    // chunk (4t+kl)^swz(j) = c0 ^ kl
 
     // Units are claimed from a device counter (zero at launch, reset by the follow-up kernel) rather than by a fixed
@@ -524,7 +532,14 @@ __global__ __launch_bounds__(kFastWaves * 64, rolled_waves(SUMS, ERRS)) void til
         total_units = (int)((n_listed + 3u) >> 2);
     }
     int stride_next = (int)(blockIdx.x * kFastWaves) + wave;                  // listed form: this wave's next unit
-    auto claim = [&]() -> int {
+    // A claim is two steps: the atomic is ISSUED at the top of a unit and its value READ after the unit's groups.  Through the
+    // compiler's atomic the value cannot stay in flight: its wait-count pass puts `s_waitcnt vmcnt(0)` behind the atomic (the atomic
+    // optimizer broadcasts the value at once) or, with the optimizer off, at the top of the next unit (the destination register is
+    // written again there) — a device-atomic round trip at the head of every unit in round 3, and with it a wait for every piece of
+    // the image.  So the in-loop claim is inline assembly the compiler's counters do not see: lane 0 alone issues it (EXEC narrowed
+    // and restored inside the statement), nothing reads `v` before claim_value's own statement, which waits first; volatile asm
+    // statements keep their order, the kernel has no scratch (checked in the build's resource report: a spill of `v` would read it early).
+    auto claim_first = [&]() -> int {
         if constexpr (LISTED) {
             const int u = stride_next;
             stride_next += (int)gridDim.x * kFastWaves;
@@ -535,6 +550,24 @@ __global__ __launch_bounds__(kFastWaves * 64, rolled_waves(SUMS, ERRS)) void til
             const unsigned k = (unsigned)__builtin_amdgcn_readfirstlane(v);
             return k < 0x01000000u ? group + (int)k * groups : 0x7FFFFFFF;
         }
+    };
+    auto claim_issue = [&]() -> unsigned {
+        unsigned v;
+        if constexpr (LISTED) {
+            v = (unsigned)stride_next;
+            stride_next += (int)gridDim.x * kFastWaves;
+        } else {
+            unsigned long long saved;
+            asm volatile("s_mov_b64 %1, exec\n\ts_mov_b64 exec, 1\n\tglobal_atomic_add %0, %2, %3, %4 sc0\n\ts_mov_b64 exec, %1"
+                         : "=&v"(v), "=&s"(saved) : "v"(0u), "v"(1u), "s"(queue) : "memory");
+        }
+        return v;
+    };
+    auto claim_value = [&](unsigned v) -> int {
+        if constexpr (LISTED) return (int)v;
+        unsigned k;
+        asm volatile("s_waitcnt vmcnt(0)\n\tv_readfirstlane_b32 %0, %1\n\ts_nop 4" : "=s"(k) : "v"(v) : "memory");
+        return k < 0x01000000u ? group + (int)k * groups : 0x7FFFFFFF;
     };
     const int o_bf16 = 2, o8 = 2 + 5 * __builtin_popcount(fmt_mask & 1u), o4 = 2 + 5 * __builtin_popcount(fmt_mask & 3u),
               o2 = 2 + 5 * __builtin_popcount(fmt_mask & 7u);
@@ -548,7 +581,8 @@ __global__ __launch_bounds__(kFastWaves * 64, rolled_waves(SUMS, ERRS)) void til
     };
     // listed form: the global tile this lane's 16-lane group serves in unit u (a short last unit repeats the list's last tile)
     auto listed_tile = [&](int u, uint32_t q) -> uint32_t { return la.list[min((uint32_t)u * 4u + q, n_listed - 1u)]; };
-    auto issue_dma = [&](int u) {
+    // the four pieces of unit u's even (odd = 0) or odd (odd = 1) rows into the half at LDS address `half`
+    auto issue_rows = [&](int u, int odd, uint32_t half) {
         if constexpr (LISTED) {
             // lane q < 4 works out where tile q of the unit starts; every lane then picks the start of the tile its chunk belongs to
             const uint32_t gt = listed_tile(u, (uint32_t)lane & 3u);
@@ -556,17 +590,18 @@ __global__ __launch_bounds__(kFastWaves * 64, rolled_waves(SUMS, ERRS)) void til
             const uint32_t tr = tt / la.tiles_w32, tc = tt - tr * la.tiles_w32;
             const unsigned long long mine = (unsigned long long)(uintptr_t)(x + (int64_t)b * stride + ((int64_t)tr * kTile) * ld + (int64_t)tc * kTile);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const unsigned lo = (unsigned)__shfl((int)(unsigned)mine, (int)dma_tile[i], 64), hi = (unsigned)__shfl((int)(unsigned)(mine >> 32), (int)dma_tile[i], 64);
-                const unsigned long long src = (((unsigned long long)hi << 32) | lo) + dma_off[i];
-                glds16v(reinterpret_cast<const void *>((uintptr_t)src), in_addr + i * 1024);
+            for (int i = 0; i < 4; ++i) {
+                const uint32_t tl = odd ? dma_tile[4 + i] : dma_tile[i], off = odd ? dma_off[4 + i] : dma_off[i];
+                const unsigned lo = (unsigned)__shfl((int)(unsigned)mine, (int)tl, 64), hi = (unsigned)__shfl((int)(unsigned)(mine >> 32), (int)tl, 64);
+                const unsigned long long src = (((unsigned long long)hi << 32) | lo) + off;
+                glds16v(reinterpret_cast<const void *>((uintptr_t)src), half + i * 1024);
             }
         } else {
             int b, tr, uc;
             unit_base(u, b, tr, uc);
             const unsigned char *base = reinterpret_cast<const unsigned char *>(x + (int64_t)b * stride + ((int64_t)tr * kTile) * ld + (int64_t)uc * kUnitCols);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) glds16(base, dma_off[i], in_addr + i * 1024);
+            for (int i = 0; i < 4; ++i) glds16(base, odd ? dma_off[4 + i] : dma_off[i], half + i * 1024);
         }
     };
     // lane j of a tile's 16 lanes reduces one statistic and puts it where the record wants it (place_stat: everything by value — as a
@@ -587,12 +622,19 @@ __global__ __launch_bounds__(kFastWaves * 64, rolled_waves(SUMS, ERRS)) void til
     // are resident at once and slots keep opening up, so that the one-wave-per-tensor scan kernels of earlier chunks
     // (csrc/mtq_scan.hip, other streams) are placed within a block's lifetime instead of waiting for the whole launch to drain.
     int left = units_per_wave > 0 ? units_per_wave : 0x7FFFFFFF;
-    int u = claim();
+    int u = claim_first();
     --left;
-    if (u < total_units) issue_dma(u);
+    uint32_t par = 0u;                                                        // the half the current unit's even rows are in
+    if (u < total_units) { issue_rows(u, 0, in_addr); issue_rows(u, 1, in_addr + kHalfBytes); }
     while (u < total_units) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                     // image landed (and the previous records retired)
-        const int u_next = left > 0 ? claim() : 0x7FFFFFFF;                   // its latency hides behind this unit's arithmetic
+        unsigned char *half_a = in + par * kHalfBytes, *half_b = in + (par ^ 1u) * kHalfBytes;
+        double *scratch = reinterpret_cast<double *>(half_a);                  // overlays the even rows after groups 0 and 1 have read them
+        double *recbuf = scratch + scratch_doubles;
+        // everything but the wave's four youngest vector-memory operations is done: the even rows landed (and the previous records retired);
+        // the four youngest are the odd rows' pieces — the last thing a unit issues
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        const bool more = left > 0;
+        const unsigned claimed = more ? claim_issue() : 0u;                   // in flight behind this unit's arithmetic
         --left;
 
         double acc[kSums];
@@ -602,8 +644,9 @@ __global__ __launch_bounds__(kFastWaves * 64, rolled_waves(SUMS, ERRS)) void til
         bool bad = false;
 #pragma nounroll
         for (int g = 0; g < 4; ++g) {                                         // rows 2j (g = 0,1) then 2j+1 (g = 2,3)
+            if (g == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the odd rows landed (and this unit's claim returned)
             const uint32_t kl = 2u * (g & 1);
-            const unsigned char *rowp = in + rd_base + (g >> 1) * 256u;
+            const unsigned char *rowp = (g < 2 ? half_a : half_b) + rd_row;
             const uint4 lo = *reinterpret_cast<const uint4 *>(rowp + ((c0 ^ kl) << 4));
             const uint4 hi = *reinterpret_cast<const uint4 *>(rowp + ((c0 ^ (kl | 1u)) << 4));
             const uint32_t w[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
@@ -634,7 +677,25 @@ __global__ __launch_bounds__(kFastWaves * 64, rolled_waves(SUMS, ERRS)) void til
         }
         const unsigned long long bad_lanes = __ballot(bad);
         const bool tile_bad = ((bad_lanes >> (16 * t)) & 0xFFFFull) != 0ull;
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                   // every lane's image reads are done: overlay may begin
+        const int u_next = more ? claim_value(claimed) : 0x7FFFFFFF;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                   // every lane's image reads are done: both halves are free
+        if (u_next < total_units) issue_rows(u_next, 0, in_addr + (par ^ 1u) * kHalfBytes);   // EARLY: the next unit's even rows, into the half the odd rows were in
+
+        // the reduce, `per` statistics at a time: lane j < per of a tile's 16 adds the 16 row pairs' partials of one statistic by the balanced tree
+        auto reduce_pass = [&](int pass, auto &&sink) {
+#pragma unroll
+            for (int i = 0; i < per; ++i)
+                if (pass * per + i < nsum) scratch[(t * per + i) * kScratchStride + j] = acc[term_at(SUMS, ERRS, XS, pass * per + i)];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if ((int)j < per && pass * per + (int)j < nsum) {
+                const double r = tree16(scratch + (t * per + j) * kScratchStride);
+                int sidx = 0;
+#pragma unroll
+                for (int i = 0; i < per; ++i) sidx = (int)j == i ? term_at(SUMS, ERRS, XS, min(pass * per + i, nsum - 1)) : sidx;
+                sink(sidx, r);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // the scratch is consumed (next pass / the records / the refill)
+        };
 
         if constexpr (LISTED) {
             // every statistic straight to its place in the tile's own record; a tile of the list's padding (a short last unit) writes nothing
@@ -642,24 +703,17 @@ __global__ __launch_bounds__(kFastWaves * 64, rolled_waves(SUMS, ERRS)) void til
             const uint32_t gt = listed_tile(u, t);
             double *rec_g = stats + (int64_t)gt * rec;
 #pragma unroll
-            for (int i = 0; i < nsum; ++i) scratch[(t * nsum + i) * kScratchStride + j] = acc[term_at(SUMS, ERRS, XS, i)];
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if ((int)j < nsum && real && !tile_bad) {
-                const double r = tree16(scratch + (t * nsum + j) * kScratchStride);
-                int sidx = 0;
-#pragma unroll
-                for (int i = 0; i < nsum; ++i) sidx = (int)j == i ? term_at(SUMS, ERRS, XS, i) : sidx;
-                place_stat(pa, rec_g, sidx, r);
-            }
+            for (int pass = 0; pass < npass; ++pass)
+                reduce_pass(pass, [&](int sidx, double r) { if (real && !tile_bad) place_stat(pa, rec_g, sidx, r); });
             if (j == 15 && real && !tile_bad) {
                 if (ERRS & 1u) rec_g[o8 + 4] = (double)mx[0];
                 if (ERRS & 2u) rec_g[o4 + 4] = (double)mx[1];
                 if (ERRS & 4u) rec_g[o2 + 4] = (double)mx[2];
             }
             if (j == 0 && real && tile_bad) la.redo[atomicAdd(la.n_redo, 1u)] = gt;   // the direct listed kernel takes it (literal route)
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // the scratch is consumed: the image may be refilled
-            if (u_next < total_units) issue_dma(u_next);
+            if (u_next < total_units) issue_rows(u_next, 1, in_addr + par * kHalfBytes);   // LATE: the next unit's odd rows — the unit's last vector-memory operations
             u = u_next;
+            par ^= 1u;
             continue;
         }
 
@@ -671,28 +725,8 @@ __global__ __launch_bounds__(kFastWaves * 64, rolled_waves(SUMS, ERRS)) void til
             if (lane + 64 < nrec) recbuf[lane + 64] = poison;
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
-        if constexpr (one_pass) {
 #pragma unroll
-            for (int i = 0; i < nsum; ++i) scratch[(t * nsum + i) * kScratchStride + j] = acc[term_at(SUMS, ERRS, XS, i)];
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if ((int)j < nsum) {
-                const double r = tree16(scratch + (t * nsum + j) * kScratchStride);
-                int sidx = 0;
-#pragma unroll
-                for (int i = 0; i < nsum; ++i) sidx = (int)j == i ? term_at(SUMS, ERRS, XS, i) : sidx;
-                place_stat(pa, rec_t, sidx, r);
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        } else {
-#pragma unroll
-            for (int pass = 0; pass < 2; ++pass) {
-#pragma unroll
-                for (int s = 0; s < 7; ++s) scratch[(t * 7 + s) * kScratchStride + j] = acc[7 * pass + s];
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                if (j < 7) place_stat(pa, rec_t, 7 * pass + (int)j, tree16(scratch + (t * 7 + j) * kScratchStride));
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            }
-        }
+        for (int pass = 0; pass < npass; ++pass) reduce_pass(pass, [&](int sidx, double r) { place_stat(pa, rec_t, sidx, r); });
         if (j == 15) {
             if ((ERRS & 1u) && (eval_mask & ~part_mask & 2u)) rec_t[o8 + 4] = (double)mx[0];
             if ((ERRS & 2u) && (eval_mask & ~part_mask & 4u)) rec_t[o4 + 4] = (double)mx[1];
@@ -712,11 +746,12 @@ __global__ __launch_bounds__(kFastWaves * 64, rolled_waves(SUMS, ERRS)) void til
         double r0 = 0.0, r1 = 0.0;
         if (lane < nrec) r0 = recbuf[lane];
         if (lane + 64 < nrec) r1 = recbuf[lane + 64];
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                   // records are in registers: the image may be refilled
-        if (u_next < total_units) issue_dma(u_next);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                   // records are in registers: this half may be refilled
         if (lane < nrec) out[lane] = r0;
         if (lane + 64 < nrec) out[lane + 64] = r1;
+        if (u_next < total_units) issue_rows(u_next, 1, in_addr + par * kHalfBytes);   // LATE: the next unit's odd rows — the unit's last vector-memory operations
         u = u_next;
+        par ^= 1u;
     }
     if constexpr (!LISTED) {
         // The launch resets its own unit counters: every wave of the grid ends here once, and the one that completes the count knows that
