@@ -301,27 +301,44 @@ def deepseek_tensors(device):
 def leg_threshold(device) -> dict:
     """configs[2]: mixed-tile-threshold over the seven DeepSeek-R1 model.layers.0.self_attn tensors (five float32 matrices after the
     fp8 x scale dequantisation, two bf16 vectors) — K1 (tile_stats_direct for float32 storage) + K4 on the device + the knife-edge
-    re-score, through the streamed ThresholdPipeline (matrices) and the plug-in call (vectors)."""
+    re-score, all seven through ThresholdPipeline.run_batches (vectors as (n/32, 32) matrices with their element count)."""
+    import numpy as np
+
     from quantization_analysis_amd import hip_backend as hb
-    from quantization_analysis_amd.compression_algorithms import create_algorithm
-    from quantization_analysis_amd.compression_algorithms.quantizer import Quantizer
     from quantization_analysis_amd.pipeline import ThresholdPipeline
 
     names, xs = deepseek_tensors(device)
-    q = Quantizer("hip")
-    algo = create_algorithm("mixed-tile-threshold", {"metric": "pcc", "threshold": THRESHOLD, "materialize_y": False})
     mats = [x for x in xs if x.dim() == 2]
     vecs = [x for x in xs if x.dim() != 2]
     tiles = sum(-(-x.shape[0] // 32) * -(-x.shape[1] // 32) for x in mats) + sum(-(-x.numel() // 1024) for x in vecs)
+    def as_batch(x):   # a 1-D tensor is the (ceil(n/32), 32) matrix of tile_utils.py:96-102 with its own element count
+        if x.dim() == 2:
+            return (x[None], None)
+        n = x.numel()
+        rows = -(-n // 32)
+        m = torch.zeros((rows * 32,), dtype=x.dtype, device=x.device)
+        m[:n] = x
+        return (m.view(1, rows, 32), n)
+
+    batches = [as_batch(x) for x in xs]
     with ThresholdPipeline(FORMATS, "pcc", THRESHOLD, chunk=1) as pipe:
+        last = []
+
         def once():
-            for x in mats:
-                pipe.run(x[None])
-            for v in vecs:
-                algo.run(v, FORMATS, q, None)
+            last[:] = pipe.run_batches(batches)   # every tensor's K1 / K4 / knife listing enqueued first, decisions and column sums behind them
 
         ms_, _ = timed(once, reps=5)
         knife = pipe.knife_tiles // 6
+    # parity on the leg's own inputs: one matrix and one vector against the oracle (maps bit for bit; columns from the same records' sums)
+    from oracle import mtq_oracle as orc
+
+    checked = []
+    for i in (min(range(len(xs)), key=lambda k: xs[k].numel() if xs[k].dim() == 2 else 1 << 62), next(k for k, x in enumerate(xs) if x.dim() != 2)):
+        a, c = orc.threshold(xs[i].float().cpu().numpy(), FORMATS, "pcc", THRESHOLD)[:2]
+        r = last[i][0]
+        if not np.array_equal(r.assignment, a) or any(int(r.counts[f]) != int(c[f]) for f in c):
+            raise SystemExit(f"bench: threshold leg, tensor {names[i]}: the GPU's map differs from the oracle's")
+        checked.append(names[i])
     # the float32 K1 alone on the matrices (HIP events): its share of the 4096 B/tile read roofline
     f32 = [x for x in mats if x.dtype == torch.float32]
     f32_tiles = sum(-(-x.shape[0] // 32) * -(-x.shape[1] // 32) for x in f32)
@@ -339,6 +356,7 @@ def leg_threshold(device) -> dict:
     k1 = median(ts)
     return {"workload": f"DeepSeek-R1 model.layers.0.self_attn, {len(xs)} tensors ({len(mats)} matrices, {len(vecs)} vectors), mixed-tile-threshold pcc>=0.999 (BASELINE.json configs[2])",
             "value": tiles / (ms_ * 1e-3), "unit": "tiles/s", "ms": ms_, "tiles": tiles, "knife_edge_tiles": knife,
+            "maps_equal_oracle": checked,
             "roofline": {"bound": "hbm", "kernel": "tile_stats_direct<float, 15> (K1, float32 storage)", "achieved": 4096 * f32_tiles / (k1 * 1e-3) / 1e9,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": 4096 * f32_tiles / (k1 * 1e-3) / 1e9 / HBM_PEAK_GBS, "launch_ms": k1, "tiles": f32_tiles,
                          "traffic": None, "note": "4096 B read per float32 tile; the five matrices back to back, HIP events"}}
@@ -386,7 +404,17 @@ def leg_llama(device) -> dict:
         res = pipe.run_batches(xs)
         fallbacks = pipe.host_fallbacks
     counts = [sum(r.counts[f] for rs in res for r in rs) for f in FORMATS]
-    return {"workload": "Llama-3-8B model.layers.* linear weights, 224 bf16 tensors (6.8 M tiles, 14 GB), mixed-tile-greedy pcc>=0.999 seed 123 (BASELINE.json configs[3]) on ONE GPU",
+    # parity on the leg's own inputs: the first tensor of the smallest shape group (k_proj, 1024 x 4096) against the oracle's greedy search
+    import numpy as np
+
+    from oracle import mtq_oracle as orc
+
+    bi = min(range(len(xs)), key=lambda k: xs[k].shape[1] * xs[k].shape[2])
+    a, c, _st = orc.greedy(xs[bi][0].float().cpu().numpy(), FORMATS, METRIC, THRESHOLD, SEED)
+    r0 = res[bi][0]
+    if not np.array_equal(r0.assignment, a) or any(int(r0.counts[f]) != int(c[f]) for f in c):
+        raise SystemExit(f"bench: llama leg, tensor {names[batches[bi][0][0]]}: the GPU's map differs from the oracle's")
+    return {"maps_equal_oracle": [names[batches[bi][0][0]]], "workload": "Llama-3-8B model.layers.* linear weights, 224 bf16 tensors (6.8 M tiles, 14 GB), mixed-tile-greedy pcc>=0.999 seed 123 (BASELINE.json configs[3]) on ONE GPU",
             "value": tiles / (ms_ * 1e-3), "unit": "tiles/s", "pipeline_ms": ms_, "pipeline_ms_all": all_ms, "tiles": tiles, "tensors": len(mine), "batches": len(xs),
             "loader_seconds": load_s, "loader": "synthetic tensors drawn on the device, one seeded generator call per tensor",
             "k1_tiles_per_s": k1_tiles / max(k1_ms, 1e-9) * 1e3, "host_fallbacks": fallbacks, "counts_bf16_bfp8_bfp4_bfp2": counts}
@@ -572,6 +600,8 @@ def run_llama_workload(args, dist, rank, world, device, barrier, numa) -> None:
 
 
 def run_m1_workload(args, dist, rank, world, device, barrier, numa) -> None:
+    import numpy as np
+
     from quantization_analysis_amd.pipeline import GreedyPipeline
 
     batch = make_batch(args.tensors, rank, device)
@@ -624,7 +654,7 @@ def run_m1_workload(args, dist, rank, world, device, barrier, numa) -> None:
     # the only data-path collective: per-tensor summary rows to rank 0; outside the timed steps
     # the rows of the LAST step are gathered so the multi-GPU path is exercised end to end.
     rows = torch.tensor([[r.index, ROWS * COLS, r.pcc, r.mae, r.atol, r.tile_bytes, r.counts["bf16"], r.counts["bfp8"],
-                          r.counts["bfp4"], r.counts["bfp2"], 0.0] for r in res], dtype=torch.float64, device=device)
+                          r.counts["bfp4"], r.counts["bfp2"], float(rank)] for r in res], dtype=torch.float64, device=device)   # last column: the rank that searched the tensor
     all_rows, dt = gather_summary(rows, regions[mid], dist, rank, world)
     if dist is not None:   # every region's MAX over ranks, for the record
         rt = torch.tensor(regions, dtype=torch.float64, device=device)
@@ -659,6 +689,8 @@ def run_m1_workload(args, dist, rank, world, device, barrier, numa) -> None:
                        "route": ("lazy: K1 evaluates bfp8 (five statistics) and bfp4 (three sums); the search stops before its last pass, the listed kernel evaluates bfp2 and "
                                  "bfp4's error statistics for that pass's candidates, the last pass follows (DESIGN.md §4)") if lazy else "whole records",
                        "listed_tiles_per_step": pipe.listed_tiles / max(total_steps + args.warmup, 1), "shared_visiting_orders": bool(pipe.shared_orders and pipe.device_scan),
+                       "ranks_seen_by_the_collective": int(dist.get_world_size()) if dist is not None else 1,
+                       "per_rank_tiles_per_step": [int(v) for v in np.bincount(all_rows[:, 10].astype(np.int64), minlength=world) * (ROWS // 32) * (COLS // 32)],
                        "host_cpu_ms_per_step": host_cpu_ms, "host_fallbacks": pipe.host_fallbacks,
                        "driver_thread_ms_per_step": {k: v / (total_steps + args.warmup) * 1e3 for k, v in pipe.host_seconds.items()}, "scan_workers": args.workers, "numa_bind": numa, "sharding": f"tensors x{world}, RCCL gather of summary rows"},
             "roofline": {"bound": "hbm", "kernel": "tile_stats (K1)" + (": tile_stats_bf16_rolled<3, 1> (partial records)" if lazy else ""), "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -181,7 +181,21 @@ def gather_tiles(ts: TileStats, tile_ids: np.ndarray) -> np.ndarray:
     return out
 
 
-def literal_inputs(ts: TileStats, tile_ids: np.ndarray, fmt: str, quantizer) -> tuple[np.ndarray, np.ndarray, np.ndarray]:
+_PINNED = {}   # thread id -> flat pinned float32 staging buffer of literal_inputs(pinned=True); grows, never shrinks
+
+
+def _pinned_f32(torch, numel: int):
+    import threading
+
+    key = threading.get_ident()
+    buf = _PINNED.get(key)
+    if buf is None or buf.numel() < numel:
+        buf = torch.empty((int(numel * 1.25) + 1024,), dtype=torch.float32, pin_memory=True)
+        _PINNED[key] = buf
+    return buf[:numel]
+
+
+def literal_inputs(ts: TileStats, tile_ids: np.ndarray, fmt: str, quantizer, pinned: bool = False) -> tuple[np.ndarray, np.ndarray, np.ndarray]:
     """(x tiles, y tiles, ids) of the named tiles as zero-padded (k,32,32) float32 host arrays, `ids` naming the tile of every row
     (a permutation of tile_ids): what the reference's literal float32 tile score takes (tile_utils.py:46-57 on y = Quantizer.quantize
     of the tiles).  On the hip backend both come from one device call (mtq_knife_tiles_device: the tiles fetched and quantised where the
@@ -202,6 +216,15 @@ def literal_inputs(ts: TileStats, tile_ids: np.ndarray, fmt: str, quantizer) -> 
             lst = torch.empty((k + 1,), dtype=torch.int64, device=dev)
             out = torch.empty((2, k, TILE, TILE), dtype=torch.float32, device=dev)
             hb.knife_tiles_device(ts.x2d[None], flags, [fmt], k, lst, out)
+            if pinned:
+                # the calling thread's own pinned staging buffer (a pageable .cpu() of the sweep's 1.5 GB of tiles ran at a sixth of the link's
+                # rate: 190 of the leg's 280 ms); the arrays alias it: valid until this thread's next call
+                stage = _pinned_f32(torch, out.numel()).view(out.shape)
+                stage.copy_(out, non_blocking=True)
+                ids_home = lst[:k].cpu().numpy()        # synchronises the stream behind the staged copy
+                torch.cuda.current_stream().synchronize()
+                host = stage.numpy()
+                return host[0], host[1], ids_home
             host = out.cpu().numpy()
             return host[0], host[1], lst[:k].cpu().numpy()
     xt = gather_tiles(ts, ids)

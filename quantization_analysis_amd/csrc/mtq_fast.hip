@@ -864,7 +864,8 @@ extern "C" int mtq_launch_tile_stats_bf16_listed(const void *x, int64_t count, i
     const int64_t need = (((int64_t)cap + 3) / 4 + kFastWaves - 1) / kFastWaves;
     static int lw = -1;                                  // MTQ_LISTED_WAVES: waves per SIMD the listed grid is sized for
     if (lw < 0) { const char *e = getenv("MTQ_LISTED_WAVES"); lw = e ? atoi(e) : 0; }
-    const int64_t max_blocks = (int64_t)cus * (lw > 0 ? lw : rolled_waves(sums, errs)) * 4 / kFastWaves;
+    // 4 waves per SIMD (the listed instantiations take 112–116 registers): the launch waits on 64-byte row segments, not on the issue port — 0.280 against 0.314 ms at 3
+    const int64_t max_blocks = (int64_t)cus * (lw > 0 ? lw : 4) * 4 / kFastWaves;
     const dim3 grid((unsigned)(need < max_blocks ? need : max_blocks)), block(kFastWaves * 64);
     const size_t lds_bytes = kFastWaves * kRolledWaveLds;
     hipStream_t st = static_cast<hipStream_t>(stream);

@@ -161,6 +161,9 @@ class ShardEvaluator:
                 if greedy and getattr(pipe, "device_scan", False):
                     pipe.chunk = 1 << 30                  # one K1 launch and one scan launch (a wave per tensor) per batch
                     all_results = pipe.run_batches([x for x, _m in loaded])
+                elif hasattr(pipe, "run_batches"):          # threshold: every batch of the window enqueued first, decisions and column sums behind
+                    pipe.chunk = 1 << 30                  # one K1 launch per batch
+                    all_results = pipe.run_batches([x for x, _m in loaded])
                 else:
                     all_results = []
                     for (key, part, tiles), (x3d, _m) in zip(window, loaded):

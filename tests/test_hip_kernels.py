@@ -495,6 +495,39 @@ def test_threshold_pipeline_matches_oracle():
         assert pipe.knife_tiles >= 1
 
 
+@pytest.mark.gpu
+def test_threshold_run_batches_equals_run():
+    """ThresholdPipeline.run_batches over batches of different shapes and storage types, a vector as a (n/32, 32) matrix with its element
+    count among them, with a threshold ON a tile's float32 score (knife-edge tiles in flight while later batches are enqueued): per batch the
+    results of run(), and the oracle's maps."""
+    import torch
+
+    from quantization_analysis_amd.pipeline import ThresholdPipeline
+
+    v = gen("normal_bf16", 77, (1000,))
+    vm = np.zeros((32 * 32,), dtype=np.float32)
+    vm[:1000] = v
+    mats = [np.stack([gen("normal_bf16", 70 + i, (128, 256)) for i in range(3)]), np.stack([gen("heavy_f32", 80 + i, (96, 160)) for i in range(2)]),
+            np.stack([gen("normal_bf16", 90, (100, 72))])]
+    s4 = orc.threshold_scores(mats[0][0], ALL, "pcc")["bfp4"]
+    for thr in (0.99, float(np.sort(s4)[len(s4) // 2])):
+        batches = [(dev(mats[0], bf16=True), None), (dev(mats[1], bf16=False), None), (dev(mats[2], bf16=True), None),
+                   (torch.from_numpy(vm).cuda().to(torch.bfloat16).view(1, 32, 32), 1000)]
+        with ThresholdPipeline(ALL, "pcc", thr, chunk=2) as pipe:
+            got = pipe.run_batches(batches)
+            want = [pipe.run(x, n) for x, n in batches]
+        for g, w in zip(got, want):
+            assert len(g) == len(w)
+            for r1, r2 in zip(g, w):
+                assert np.array_equal(r1.assignment, r2.assignment) and r1.counts == r2.counts and (r1.pcc, r1.mae, r1.atol) == (r2.pcc, r2.mae, r2.atol)
+        for b, m in enumerate(mats):
+            for i in range(m.shape[0]):
+                a, counts, _sc = orc.threshold(m[i], ALL, "pcc", thr)
+                assert np.array_equal(got[b][i].assignment, a) and got[b][i].counts == counts, (thr, b, i)
+        a, counts, _sc = orc.threshold(v, ALL, "pcc", thr)
+        assert np.array_equal(got[3][0].assignment, a) and got[3][0].counts == counts
+
+
 @pytest.mark.parametrize("scan", ["device", "host"])
 def test_streamed_pipeline_matches_oracle(scan):
     """GreedyPipeline (what bench.py times), with the scan on the device (csrc/mtq_scan.hip: maps come back, records stay) and
