@@ -234,21 +234,6 @@ int mtq_greedy_run_batch(const double *stats, int64_t count, int64_t tiles, uint
  */
 int mtq_tile_scores(const double *stats, int64_t tiles, uint32_t fmt_mask, int metric, double *scores);
 
-/*
- * The greedy search on CHAIN records — pcc metric, distinct formats f0, f1, … (2..4 of them).  Every visit of pass p >= 1
- * moves a tile from f(p-1) to f(p): a tile still in the running accepted every earlier pass.  So the scan reads, per visit,
- * only the difference of two consecutive formats' sums: chain[t] = [dy_1, dy2_1, dxy_1, dy_2, ...] with
- * d_p = (Σy, Σy², Σxy)(f_p) − (Σy, Σy², Σxy)(f_(p-1)), 3(F−1) doubles — the subtraction mixed_tile_greedy.py:259-261 performs,
- * done by mtq_pack_chain_records on the device.  The running sums start from the all-f0 sums accumulated in tile order
- * (:147-174) from the side array base[t] = [Σx, Σx²] (base_doubles 2: f0 is the identity bf16) or [Σx, Σx², Σy, Σy², Σxy](f0)
- * (base_doubles 5).  One 24-byte read per visit instead of two record slots; same operations in the same order as
- * mtq_greedy_run: same map, same counts.  MTQ_ERR_UNSUPPORTED for a zero-variance tensor (needs Σ|x−y|).
- */
-int mtq_greedy_run_chain(const double *chain, const double *base, int base_doubles, int64_t tiles, const int *formats, int n_formats,
-                         double threshold, double elem_count, uint64_t seed, int8_t *map, int64_t counts[4]);
-int mtq_greedy_run_chain_batch(const double *chain, const double *base, int base_doubles, int64_t count, int64_t tiles,
-                               const int *formats, int n_formats, double threshold, double elem_count, const uint64_t *seeds,
-                               int8_t *maps, int64_t *counts, int n_threads);
 
 /*
  * K4 threshold_assign — mixed_tile_threshold.py:111-123 / scripts/sweep_mixed_tile_threshold.py:145-155:
@@ -293,10 +278,6 @@ int mtq_tile_scores_device(const double *stats, int64_t tiles, uint32_t fmt_mask
 int mtq_threshold_assign_device(const double *stats, int64_t tiles, uint32_t fmt_mask, const int *formats, int n_formats,
                                 int metric, double threshold, double band, int8_t *map, uint8_t *knife, void *stream);
 
-/* Chain records for mtq_greedy_run_chain from full records [tiles][2+5F] (tiles of any number of tensors back to back):
- * chain[tiles][3(n_formats-1)] and the side array base[tiles][base_doubles] (2 when formats[0] is the identity bf16, else 5). */
-int mtq_pack_chain_records(const double *stats, int64_t tiles, uint32_t fmt_mask, const int *formats, int n_formats, double *chain,
-                           double *base, int base_doubles, void *stream);
 
 /* Σx, Σx², Σy, Σy², Σxy, Σ|d|, max|d| of the reconstruction `map` implies → scratch[0..6] (device).  scratch must hold
  * mtq_columns_scratch_doubles() doubles.  Σx is NaN when the map names a format that is not available.  The caller

@@ -98,30 +98,6 @@ __global__ __launch_bounds__(256) void columns_final_dev(const double *__restric
     if (threadIdx.x < kColVals) out[threadIdx.x] = red[threadIdx.x][0];
 }
 
-// Chain records for the pcc greedy scan over distinct formats f0, f1, … (include/mtq.h): per tile the differences of
-// consecutive formats' (Σy, Σy², Σxy) — the subtraction the scan performs at every visit (mixed_tile_greedy.py:259-261) — and,
-// for the initial sums the host accumulates in tile order, a compact side array: [Σx, Σx²] when f0 is the identity bf16 (its
-// Σy, Σy², Σxy are Σx, Σx², Σx²), else [Σx, Σx², Σy, Σy², Σxy](f0).  One thread per tile.
-struct ChainPlan { int slot[MTQ_NUM_TILE_FORMATS], n, base_doubles; };
-__global__ __launch_bounds__(256) void pack_chain_records_dev(const double *__restrict__ stats, int64_t tiles, int rec, ChainPlan plan,
-                                                              double *__restrict__ chain, double *__restrict__ base)
-{
-    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (t >= tiles) return;
-    const double *r = stats + t * rec;
-    Sums5 prev = load5(r, plan.slot[0]);
-    double *b = base + t * plan.base_doubles;
-    b[0] = r[0]; b[1] = r[1];
-    if (plan.base_doubles == 5) { b[2] = prev.y; b[3] = prev.y2; b[4] = prev.xy; }
-    double *c = chain + t * 3 * (plan.n - 1);
-    for (int p = 1; p < plan.n; ++p) {
-        const Sums5 q = load5(r, plan.slot[p]);
-        c[0] = q.y - prev.y; c[1] = q.y2 - prev.y2; c[2] = q.xy - prev.xy;
-        c += 3;
-        prev = q;
-    }
-}
-
 static SlotTable slot_table(uint32_t fmt_mask)
 {
     SlotTable st;
@@ -184,27 +160,3 @@ extern "C" int mtq_column_sums_device(const double *stats, int64_t tiles, uint32
     return mtq_column_sums_device_batched(stats, 1, tiles, fmt_mask, map, scratch, stream);
 }
 
-extern "C" int mtq_pack_chain_records(const double *stats, int64_t tiles, uint32_t fmt_mask, const int *formats, int n_formats, double *chain,
-                                      double *base, int base_doubles, void *stream)
-{
-    if (!stats || !formats || !chain || !base) return fail(MTQ_ERR_INVALID, "null argument");
-    if (tiles <= 0 || tiles > ((int64_t)1 << 34)) return fail(MTQ_ERR_INVALID, "tiles out of range");
-    if (n_formats < 2 || n_formats > MTQ_NUM_TILE_FORMATS) return fail(MTQ_ERR_INVALID, "a chain needs 2..4 formats");
-    if (fmt_mask & MTQ_MASK_SLIM) return fail(MTQ_ERR_INVALID, "chain records are packed from full records");
-    ChainPlan plan;
-    plan.n = n_formats;
-    plan.base_doubles = base_doubles;
-    for (int p = 0; p < MTQ_NUM_TILE_FORMATS; ++p) plan.slot[p] = -1;
-    for (int p = 0; p < n_formats; ++p) {
-        plan.slot[p] = slot_of(fmt_mask, formats[p]);
-        if (!slot_ok(plan.slot[p])) return fail(MTQ_ERR_INVALID, "a requested format is not in fmt_mask");
-        for (int q = 0; q < p; ++q) if (formats[q] == formats[p]) return fail(MTQ_ERR_INVALID, "chain records need distinct formats");
-    }
-    if (base_doubles != 5 && !(base_doubles == 2 && plan.slot[0] == kVirtualSlot))
-        return fail(MTQ_ERR_INVALID, "base_doubles is 5, or 2 when the first format is the identity bf16");
-    if (int rc = require_device()) return rc;
-    const int rec = 2 + 5 * popcount4(fmt_mask);
-    hipLaunchKernelGGL(pack_chain_records_dev, dim3((unsigned)((tiles + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), stats, tiles,
-                       rec, plan, chain, base);
-    return check_launch("mtq_pack_chain_records");
-}

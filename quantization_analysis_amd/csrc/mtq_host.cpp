@@ -142,7 +142,6 @@ struct mtq_greedy {
     int w;              // doubles per format slot: 5, or 3 for slim records (MTQ_MASK_SLIM: no Σ|d|, no max)
     bool degenerate;    // slim records only: a decision needed Σ|d| (zero-variance case) — the result is not valid
     int slot4[MTQ_NUM_TILE_FORMATS]; // record slot of every format (−1: not in mask)
-    int chain_off = -1; // >= 0: `stats` holds chain records (mtq_greedy_run_chain) and this pass's Δ(Σy, Σy², Σxy) sit at this offset
     std::vector<int8_t> assign;  // the CURRENT format of every tile; its sums are stats[t][2 + 5*slot4[assign[t]] ..]
     std::vector<uint8_t> fixed;
     int64_t counts[MTQ_NUM_TILE_FORMATS];
@@ -227,19 +226,6 @@ static inline void pcc_visit(mtq_greedy *g, int fmt, int slot, int64_t t)
     const double thr = g->thr, N = g->n;
     const int prev = g->assign[(size_t)t];
     const double *rt = g->stats + t * g->rec;
-    if (g->chain_off >= 0) { // chain records: the differences the lines below would form are what the record holds
-        const double *d = rt + g->chain_off;
-        const double cy = g->sum_y + d[0], cy2 = g->sum_y2 + d[1], cxy = g->sum_xy + d[2];
-        if (is_good(pcc_hoisted(N, g->mean_x, g->am2, cy, cy2, cxy, g->sum_abs, &g->degenerate), MTQ_METRIC_PCC, thr)) {
-            g->sum_y = cy; g->sum_y2 = cy2; g->sum_xy = cxy; g->cur_valid = false;
-            g->counts[prev]--;
-            g->counts[fmt]++;
-            g->assign[(size_t)t] = (int8_t)fmt;
-        } else {
-            g->fixed[(size_t)t] = 1;
-        }
-        return;
-    }
     if (prev == fmt) { // :237-241 — current_value is a pure function of the running sums: reuse it until a move is accepted
         if (!g->cur_valid) {
             g->cur_value = pcc_hoisted(N, g->mean_x, g->am2, g->sum_y, g->sum_y2, g->sum_xy, g->sum_abs, &g->degenerate);
@@ -275,11 +261,11 @@ static inline void pcc_visit(mtq_greedy *g, int fmt, int slot, int64_t t)
 // The mode follows the last outcome (long runs of either kind are the rule: the scan accepts until the metric reaches the
 // threshold and mostly rejects afterwards).  Batches with an out-of-range id, a tile already in this format or a zero
 // denominator, and the tail of the order, go through pcc_visit one by one.
-enum { kScanFull = 0, kScanSlim = 1, kScanChain = 2 };
+enum { kScanFull = 0, kScanSlim = 1 };
 template <int kMode, typename Idx>
 __attribute__((target("avx512f"))) static int greedy_pass_pcc8(mtq_greedy *g, int fmt, int slot, const Idx *order, int64_t n)
 {
-    constexpr bool kSlim = kMode != kScanFull, kChain = kMode == kScanChain;   // chain records carry no Σ|d| either
+    constexpr bool kSlim = kMode != kScanFull;
     const double thr = g->thr, N = g->n;
     const int w = g->w, rec = g->rec;
     // where Σy, Σy², Σxy of every format sit in a slim record (the identity bf16 reads Σx, Σx², Σx²): branch-free deltas
@@ -290,7 +276,7 @@ __attribute__((target("avx512f"))) static int greedy_pass_pcc8(mtq_greedy *g, in
         oy2[f] = ps >= 0 ? 3 + w * ps : 1;
         oxy[f] = ps >= 0 ? 4 + w * ps : 1;
     }
-    const int so = kChain ? g->chain_off : oy[fmt];
+    const int so = oy[fmt];
     bool accept_mode = true;
     alignas(64) double cy[8], cy2[8], cxy[8], cab[8];
     int64_t moved[MTQ_NUM_TILE_FORMATS] = {0, 0, 0, 0};   // accepted moves by previous format (counts are adjusted once, at the end)
@@ -304,7 +290,7 @@ __attribute__((target("avx512f"))) static int greedy_pass_pcc8(mtq_greedy *g, in
             const int64_t t = order[k + i];
             if ((uint64_t)t >= (uint64_t)g->T) { plain = false; break; }
             const int p = g->assign[(size_t)t];
-            if (!kChain && p == fmt) { plain = false; break; }
+            if (p == fmt) { plain = false; break; }
             tt[i] = t;
             prev[i] = p;
         }
@@ -314,7 +300,7 @@ __attribute__((target("avx512f"))) static int greedy_pass_pcc8(mtq_greedy *g, in
                 if ((uint64_t)ta >= (uint64_t)g->T) continue;
                 const double *ra = g->stats + ta * rec;
                 __builtin_prefetch(ra + so);
-                if (!kChain) __builtin_prefetch(ra + oy[g->assign[(size_t)ta]]);
+                __builtin_prefetch(ra + oy[g->assign[(size_t)ta]]);
                 if (!kSlim) __builtin_prefetch(ra + so + 4);
             }
         }
@@ -330,9 +316,7 @@ __attribute__((target("avx512f"))) static int greedy_pass_pcc8(mtq_greedy *g, in
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const double *rt = g->stats + tt[i] * rec;
-            if (kChain) {
-                dy[i] = rt[so]; dy2[i] = rt[so + 1]; dxy[i] = rt[so + 2];
-            } else if (kSlim) {
+            if (kSlim) {
                 const int p = prev[i];
                 dy[i] = rt[so] - rt[oy[p]]; dy2[i] = rt[so + 1] - rt[oy2[p]]; dxy[i] = rt[oxy[fmt]] - rt[oxy[p]];
             } else {
@@ -396,8 +380,8 @@ static int greedy_pass_any(mtq_greedy *g, int fmt, const Idx *order, int64_t n)
     const int slot = slot_of(g->mask, fmt);
     if (!slot_ok(slot)) return fail(MTQ_ERR_INVALID, "format is not in the handle's fmt_mask");
 #if defined(__x86_64__)
-    if (g->metric == MTQ_METRIC_PCC && g_avx512 && g->n != 0.0) return g->chain_off >= 0 ? greedy_pass_pcc8<kScanChain, Idx>(g, fmt, slot, order, n)
-               : g->w == 3 ? greedy_pass_pcc8<kScanSlim, Idx>(g, fmt, slot, order, n) : greedy_pass_pcc8<kScanFull, Idx>(g, fmt, slot, order, n);
+    if (g->metric == MTQ_METRIC_PCC && g_avx512 && g->n != 0.0)
+        return g->w == 3 ? greedy_pass_pcc8<kScanSlim, Idx>(g, fmt, slot, order, n) : greedy_pass_pcc8<kScanFull, Idx>(g, fmt, slot, order, n);
 #endif
     const double thr = g->thr, N = g->n;
     constexpr int64_t kAhead = 12; // the visiting order is random and a record is 2–3 cache lines: fetch ahead of the dependent arithmetic
@@ -811,74 +795,6 @@ extern "C" int mtq_greedy_run(const double *stats, int64_t tiles, uint32_t fmt_m
     return rc;
 }
 
-// The search of one tensor on CHAIN records (include/mtq.h): pcc metric, distinct formats f0, f1, …  Every visit of pass
-// p >= 1 moves a tile from f(p−1) to f(p) — a tile that is still a candidate accepted every earlier pass, a rejected one is
-// fixed — so all the scan reads of a tile is the difference of the two formats' sums, formed on the device by the subtraction
-// the record-based scan performs (:259-261); the running sums start from the all-f0 sums, accumulated here in tile order
-// (:147-174) from a compact side array.  Same operations in the same order as mtq_greedy_run: same maps, same counts.
-extern "C" int mtq_greedy_run_chain(const double *chain, const double *base, int base_doubles, int64_t tiles, const int *formats, int n_formats,
-                                    double threshold, double elem_count, uint64_t seed, int8_t *map, int64_t counts[4])
-{
-    if (!chain || !base || !formats || !map) return fail(MTQ_ERR_INVALID, "null argument");
-    if (base_doubles != 2 && base_doubles != 5) return fail(MTQ_ERR_INVALID, "base_doubles is 2 (identity bf16 first) or 5");
-    if (tiles <= 0) return fail(MTQ_ERR_INVALID, "tiles must be positive");
-    if (n_formats < 2 || n_formats > MTQ_NUM_TILE_FORMATS) return fail(MTQ_ERR_INVALID, "a chain needs 2..4 formats");
-    if (seed == 0) return fail(MTQ_ERR_INVALID, "seed 0 means 'draw a random seed' in the reference; resolve it before calling");
-    for (int a = 0; a < n_formats; ++a) {
-        if (formats[a] < 0 || formats[a] >= MTQ_NUM_TILE_FORMATS) return fail(MTQ_ERR_INVALID, "unknown format code");
-        for (int b = 0; b < a; ++b) if (formats[a] == formats[b]) return fail(MTQ_ERR_INVALID, "chain records need distinct formats");
-    }
-    mtq_greedy g;
-    g.T = tiles; g.mask = 0; g.rec = 3 * (n_formats - 1); g.metric = MTQ_METRIC_PCC; g.thr = threshold; g.n = elem_count;
-    g.stats = chain; g.w = 3; g.degenerate = false;
-    // running globals of the all-f0 assignment, accumulated in tile order (:147-174); for the identity bf16 Σy, Σy², Σxy are the
-    // same additions of the same values as Σx, Σx², Σx²
-    double init5[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
-    for (int64_t t = 0; t < tiles; ++t) {
-        const double *b = base + t * base_doubles;
-        init5[0] += b[0];
-        init5[1] += b[1];
-        if (base_doubles == 5) { init5[2] += b[2]; init5[3] += b[3]; init5[4] += b[4]; }
-    }
-    if (base_doubles == 2) { init5[2] = init5[0]; init5[3] = init5[1]; init5[4] = init5[1]; }
-    g.sum_x = init5[0]; g.sum_x2 = init5[1]; g.sum_y = init5[2]; g.sum_y2 = init5[3]; g.sum_xy = init5[4]; g.sum_abs = 0.0;
-    g.cur_valid = false; g.cur_value = 0.0; g.max_abs = 0.0; g.max_count = 0;
-    g.mean_x = elem_count != 0.0 ? g.sum_x / elem_count : 0.0;
-    g.am2 = g.sum_x2 - elem_count * g.mean_x * g.mean_x;
-    if (g.am2 < 0.0) g.am2 = 0.0;
-    for (int f = 0; f < MTQ_NUM_TILE_FORMATS; ++f) { g.slot4[f] = -1; g.counts[f] = 0; }
-    g.counts[formats[0]] = tiles;
-    g.assign.assign((size_t)tiles, (int8_t)formats[0]);
-    g.fixed.assign((size_t)tiles, 0);
-    mtq_rng rng;
-    rng_seed(&rng, seed);
-    int rc = MTQ_OK;
-    // the pass of f0: one question for all tiles (see mtq_greedy_run); the generator advances as its permutation would
-    rng_skip_shuffle(&rng, tiles);
-    if (!is_good(pcc_hoisted(g.n, g.mean_x, g.am2, g.sum_y, g.sum_y2, g.sum_xy, g.sum_abs, &g.degenerate), MTQ_METRIC_PCC, threshold))
-        std::fill(g.fixed.begin(), g.fixed.end(), (uint8_t)1);
-    if (tiles > INT32_MAX) return fail(MTQ_ERR_INVALID, "more than 2^31 tiles in one tensor");
-    std::vector<int32_t> cand((size_t)tiles);
-    for (int p = 1; p < n_formats && rc == MTQ_OK; ++p) {
-        int64_t n = 0;
-        for (int64_t t = 0; t < tiles; ++t) if (!g.fixed[(size_t)t]) cand[(size_t)n++] = (int32_t)t;
-        if (n == 0) break;
-        rng_shuffle(&rng, n, cand.data());
-        g.chain_off = 3 * (p - 1);
-#if defined(__x86_64__)
-        if (g_avx512 && g.n != 0.0) { rc = greedy_pass_pcc8<kScanChain, int32_t>(&g, formats[p], 0, cand.data(), n); continue; }
-#endif
-        for (int64_t k = 0; k < n; ++k) pcc_visit(&g, formats[p], 0, cand[(size_t)k]);
-    }
-    if (rc == MTQ_OK && g.degenerate)
-        rc = fail(MTQ_ERR_UNSUPPORTED, "zero-variance tensor: the decision needs the full records (Σ|x−y|), not the chain records");
-    if (rc == MTQ_OK) {
-        std::memcpy(map, g.assign.data(), (size_t)tiles);
-        if (counts) for (int f = 0; f < MTQ_NUM_TILE_FORMATS; ++f) counts[f] = g.counts[f];
-    }
-    return rc;
-}
-
 // Process-wide pool of scan threads.  The streamed driver calls mtq_greedy_run_batch once per chunk of tensors, a few
 // calls in flight at a time; spawning and joining a thread per worker per call cost about as much as scanning a tensor
 // (≈ 0.35 ms per call with 8–16 workers), so the threads are created once and sleep on a condition variable between
@@ -1000,22 +916,6 @@ extern "C" int mtq_greedy_run_batch(const double *stats, int64_t count, int64_t 
     return run_batch(count, n_threads, "mtq_greedy_run_batch failed", [=](int64_t i) {
         return mtq_greedy_run(stats + i * tiles * rec, tiles, fmt_mask, formats, n_formats, metric, threshold, elem_count, seeds[i],
                               maps + i * tiles, counts ? counts + 4 * i : nullptr, outs ? outs + 9 * i : nullptr);
-    });
-}
-
-// mtq_greedy_run_chain over `count` tensors: chain [count][tiles][3(F−1)], base [count][tiles][base_doubles].
-extern "C" int mtq_greedy_run_chain_batch(const double *chain, const double *base, int base_doubles, int64_t count, int64_t tiles,
-                                          const int *formats, int n_formats, double threshold, double elem_count, const uint64_t *seeds,
-                                          int8_t *maps, int64_t *counts, int n_threads)
-{
-    if (!chain || !base || !formats || !seeds || !maps) return fail(MTQ_ERR_INVALID, "null argument");
-    if (count <= 0 || tiles <= 0) return fail(MTQ_ERR_INVALID, "count and tiles must be positive");
-    if (n_formats < 2 || n_formats > MTQ_NUM_TILE_FORMATS) return fail(MTQ_ERR_INVALID, "a chain needs 2..4 formats");
-    if (base_doubles != 2 && base_doubles != 5) return fail(MTQ_ERR_INVALID, "base_doubles is 2 (identity bf16 first) or 5");
-    const int rec = 3 * (n_formats - 1);
-    return run_batch(count, n_threads, "mtq_greedy_run_chain_batch failed", [=](int64_t i) {
-        return mtq_greedy_run_chain(chain + i * tiles * rec, base + i * tiles * base_doubles, base_doubles, tiles, formats, n_formats, threshold,
-                                    elem_count, seeds[i], maps + i * tiles, counts ? counts + 4 * i : nullptr);
     });
 }
 

@@ -28,7 +28,7 @@ EXPORTS = [
     "mtq_shutdown", "mtq_tile_stats", "mtq_tile_stats_batched", "mtq_tile_stats_partial", "mtq_tile_stats_partial_begin", "mtq_tile_stats_partial_end", "mtq_tile_stats_listed", "mtq_quantize", "mtq_apply_assignment", "mtq_dequant_fp8_block", "mtq_pack_slim_records",
     "mtq_greedy_create", "mtq_greedy_pass", "mtq_greedy_assignment", "mtq_greedy_fixed",
     "mtq_greedy_counts", "mtq_greedy_value", "mtq_greedy_destroy",
-    "mtq_greedy_run_chain", "mtq_greedy_run_chain_batch", "mtq_pack_chain_records", "mtq_tile_scores", "mtq_threshold_assign", "mtq_columns_from_stats", "mtq_columns_from_sums", "mtq_tile_scores_device",
+    "mtq_tile_scores", "mtq_threshold_assign", "mtq_columns_from_stats", "mtq_columns_from_sums", "mtq_tile_scores_device",
     "mtq_threshold_assign_device", "mtq_columns_scratch_doubles", "mtq_column_sums_device", "mtq_column_sums_device_batched",
     "mtq_rng_create", "mtq_rng_permutation", "mtq_rng_integers", "mtq_rng_destroy", "mtq_greedy_run", "mtq_greedy_run_batch",
     "mtq_selftest_slot_ring", "mtq_device_copy_2d", "mtq_knife_tiles_device", "mtq_greedy_scan_scratch_bytes", "mtq_greedy_scan_device", "mtq_greedy_scan_device_ex", "mtq_scan_carry_bytes",
@@ -108,9 +108,6 @@ def lib() -> ctypes.CDLL:
     L.mtq_rng_destroy.restype = None
     L.mtq_greedy_run.argtypes = [vp, i64, u32, vp, ci, ci, dbl, dbl, ctypes.c_uint64, vp, vp, vp]
     L.mtq_greedy_run_batch.argtypes = [vp, i64, i64, u32, vp, ci, ci, dbl, dbl, vp, vp, vp, vp, ci]
-    L.mtq_pack_chain_records.argtypes = [vp, i64, u32, vp, ci, vp, vp, ci, vp]
-    L.mtq_greedy_run_chain.argtypes = [vp, vp, ci, i64, vp, ci, dbl, dbl, ctypes.c_uint64, vp, vp]
-    L.mtq_greedy_run_chain_batch.argtypes = [vp, vp, ci, i64, i64, vp, ci, dbl, dbl, vp, vp, vp, ci]
     L.mtq_greedy_scan_scratch_bytes.argtypes = [i64, i64]
     L.mtq_greedy_scan_scratch_bytes.restype = ctypes.c_size_t
     L.mtq_greedy_scan_device.argtypes = [vp, i64, i64, u32, vp, ci, ci, dbl, dbl, vp, vp, vp, vp, vp, ctypes.c_size_t, vp]
@@ -178,7 +175,9 @@ def bind_to_gpu_numa_node(device_index: int) -> str:
     node its GPU hangs off, read from sysfs through the device's PCI address.  The records are DMA-written into pinned host
     memory and then read by the scan threads: on a two-socket host both want that memory on the GPU's socket.  Returns a
     short description; does nothing (and says so) when the topology cannot be read.  MTQ_NUMA_BIND=0 disables it."""
-    if os.environ.get("MTQ_NUMA_BIND", "1") == "0" or not hasattr(os, "sched_setaffinity"):
+    from .settings import settings
+
+    if not settings().numa_bind or not hasattr(os, "sched_setaffinity"):
         return "off"
     try:
         p = _torch().cuda.get_device_properties(device_index)
@@ -603,44 +602,6 @@ def greedy_run_batch(stats: np.ndarray, mask: int, formats, metric: str, thresho
     check(lib().mtq_greedy_run_batch(stats.ctypes.data, count, T, mask, fm, len(formats), METRIC_CODE[metric], float(threshold),
                                      float(elem_count), sd.ctypes.data, maps.ctypes.data, counts.ctypes.data, outs.ctypes.data, int(n_threads)))
     return maps, counts, outs
-
-
-def chain_base_doubles(mask: int, formats) -> int:
-    """Doubles per tile of the chain records' side array: 2 ([Σx, Σx²]) when the first format is the identity bf16, else 5."""
-    return 2 if formats[0] == "bf16" and (mask & MASK_BF16_IDENTITY) and not (mask & 1) else 5
-
-
-def pack_chain_records(stats_dev, mask: int, formats, chain_out=None, base_out=None):
-    """Device: full records [count, tiles, rec] → chain records [count, tiles, 3(F-1)] and the side array [count, tiles, 2|5]
-    the host accumulates the initial sums from (mtq_pack_chain_records on the current stream).  → (chain, base) device tensors."""
-    torch = _torch()
-    require_gpu()
-    count, T = stats_dev.shape[0], stats_dev.shape[1]
-    F = len(formats)
-    bd = chain_base_doubles(mask, formats)
-    fm = (ctypes.c_int * F)(*[MIXED_TILE_FORMATS.index(f) for f in formats])
-    dev = stats_dev.device
-    chain = chain_out if chain_out is not None else torch.empty((count, T, 3 * (F - 1)), dtype=torch.float64, device=dev)
-    base = base_out if base_out is not None else torch.empty((count, T, bd), dtype=torch.float64, device=dev)
-    check(lib().mtq_pack_chain_records(stats_dev.data_ptr(), count * T, mask, fm, F, chain.data_ptr(), base.data_ptr(), bd, _stream_ptr()))
-    return chain, base
-
-
-def greedy_run_chain_batch(chain: np.ndarray, base: np.ndarray, formats, threshold: float, elem_count: float, seeds, n_threads: int):
-    """mtq_greedy_run_chain over [count, tiles, 3(F-1)] chain records and the [count, tiles, 2|5] side array (pcc, distinct
-    formats) on n_threads host threads → (int8 [count, tiles] maps, int64 [count, 4] counts)."""
-    chain = np.ascontiguousarray(chain, dtype=np.float64)
-    base = np.ascontiguousarray(base, dtype=np.float64)
-    count, T = chain.shape[0], chain.shape[1]
-    if chain.shape[2] != 3 * (len(formats) - 1) or base.shape[:2] != (count, T) or base.shape[2] not in (2, 5):
-        raise MtqError("chain records / side array have the wrong shape")
-    fm = (ctypes.c_int * len(formats))(*[MIXED_TILE_FORMATS.index(f) for f in formats])
-    sd = np.ascontiguousarray(seeds, dtype=np.uint64)
-    maps = np.empty((count, T), dtype=np.int8)
-    counts = np.empty((count, 4), dtype=np.int64)
-    check(lib().mtq_greedy_run_chain_batch(chain.ctypes.data, base.ctypes.data, base.shape[2], count, T, fm, len(formats), float(threshold),
-                                           float(elem_count), sd.ctypes.data, maps.ctypes.data, counts.ctypes.data, int(n_threads)))
-    return maps, counts
 
 
 def tile_scores(stats: np.ndarray, mask: int, metric: str) -> np.ndarray:

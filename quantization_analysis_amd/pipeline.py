@@ -21,6 +21,7 @@ from dataclasses import dataclass, field
 import numpy as np
 
 from . import hip_backend as hb
+from .settings import settings
 from .compression_algorithms.tile_utils import MIXED_TILE_FORMATS, mixed_tile_total_bytes
 
 
@@ -70,8 +71,8 @@ def cpu_budget() -> int:
 def default_workers() -> int:
     """Scan threads per rank: the rank's share of the CPU budget (the driver's own threads mostly sleep), at most 32;
     MTQ_SCAN_WORKERS overrides."""
-    if "MTQ_SCAN_WORKERS" in os.environ:
-        return int(os.environ["MTQ_SCAN_WORKERS"])
+    if settings().scan_workers is not None:
+        return settings().scan_workers
     local = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")))
     return max(4, min(32, cpu_budget() // max(local, 1)))
 
@@ -85,17 +86,6 @@ def _scan_chunk(first, stats, mask, tiles_hw, numel, tile_formats, metric, thres
         c = {f: int(counts[j, i]) for i, f in enumerate(MIXED_TILE_FORMATS)}
         res.append(TensorResult(first + j, maps[j].reshape(tiles_hw), c, mixed_tile_total_bytes(c), float(outs[j, 0]), float(outs[j, 1]),
                                 float(outs[j, 2]), float(outs[j, k])))
-    return res
-
-
-def _scan_chunk_chain(first, chain, base, tiles_hw, numel, tile_formats, threshold, seeds, n_threads) -> list[TensorResult]:
-    """_scan_chunk on chain records (pcc, distinct formats): maps and counts; pcc / mae / atol are filled in from the device."""
-    maps, counts = hb.greedy_run_chain_batch(chain, base, tile_formats, threshold, float(numel), seeds, n_threads)
-    nan = float("nan")
-    res = []
-    for j in range(maps.shape[0]):
-        c = {f: int(counts[j, i]) for i, f in enumerate(MIXED_TILE_FORMATS)}
-        res.append(TensorResult(first + j, maps[j].reshape(tiles_hw), c, mixed_tile_total_bytes(c), nan, nan, nan, nan))
     return res
 
 
@@ -131,7 +121,7 @@ def columns_from_sums_batch(sums: np.ndarray, n: float) -> np.ndarray:
 class GreedyPipeline:
     """mixed-tile-greedy over a (count, rows, cols) device tensor of equally shaped bf16/fp32 matrices."""
 
-    SLOTS = int(os.environ.get("MTQ_PIPE_SLOTS", "4"))   # record slots = batches in flight: one on the GPU, one queued behind it, the others being searched (see run_steps).
+    SLOTS = None   # record slots = batches in flight: one on the GPU, one queued behind it, the others being searched (see run_steps).
                                                          # Round 3: a batch's search is a chain of launches (orders, phase 1, listed K1, phase 2, column sums) that takes 5–7 ms
                                                          # beside K1 launches of ~2 ms, so three slots made the K1 stream wait for a slot (2.65 against 2.47 ms per step at four)
 
@@ -154,22 +144,22 @@ class GreedyPipeline:
             raise ValueError("seed 0 means 'draw a random seed' in the reference; pass a non-zero seed")
         self.chunk = int(chunk)
         self.workers = int(workers)
-        self.pool = cf.ThreadPoolExecutor(max_workers=int(os.environ.get("MTQ_CHUNK_TASKS", "8")))  # chunk-level tasks; the fan-out over tensors happens inside the C call (shared scan pool)
+        self.pool = cf.ThreadPoolExecutor(max_workers=settings().chunk_tasks)  # chunk-level tasks; the fan-out over tensors happens inside the C call (shared scan pool)
         self.stream = torch.cuda.Stream()        # K1 launches
         self.copy_stream = torch.cuda.Stream()   # records D2H, overlapped with the next chunk's K1
         self.col_stream = torch.cuda.Stream()    # maps up / column sums / sums down of a finished batch (must not queue behind the next batch's copies)
         self.timing = KernelTiming()
-        self.SLOTS = type(self).SLOTS            # per instance: callers that stream many shape groups raise it (streamed.py)
+        self.SLOTS = type(self).SLOTS or settings().pipe_slots   # per instance: callers that stream many shape groups raise it (streamed.py)
         if scan not in ("auto", "host", "device"):
             raise ValueError("scan must be 'auto', 'host' or 'device'")
         can = hb.device_scan_supported(self.tile_formats, self.metric, 1)
         if scan == "device" and not can:
             raise ValueError("the device scan needs distinct formats")
-        self.device_scan = can and scan != "host" and os.environ.get("MTQ_DEVICE_SCAN", "1") != "0"
+        self.device_scan = can and scan != "host" and settings().device_scan
         # A device scan is ONE wave per tensor (≈ 0.14–0.19 µs per tile, three passes): right when a batch holds many tensors, a long
         # pole when a batch is a few very large ones — a host core scans a tile in ≈ 0.025 µs.  Callers whose batches are latency-bound
         # (streamed.py: a model's shape groups) lower this limit; batches above it take the host route, the others the device route.
-        self.device_scan_max_tiles = int(os.environ.get("MTQ_DEVICE_SCAN_MAX_TILES", str(hb.SCAN_DEVICE_MAX_TILES)))
+        self.device_scan_max_tiles = settings().device_scan_max_tiles or hb.SCAN_DEVICE_MAX_TILES
         self.host_chunk_tiles = None             # host route: tiles per K1 launch / records copy / scan task (None: self.chunk tensors)
         # device scans + column sums: behind their chunk's K1, beside the next chunks' K1.  A scan is one wave per tensor for a few
         # milliseconds (latency-bound), so consecutive chunks' scans must overlap each other: a ring of streams
@@ -178,8 +168,8 @@ class GreedyPipeline:
         # more hardware queues in play).  A model's shape groups (streamed.py) keep every batch of a window in flight and asked for eight in round 2.
         # Round 3 (a step's chain is three search launches and the listed K1 now, four record slots): three streams again — with four,
         # K1's launch is 3 % longer and the 20-step figure 3 % lower (916–927 against 947–956 M tiles/s, tools/r3_env_ab.sh); two starve.
-        n_scan = int(os.environ.get("MTQ_SCAN_STREAMS", str(3 if scan_streams is None else scan_streams)))
-        self.scan_streams = [torch.cuda.Stream(priority=int(os.environ.get("MTQ_SCAN_PRIORITY", "-1")))
+        n_scan = settings().scan_streams if settings().scan_streams is not None else (3 if scan_streams is None else scan_streams)
+        self.scan_streams = [torch.cuda.Stream(priority=settings().scan_priority)
                              for _ in range(max(1, n_scan))]   # priority -1: ahead of K1's blocks when a slot opens
         self._scan_rr = 0
         # Round 3.  shared orders: the tensors of a batch are searched with one seed, so the base pass's draws and the permutations of
@@ -187,14 +177,14 @@ class GreedyPipeline:
         # of the visiting wave.  lazy: K1 leaves out the last format of the list (and Σ|x−y|, max|x−y| of the one before it); the search
         # stops before its last pass, the left-out statistics are evaluated for that pass's candidates only (mtq_tile_stats_listed: the
         # tiles that accepted every earlier format — 15 % at pcc >= 0.999), and the last pass follows.  Same maps, same columns.
-        self.shared_orders = os.environ.get("MTQ_SHARED_ORDERS", "1") != "0"
-        self.lazy = (os.environ.get("MTQ_LAZY", "1") != "0" and self.metric == "pcc" and len(self.tile_formats) >= 3 and self.tile_formats[0] == "bf16"
+        self.shared_orders = settings().shared_orders
+        self.lazy = (settings().lazy and self.metric == "pcc" and len(self.tile_formats) >= 3 and self.tile_formats[0] == "bf16"
                      and len(set(self.tile_formats)) == len(self.tile_formats) and not self.pure_formats)
         self.listed_tiles = 0                    # tiles the lazy route evaluated late (diagnostics)
         # The lazy route pays when few tiles reach the last pass: K1 <3,1> costs 469 instructions per tile and the listed kernel 432 per
         # listed tile, against 652 for the whole record — break-even at 42 % listed, less the phases' launches.  A batch that listed more
         # switches the route off for tensors of its tile count (the batches already in flight finish as they were enqueued).
-        self.lazy_max_listed = float(os.environ.get("MTQ_LAZY_MAX_LISTED", "0.35"))
+        self.lazy_max_listed = settings().lazy_max_listed
         self.lazy_off = {}                       # tiles per tensor -> the listed fraction that switched the lazy route off
         self.host_fallbacks = 0                  # tensors the device scan handed back (zero denominator)
         self.host_seconds = {"enqueue": 0.0, "wait": 0.0, "wrap": 0.0}   # driver-thread time: launching, waiting for results, wrapping them
@@ -202,7 +192,6 @@ class GreedyPipeline:
         self._orders_cache = {}   # (device, seed, tiles, orders) -> [device buffer of mtq_scan_orders_device, event until it is complete]
         self._orders_retired = []
         self._bufs = {}
-        self._chainbufs = {}
         self._colbufs = {}
         self._unresolved = []  # batches whose device-side columns are in flight (oldest first)
         self._open = []        # enqueued, not yet finished (oldest first)
@@ -214,10 +203,10 @@ class GreedyPipeline:
         (MTQ_MASK_BF16_IDENTITY).  pcc metric: Σ|d| and max feed no decision (bar the zero-variance case), so a slim copy of the
         records (3 doubles per format, MTQ_MASK_SLIM) crosses PCIe and the result's mae / atol come from the device."""
         torch = self.torch
-        identity = x3d.dtype == torch.bfloat16 and (self.mask & 1) and (self.mask & 0xE) and os.environ.get("MTQ_IDENTITY_RECORDS", "1") != "0"
+        identity = x3d.dtype == torch.bfloat16 and (self.mask & 1) and (self.mask & 0xE) and settings().identity_records
         k1_mask = self.mask & 0xE if identity else self.mask
         host_mask = k1_mask | hb.MASK_BF16_IDENTITY if identity else self.mask
-        slim = self.metric == "pcc" and os.environ.get("MTQ_SLIM_RECORDS", "1") != "0"
+        slim = self.metric == "pcc" and settings().slim_records
         return k1_mask, host_mask | (hb.MASK_SLIM if slim else 0), slim
 
     def lazy_plan(self, x3d):
@@ -243,14 +232,6 @@ class GreedyPipeline:
             return hb.tile_stats_batched(x3d, self._layout(x3d)[0], out=out)
         return hb.tile_stats_partial(x3d, plan[0], plan[1], plan[2], out=out)
 
-    def _chain(self, slim: bool) -> bool:
-        """Chain records (differences of consecutive formats' sums, 3 doubles per step of the format chain, plus Σx, Σx² — or the
-        first format's five sums — in a side array) serve the pcc search over distinct formats: the same bytes over PCIe, one
-        24-byte read per visit instead of two record slots and a short sequential pass for the initial sums.  Measured
-        equal or slower than the slim records on the GPU boxes, hence opt-in: MTQ_CHAIN_RECORDS=1."""
-        f = self.tile_formats
-        return slim and len(f) >= 2 and len(set(f)) == len(f) and os.environ.get("MTQ_CHAIN_RECORDS", "0") == "1"
-
     def _buffers(self, slot: int, count: int, tiles: int, rec: int, rec_host: int, device):
         """Records of a whole batch: device buffer (full records, what K1 writes), device staging buffer of what crosses PCIe
         (the same buffer unless the records are slimmed) and its pinned host mirror (scans read the pinned memory in place).
@@ -264,15 +245,6 @@ class GreedyPipeline:
             host = torch.empty((count, tiles, rec_host), dtype=torch.float64, pin_memory=True)
             self._bufs[slot] = (key, dev, stage, host, host.numpy())
         return self._bufs[slot][1:]
-
-    def _chain_buffers(self, slot: int, count: int, tiles: int, bd: int, device):
-        """The chain path's side array ([Σx, Σx²] or the first format's five sums per tile): device + pinned host."""
-        key = (count, tiles, bd, str(device))
-        if self._chainbufs.get(slot, (None,))[0] != key:
-            torch = self.torch
-            host = torch.empty((count, tiles, bd), dtype=torch.float64, pin_memory=True)
-            self._chainbufs[slot] = (key, torch.empty((count, tiles, bd), dtype=torch.float64, device=device), host, host.numpy())
-        return self._chainbufs[slot][1:]
 
     def reserve(self, x3d) -> None:
         """Allocate both record slots (device + pinned host) for batches shaped like x3d and start the scan threads, so that
@@ -290,17 +262,12 @@ class GreedyPipeline:
                 b["sums_host"].copy_(b["sums_dev"][:, :, :7], non_blocking=True)
             torch.cuda.synchronize()
             return
-        chain = self._chain(slim)
-        rec_host = 3 * (len(self.tile_formats) - 1) if chain else hb.record_doubles(host_mask)
+        rec_host = hb.record_doubles(host_mask)
         for slot in range(self.SLOTS):
             dev, stage, host, _np = self._buffers(slot, count, th * tw, hb.record_doubles(k1_mask), rec_host, x3d.device)
             dev.zero_()
             stage.zero_()
             host.copy_(stage, non_blocking=True)   # first DMA into the pinned pages (mappings are set up lazily)
-            if chain:
-                base_dev, base_host, _bnp = self._chain_buffers(slot, count, th * tw, hb.chain_base_doubles(host_mask, self.tile_formats), x3d.device)
-                base_dev.zero_()
-                base_host.copy_(base_dev, non_blocking=True)
         torch.cuda.synchronize()
         hb.greedy_run_batch(np.zeros((self.workers, 1, hb.record_doubles(0xF))), 0xF, ["bf16"], self.metric, self.threshold, 1024.0,
                             [1] * self.workers, self.workers)
@@ -321,13 +288,10 @@ class GreedyPipeline:
             return self._enqueue_device(x3d, seeds, numel, slot, k1_mask, host_mask & ~hb.MASK_SLIM, th, tw)
         # the batch SLOTS back read this slot's records in its device-side column sums: those run on the K1 stream (see
         # _launch_columns), ahead of the K1 launches below in stream order — no host-side wait is needed here
-        chain = self._chain(slim)
-        trace = os.environ.get("MTQ_PIPE_TRACE") == "1"
+        trace = settings().pipe_trace
         t_enq = time.perf_counter()
-        rec_host = 3 * (len(self.tile_formats) - 1) if chain else hb.record_doubles(host_mask)
+        rec_host = hb.record_doubles(host_mask)
         dev, stage, host, host_np = self._buffers(slot, count, tiles, hb.record_doubles(k1_mask), rec_host, x3d.device)
-        if chain:
-            base_dev, base_host, base_np = self._chain_buffers(slot, count, tiles, hb.chain_base_doubles(host_mask, self.tile_formats), x3d.device)
         t_buf = time.perf_counter()
         dec_mask = host_mask & ~hb.MASK_SLIM             # what the full records on the device hold (identity bf16 included)
         pending = []  # (event, first_index, n)
@@ -346,36 +310,24 @@ class GreedyPipeline:
                 # Packing stays on the K1 stream: K1 is a persistent grid over every CU, so a kernel on another stream only gets
                 # waves once K1 drains — packing there delayed each chunk's copy by a whole K1 launch (measured: 450–517 M tiles/s
                 # against 582–603 M).
-                if chain:
-                    hb.pack_chain_records(dev[first:first + n], dec_mask, self.tile_formats, chain_out=stage[first:first + n],
-                                          base_out=base_dev[first:first + n])
-                elif slim:
+                if slim:
                     hb.pack_slim_records(dev[first:first + n], k1_mask, out=stage[first:first + n])
-                if chain or slim:
                     ready = torch.cuda.Event()
                     ready.record(self.stream)
                 self.copy_stream.wait_event(ready)
                 with torch.cuda.stream(self.copy_stream):
                     host[first:first + n].copy_(stage[first:first + n], non_blocking=True)
-                    if chain:
-                        base_host[first:first + n].copy_(base_dev[first:first + n], non_blocking=True)
                     done = torch.cuda.Event(blocking=True)   # the driver thread sleeps while it waits: spinning would burn a core of the scan budget
                     done.record(self.copy_stream)
                 pending.append((done, first, n))
         enq = {"host_np": host_np, "host_mask": host_mask, "tiles_hw": (th, tw), "numel": rows * cols if numel is None else int(numel),
-               "seeds": seeds, "x": x3d, "dev": dev, "k1_mask": k1_mask, "slim": slim, "chain": chain,
-               "base_np": base_np if chain else None}
+               "seeds": seeds, "x": x3d, "dev": dev, "k1_mask": k1_mask, "slim": slim}
         # The scans are handed to the chunk-task pool HERE, each behind its records' event: they start the moment the records land,
         # whatever the driver thread is doing (with the submission in finish() the scans of a batch only started once the driver
         # got there — all four chunks at once, 3.3 ms of scans with the GPU idle behind them).
         futures = []
         for done, first, n in pending:
-            if chain:
-                a = self._scan_args(enq, first, n, None, 0)
-                futures.append((first, n, self.pool.submit(_when_landed, done, _scan_chunk_chain, first, host_np[first:first + n], base_np[first:first + n],
-                                                           a[3], a[4], self.tile_formats, self.threshold, a[8], self.workers)))
-            else:
-                futures.append((first, n, self.pool.submit(_when_landed, done, _scan_chunk, *self._scan_args(enq, first, n, host_np[first:first + n], host_mask))))
+            futures.append((first, n, self.pool.submit(_when_landed, done, _scan_chunk, *self._scan_args(enq, first, n, host_np[first:first + n], host_mask))))
         enq["futures"] = futures
         self._open.append(enq)
         if trace:
@@ -452,7 +404,7 @@ class GreedyPipeline:
         import time
 
         t_enq = time.perf_counter()
-        trace = os.environ.get("MTQ_PIPE_TRACE") == "1"
+        trace = settings().pipe_trace
         marks = []
         torch = self.torch
         count, rows, cols = x3d.shape
@@ -509,7 +461,7 @@ class GreedyPipeline:
                 e0.record(self.stream)
                 # bf16 storage in whole 32x128 units: K1 as the exact-integer kernel alone (it resets its own unit counters), its literal
                 # fix-up — usually nothing to do — on the search stream: nothing sits between two K1 launches on this stream
-                two_launch = x3d.dtype == torch.bfloat16 and (k1_mask & 1) == 0 and rows % 32 == 0 and cols % 128 == 0 and os.environ.get("MTQ_K1_TWO_LAUNCH", "1") != "0"
+                two_launch = x3d.dtype == torch.bfloat16 and (k1_mask & 1) == 0 and rows % 32 == 0 and cols % 128 == 0 and settings().k1_two_launch
                 k1_id = None
                 if two_launch:
                     k1_id = hb.tile_stats_partial_begin(x3d[first:first + n], k1_mask, full_now if lazy else k1_mask, prev_bit if lazy else 0,
@@ -633,7 +585,7 @@ class GreedyPipeline:
                 r.pcc, r.mae, r.atol, r.metric_value = out["pcc"], out["mae"], out["atol"], out[self.metric]
             self.host_seconds["wait"] += t1 - t0
             self.host_seconds["wrap"] += time.perf_counter() - t1
-            if os.environ.get("MTQ_PIPE_TRACE") == "1":
+            if settings().pipe_trace:
                 print(f"[pipe] finish {n} x {th * tw}: waited {1e3 * (t1 - t0):.2f} ms, wrapped in {1e3 * (time.perf_counter() - t1):.2f} ms, handed back {bad.size}", flush=True)
         self._open.pop(0)
         enq["x"] = None
@@ -673,7 +625,7 @@ class GreedyPipeline:
             self._launch_columns(enq, results)
             if not defer_columns:
                 self.resolve(enq)
-        if os.environ.get("MTQ_PIPE_TRACE") == "1":
+        if settings().pipe_trace:
             print(f"[pipe] finish (host route) {len(results)} tensors: scans collected after {1e3 * (t_scanned - t_fin):.2f} ms, columns after {1e3 * (time.perf_counter() - t_scanned):.2f} ms", flush=True)
         return results
 
@@ -810,19 +762,16 @@ class GreedyPipeline:
             th, tw = hb.tiles_hw(rows, cols)
             k1_mask, host_mask, slim = self._layout(x3d)
             if not self._use_device_scan(th * tw):
-                host_route.append((i, count, th * tw, hb.record_doubles(k1_mask), 3 * (len(self.tile_formats) - 1) if self._chain(slim) else hb.record_doubles(host_mask),
-                                   hb.chain_base_doubles(host_mask, self.tile_formats) if self._chain(slim) else 0, x3d.device, slim))
+                host_route.append((i, count, th * tw, hb.record_doubles(k1_mask), hb.record_doubles(host_mask), x3d.device, slim))
                 continue
             for slot in range(self.SLOTS):
                 self._device_buffers(slot, count, th * tw, hb.record_doubles(k1_mask), x3d.device)
         # host-route batches: the record slot each one will land on (slots rotate per enqueue), its pinned mirror touched once, the
         # column buffers at the largest shape, the scan threads started
-        for i, count, tiles, rec, rec_host, bd, device, slim in host_route:
+        for i, count, tiles, rec, rec_host, device, slim in host_route:
             slot = (self._next_slot + i) % self.SLOTS
             dev, stage, host, _np = self._buffers(slot, count, tiles, rec, rec_host, device)
             host.copy_(stage, non_blocking=True)   # first DMA into the pinned pages (mappings are set up lazily)
-            if bd:
-                self._chain_buffers(slot, count, tiles, bd, device)
             if slim or self.pure_formats:
                 self._column_buffers(count, tiles, device)
         if host_route:
@@ -843,7 +792,7 @@ class GreedyPipeline:
             out.append(self.finish(open_.pop(0)))
         for st in (self.stream, self.copy_stream, *self.scan_streams):
             torch.cuda.current_stream().wait_stream(st)
-        if os.environ.get("MTQ_PIPE_TRACE") == "1" and getattr(self, "_trace_rows", None):
+        if settings().pipe_trace and getattr(self, "_trace_rows", None):
             torch.cuda.synchronize()
             ref = self._trace_ref
             for count, tiles, e0, e1, scanned, done, t_host in self._trace_rows:
@@ -900,7 +849,7 @@ class GreedyPipeline:
             self.pool.shutdown(wait=True)
             self._open.clear()
             self._unresolved.clear()
-            for d in (self._devbufs, self._bufs, self._chainbufs, self._colbufs, self._orders_cache):
+            for d in (self._devbufs, self._bufs, self._colbufs, self._orders_cache):
                 d.clear()
             self._orders_retired.clear()
             self.timing.events.clear()
@@ -935,7 +884,7 @@ class ThresholdPipeline:
         self.quantizer = Quantizer("hip")
         self.knife_tiles = 0
         self._side = torch.cuda.Stream()      # the knife-edge tiles' fetch and way home, beside the main stream's K1
-        self.knife_cap = int(os.environ.get("MTQ_KNIFE_CAP", "128"))   # knife-edge tiles per chunk fetched without a round trip (more: one extra trip)
+        self.knife_cap = settings().knife_cap   # knife-edge tiles per chunk fetched without a round trip (more: one extra trip)
         self._pin = {}
 
     def close(self) -> None:
@@ -1066,12 +1015,12 @@ class ThresholdPipeline:
                     self._side.wait_event(decided)
                 hb.knife_tiles_device(x3d[first:first + n], both_dev[1, part], self.tile_formats, cap, idx_dev[c], knife_dev[c])
                 hb.device_copy(idx_host[c], idx_dev[c])
-                if cap and not single:
+                if cap and not single and not overlap:   # (run_batches: the whole cap-sized buffer — 2.6 MB — per batch of a few thousand tiles cost more than its K1; the listed tiles follow on demand)
                     hb.device_copy(knife_host[c], knife_dev[c])
                 landed = torch.cuda.Event()
                 landed.record()
             launched.append((first, n, recs, part, decided, landed))
-        return {"x": x3d, "numel": numel, "hw": (th, tw), "tiles": tiles, "dec_mask": dec_mask, "cap": cap, "single": single, "planes": planes,
+        return {"x": x3d, "tiles_sent": bool(cap and not single and not overlap), "numel": numel, "hw": (th, tw), "tiles": tiles, "dec_mask": dec_mask, "cap": cap, "single": single, "planes": planes,
                 "launched": launched, "both_host": both_host, "idx_host": idx_host, "knife_host": knife_host, "sums_host": sums_host,
                 "both_dev": both_dev, "idx_dev": idx_dev, "knife_dev": knife_dev, "maps": np.empty((count, tiles), dtype=np.int8)}
 
@@ -1095,7 +1044,7 @@ class ThresholdPipeline:
                 near = both_host[1, part].numpy()
                 if k <= cap:
                     flat = idx_host[c, :k].numpy().copy()                                      # the list is in no particular order: ids travel with their tiles
-                    if st["single"]:                                                           # the tiles were not sent with the list
+                    if not st["tiles_sent"]:                                                   # the tiles were not sent with the list
                         home = knife_host[c].reshape(-1)[:planes * k * 1024].view(planes, k, 32, 32)
                         hb.device_copy(home, knife_dev[c, :, :k].contiguous())
                         torch.cuda.current_stream().synchronize()

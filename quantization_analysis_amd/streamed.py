@@ -18,16 +18,17 @@ import numpy as np
 from .compression_algorithms.tile_utils import MIXED_TILE_FORMATS
 from .pipeline import GreedyPipeline, ThresholdPipeline, cpu_budget, default_workers
 from .quantization_formats import SUPPORTED_FORMATS
+from .settings import settings
 
 STREAMED_ALGOS = {"mixed-tile-greedy", "mixed-tile-threshold"}
 MAX_BATCH_TILES = 1 << 21      # tiles per pipeline batch: bounds the record buffers (≈ 0.3 GB device + 0.2 GB pinned per slot)
 K1_LAUNCH_TILES = 1 << 19      # tiles per K1 launch with the host scan (32 x 4096²: a chunk's records cross PCIe beside the next chunk's K1)
-MAX_SLOTS = int(__import__("os").environ.get("MTQ_WQ_MAX_SLOTS", "8"))   # record slots of the streamed pipeline (K1 records + scan scratch of a batch: a few hundred MB each)
+MAX_SLOTS = settings().wq_max_slots   # record slots of the streamed pipeline (K1 records + scan scratch of a batch: a few hundred MB each)
 # Batches of tensors with more tiles than this take the pipeline's host route (records over PCIe, scans on host threads) beside the
 # device-scanned rest of the window.  A device scan is one wave per tensor (≈ 10 ms at 57 344 tiles inside a window, a host core
 # needs ≈ 2 ms), but the host route's launches and copies stalled the driver thread for 8 ms per window when tried on the
 # Llama-3-8B shapes (24–29 ms per window against 19 ms all on the device): off by default.
-DEVICE_SCAN_MAX_TILES = int(__import__("os").environ.get("MTQ_WQ_DEVICE_SCAN_MAX_TILES", str(1 << 22)))
+DEVICE_SCAN_MAX_TILES = settings().wq_device_scan_max_tiles
 MAX_WINDOW_BYTES = 48 << 30    # inputs resident in HBM at once (288 GB per MI355X): the loader fills a window, the pipeline then streams it
 
 

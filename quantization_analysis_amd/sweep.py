@@ -24,9 +24,10 @@ def _literal_threads() -> int:
     import os
 
     from .pipeline import cpu_budget
+    from .settings import settings
 
-    if "MTQ_SWEEP_THREADS" in os.environ:
-        return max(1, int(os.environ["MTQ_SWEEP_THREADS"]))
+    if settings().sweep_threads is not None:
+        return max(1, settings().sweep_threads)
     local = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")))
     return max(1, cpu_budget() // max(local, 1))
 

@@ -15,3 +15,14 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return ROOT / "tests" / "golden"
+
+
+@pytest.fixture(autouse=True)
+def _fresh_settings():
+    """The package's MTQ_* switches are read once per process (quantization_analysis_amd/settings.py): every test starts from, and
+    leaves behind, what the environment says (tests that monkeypatch a switch call settings(refresh=True) themselves)."""
+    from quantization_analysis_amd.settings import settings
+
+    settings(refresh=True)
+    yield
+    settings(refresh=True)

@@ -165,21 +165,16 @@ def run(cases: int, seed: int) -> int:
                 ok_g &= (int(ds.cpu()[0]) != 0) == degenerate
                 if int(ds.cpu()[0]) == 0:
                     ok_g &= np.array_equal(dm.cpu().numpy()[0], gh)
-                # the record layouts of the streamed driver: slim (3 doubles per format), slim + identity bf16, chain records
+                # the record layouts of the streamed driver: slim (3 doubles per format), slim + identity bf16
                 keep = [0, 1] + [2 + 5 * s_ + k for s_ in range(4) for k in range(3)]
                 try:
                     g2, _c, _o = hb.greedy_run(np.ascontiguousarray(full[:, keep]), 0xF | hb.MASK_SLIM, ALL, "pcc", thr, float(x.size), 7)
                     ok_g &= np.array_equal(g2.reshape(a.shape), a)
-                    sums = lambda f: full[:, 2 + 5 * f: 5 + 5 * f]
-                    chain = np.concatenate([sums(p) - sums(p - 1) for p in (1, 2, 3)], axis=1)
-                    base = np.concatenate([full[:, :2], sums(0)], axis=1)
-                    g3, _c = hb.greedy_run_chain_batch(chain[None], base[None], ALL, thr, float(x.size), [7], 1)
-                    ok_g &= np.array_equal(g3[0].reshape(a.shape), a)
                     if bf16:
                         ident = np.ascontiguousarray(full[:, [0, 1] + [2 + 5 * s_ + k for s_ in (1, 2, 3) for k in range(3)]])
                         g4, _c, _o = hb.greedy_run(ident, 0xE | hb.MASK_BF16_IDENTITY | hb.MASK_SLIM, ALL, "pcc", thr, float(x.size), 7)
                         ok_g &= np.array_equal(g4.reshape(a.shape), a)
-                except hb.MtqError as exc:   # slim / chain records refuse a zero-variance tensor (the driver then takes the full records)
+                except hb.MtqError as exc:   # slim records refuse a zero-variance tensor (the driver then takes the full records)
                     if "zero-variance" not in str(exc):
                         raise
             elif c % 4 == 0:   # ±Inf / NaN / all-zero inputs: no oracle search to compare with, but the device scan must do what the host scan does

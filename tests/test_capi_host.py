@@ -159,48 +159,6 @@ def test_knife_tiles_are_decided_lazily_and_like_the_reference(golden_dir):
     assert 0 < evaluated < possible
 
 
-def test_chain_record_scan_equals_the_record_scan(golden_dir):
-    """mtq_greedy_run_chain (differences of consecutive formats' sums + a side array for the all-f0 sums) against the oracle's
-    greedy search and mtq_greedy_run on the records themselves: same maps and counts, for several format chains, seeds and
-    thresholds, with the 2-double side array of the identity bf16 and the 5-double one, on one and on several scan threads."""
-    cases = [("normal_bf16", (256, 256), ALL, 0.999, 123), ("heavy_f32", (160, 224), ["bfp8", "bfp4", "bfp2"], 0.995, 7),
-             ("normal_bf16", (96, 640), ["bf16", "bfp4"], 0.99, 5), ("heavy_f32", (64, 64), ["bfp4", "bfp8", "bf16"], 0.9999, 11),
-             ("normal_bf16", (128, 128), ALL, 1.5, 3), ("normal_bf16", (128, 96), ["bfp2", "bfp8"], 0.5, 9)]
-    for kind, shape, fm, thr, seed in cases:
-        x = gen(kind, seed, shape)
-        x2d, _ = orc.flatten_2d(x)
-        avail = [f for f in ALL if f in fm]
-        mask = hb.fmt_mask(avail)
-        st = orc.tile_stats(x2d, avail)
-        slot = {f: avail.index(f) for f in avail}
-        sums = lambda f: st[:, 2 + 5 * slot[f]: 5 + 5 * slot[f]]
-        chain = np.concatenate([sums(fm[p]) - sums(fm[p - 1]) for p in range(1, len(fm))], axis=1)
-        base5 = np.concatenate([st[:, :2], sums(fm[0])], axis=1)
-        a_ref, c_ref, _ = hb.greedy_run(st, mask, fm, "pcc", thr, float(x.size), seed)
-        oa, _oc, _ost = orc.greedy(x, fm, "pcc", thr, seed)
-        assert np.array_equal(a_ref.reshape(oa.shape), oa)
-        bases = [base5] + ([np.ascontiguousarray(st[:, :2])] if fm[0] == "bf16" and kind == "normal_bf16" else [])   # bf16 of bf16-valued data is the identity
-        for base in bases:
-            maps, counts = hb.greedy_run_chain_batch(chain[None], base[None], fm, thr, float(x.size), [seed], 1)
-            assert np.array_equal(maps[0], a_ref.reshape(-1)), (kind, shape, fm, base.shape)
-            assert counts[0].tolist() == [int(c_ref[f]) for f in ALL]
-    # several equally sized tensors on several threads
-    fm, thr = ALL, 0.999
-    chains, bases, want, seeds = [], [], [], []
-    for seed in range(1, 7):
-        x = gen("normal_bf16", 100 + seed, (192, 160))
-        st = orc.tile_stats(x, ALL)
-        sums = lambda f: st[:, 2 + 5 * ALL.index(f): 5 + 5 * ALL.index(f)]
-        chains.append(np.concatenate([sums(fm[p]) - sums(fm[p - 1]) for p in range(1, 4)], axis=1))
-        bases.append(st[:, :2])
-        want.append(hb.greedy_run(st, 0xF, fm, "pcc", thr, float(x.size), seed)[0].reshape(-1))
-        seeds.append(seed)
-    maps, _counts = hb.greedy_run_chain_batch(np.stack(chains), np.stack(bases), fm, thr, float(192 * 160), seeds, 4)
-    assert np.array_equal(maps, np.stack(want))
-    with pytest.raises(hb.MtqError):
-        hb.greedy_run_chain_batch(np.stack(chains), np.stack(bases), ["bf16", "bfp8", "bfp8", "bfp2"], thr, 1.0, seeds, 1)
-
-
 def test_threshold_best_precision_and_order():
     # all tiles fail → highest-bytes format among the requested ones (mixed_tile_threshold.py:115-117)
     x = gen("heavy_f32", 3, (64, 64))

@@ -95,6 +95,26 @@ def test_wq_emulation_single_process(tmp_path, monkeypatch):
     assert cli.run(["synthetic:tiny", "zzz", "--results-dir", str(tmp_path / "r2")]) == 1
 
 
+def test_config0_wq_gpt2_c_attn_emulation(tmp_path, monkeypatch):
+    """BASELINE.json configs[0] as written: `wq gpt2 h.0.attn.c_attn.weight`, mixed-tile-greedy pcc >= 0.999, --backend emulation on the
+    CPU (offline: the synthetic:gpt2 preset holds the tensor's shape and storage type, 768 x 2304 float32).  The map is the oracle's
+    for seed 123 and the counts are the pinned 0 / 1461 / 267 / 0."""
+    monkeypatch.chdir(tmp_path)
+    rc = cli.run(["synthetic:gpt2", "h.0.attn.c_attn.weight", "--compression-config", str(ROOT / "compression_configs" / "greedy_seed123.json"),
+                  "--backend", "emulation", "--results-dir", str(tmp_path / "results"), "--no-plots"])
+    assert rc == 0
+    rdir = run_dir(tmp_path / "results")
+    idx = model_source.build_model_index("synthetic:gpt2")
+    names = model_source.resolve_selected_tensors(idx, "h.0.attn.c_attn.weight")
+    assert names == ["h.0.attn.c_attn.weight"]
+    check_maps_against_oracle(rdir, "mixed_tile_greedy", names, idx, lambda x: orc.greedy(x, ALL, "pcc", 0.999, 123)[0])
+    a = np.load(rdir / "mixed_tile_greedy" / cli._slug(names[0]) / "assignment.npy")
+    assert a.shape == (24, 72) and [int((a == i).sum()) for i in range(4)] == [0, 1461, 267, 0]
+    table = (rdir / "table.txt").read_text()
+    row = [ln for ln in table.splitlines() if ln.strip().startswith("mixed-tile-greedy")]
+    assert len(row) == 1 and row[0].split()[7:11] == ["0", "1461", "267", "0"] and row[0].split()[-1] == "1,764,687"   # BYTES = mixed_tile_total_bytes of the counts
+
+
 def test_wq_random_search_artifacts(tmp_path, monkeypatch):
     """mixed-tile-random through the CLI: table row, per-tensor CSV of the samples, the selected map and its mapping
     (wq:151-218); the map is the oracle's (i.e. the reference's) map for the same seed."""

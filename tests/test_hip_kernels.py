@@ -667,45 +667,6 @@ def test_device_copy_into_pinned_memory():
         hb.device_copy(dev_dst.t(), src2[:, 3:36].t())
 
 
-def test_chain_records_on_the_device(monkeypatch):
-    """mtq_pack_chain_records against NumPy on the same records (bit for bit: one subtraction per value), for the identity-bf16
-    layout (2-double side array) and stored-bf16 layouts (5 doubles); and the pipeline with chain records switched off gives the
-    maps it gives with them."""
-    from quantization_analysis_amd.pipeline import GreedyPipeline
-
-    for kind, shape, bf16, mask, fm in (("heavy_bf16", (96, 224), True, 0xE | hb.MASK_BF16_IDENTITY, ALL), ("heavy_f32", (160, 96), False, 0xF, ALL),
-                                        ("normal_bf16", (64, 128), True, 0xE | hb.MASK_BF16_IDENTITY, ["bfp8", "bfp2"]),
-                                        ("heavy_f32", (2080, 32), False, 0xF, ["bfp4", "bf16", "bfp8"])):
-        xs = np.stack([gen(kind, 40 + i, shape) for i in range(3)])
-        recs = hb.tile_stats_batched(dev(xs, bf16=bf16), mask & 0xF)
-        chain, base = hb.pack_chain_records(recs, mask, fm)
-        st = recs.cpu().numpy()
-        slots = {f: bin(mask & ((1 << ALL.index(f)) - 1) & 0xF).count("1") for f in ALL if mask >> ALL.index(f) & 1}
-
-        def sums(f):
-            if f in slots:
-                return st[:, :, 2 + 5 * slots[f]: 5 + 5 * slots[f]]
-            return np.stack([st[:, :, 0], st[:, :, 1], st[:, :, 1]], axis=2)      # the identity bf16
-
-        want_chain = np.concatenate([sums(fm[p]) - sums(fm[p - 1]) for p in range(1, len(fm))], axis=2)
-        identity_first = fm[0] == "bf16" and "bf16" not in slots
-        want_base = st[:, :, :2] if identity_first else np.concatenate([st[:, :, :2], sums(fm[0])], axis=2)
-        assert base.shape[2] == (2 if identity_first else 5)
-        assert np.array_equal(chain.cpu().numpy().view(np.uint64), want_chain.view(np.uint64)), (kind, fm)
-        assert np.array_equal(base.cpu().numpy().view(np.uint64), np.ascontiguousarray(want_base).view(np.uint64)), (kind, fm)
-    xs = dev(np.stack([gen("heavy_bf16", 60 + i, (128, 256)) for i in range(5)]), bf16=True)
-    got = {}
-    for flag in ("1", "0"):
-        monkeypatch.setenv("MTQ_CHAIN_RECORDS", flag)
-        pipe = GreedyPipeline(ALL, "pcc", 0.995, 123, chunk=2, workers=2, scan="host")
-        try:
-            got[flag] = pipe.run(xs, seeds=[3, 4, 5, 6, 7])
-        finally:
-            pipe.close()
-    for a, b in zip(got["1"], got["0"]):
-        assert np.array_equal(a.assignment, b.assignment) and a.counts == b.counts and (a.pcc, a.mae, a.atol) == (b.pcc, b.mae, b.atol)
-
-
 def test_fast_kernel_strided_view_and_batch_stride():
     """The exact-integer kernel on a column window of a wider matrix (ld > cols) and on a batch whose tensors are
     padded apart (stride > rows*cols): same records as the oracle on the dense copies."""
@@ -1065,6 +1026,7 @@ def test_lazy_pipeline_equals_whole_record_pipeline(monkeypatch):
     seeds at 2^63 and above are seeds too."""
     import torch
     from quantization_analysis_amd.pipeline import GreedyPipeline
+    from quantization_analysis_amd.settings import settings
 
     g = torch.Generator(device="cuda")
     g.manual_seed(3)
@@ -1075,6 +1037,7 @@ def test_lazy_pipeline_equals_whole_record_pipeline(monkeypatch):
     for lazy in ("1", "0"):
         monkeypatch.setenv("MTQ_LAZY", lazy)
         monkeypatch.setenv("MTQ_K1_TWO_LAUNCH", lazy)   # the whole-record run also takes K1 and its fix-up as one call
+        settings(refresh=True)                           # the switches are read once per process (quantization_analysis_amd/settings.py)
         for seeds in (None, [2**63 + 1, 5, 5, 2**64 - 1, 9, 123]):
             with GreedyPipeline(ALL, "pcc", 0.999, 2**63 + 12345, chunk=4, workers=2) as pipe:
                 assert (pipe.lazy_plan(xs) is not None) == (lazy == "1")
@@ -1092,6 +1055,7 @@ def test_lazy_pipeline_equals_whole_record_pipeline(monkeypatch):
     # a threshold most tiles pass down to the last format: the first batch lists nearly every tile, and the route switches itself off for that
     # tile count — same results from the lazy batch, the whole-record batches after it and the oracle
     monkeypatch.setenv("MTQ_LAZY", "1")
+    settings(refresh=True)
     with GreedyPipeline(ALL, "pcc", 0.9, 77, chunk=6, workers=2) as pipe:
         assert pipe.lazy_plan(xs) is not None
         first = pipe.run(xs)

@@ -158,6 +158,8 @@ def test_sweep_threaded_literal_chunks_equal_one_chunk(monkeypatch):
     want = sweep.sweep_tensor(x, ALL, "pcc", 0.9, 12, q)
     monkeypatch.setattr(sweep, "LITERAL_CHUNK_TILES", 16)
     monkeypatch.setenv("MTQ_SWEEP_THREADS", "6")
+    from quantization_analysis_amd.settings import settings
+    settings(refresh=True)
     got = sweep.sweep_tensor(x, ALL, "pcc", 0.9, 12, q)
     assert got[0] == want[0] and got[1] == want[1] and np.array_equal(got[2], want[2])
 

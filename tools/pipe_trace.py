@@ -19,10 +19,6 @@ marks = []
 def traced_scan(first, *a, **k):
     t0 = time.perf_counter(); r = orig_scan(first, *a, **k); marks.append(("scan", first, t0, time.perf_counter())); return r
 pl._scan_chunk = traced_scan
-orig_chain = pl._scan_chunk_chain
-def traced_chain(first, *a, **k):
-    t0 = time.perf_counter(); r = orig_chain(first, *a, **k); marks.append(("scan", first, t0, time.perf_counter())); return r
-pl._scan_chunk_chain = traced_chain
 orig_sync = torch.cuda.Event.synchronize
 def traced_sync(self):
     t0 = time.perf_counter(); orig_sync(self); marks.append(("evt", None, t0, time.perf_counter()))
