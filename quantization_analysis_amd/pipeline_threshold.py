@@ -1,0 +1,245 @@
+"""ThresholdPipeline — mixed-tile-threshold with the records on the device (see pipeline.py for the overview)."""
+from __future__ import annotations
+
+import concurrent.futures as cf
+import contextlib
+import os
+import time
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from . import hip_backend as hb
+from .compression_algorithms.tile_utils import MIXED_TILE_FORMATS, mixed_tile_total_bytes
+from .settings import settings
+from .pipeline_common import TensorResult, columns_from_sums_batch
+
+
+class ThresholdPipeline:
+    """mixed-tile-threshold over a (count, rows, cols) device tensor of equally shaped matrices, records never leaving
+    the GPU: per chunk K1 (batched) → K4 on the device over all of the chunk's tiles at once → map + knife-edge flags to
+    the host (2 B/tile) → the few knife-edge tiles re-scored with the literal float32 expression (as
+    compression_algorithms.mixed_tile_threshold does for one tensor) → patched maps back up → column sums on the device.
+    There is no host scan: the GPU is the pacing resource."""
+
+    def __init__(self, tile_formats=None, metric: str = "pcc", threshold: float = 0.999, chunk: int = 16, band: float = 2e-6, pure_formats=()):
+        import torch
+
+        from .compression_algorithms.quantizer import Quantizer
+
+        hb.require_gpu()
+        self.torch = torch
+        self.tile_formats = list(tile_formats or MIXED_TILE_FORMATS)
+        self.pure_formats = [f for f in pure_formats if f in self.tile_formats]
+        self.mask = hb.fmt_mask(self.tile_formats)
+        self.metric, self.threshold, self.band = metric, float(threshold), float(band)
+        self.chunk = int(chunk)
+        self.quantizer = Quantizer("hip")
+        self.knife_tiles = 0
+        self._side = torch.cuda.Stream()      # the knife-edge tiles' fetch and way home, beside the main stream's K1
+        self.knife_cap = settings().knife_cap   # knife-edge tiles per chunk fetched without a round trip (more: one extra trip)
+        self._pin = {}
+
+    def close(self) -> None:
+        """Drains the device and releases the pinned mirrors now (see GreedyPipeline.close)."""
+        self.torch.cuda.synchronize()
+        self._pin.clear()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
+
+    def _pinned(self, name: str, numel: int, dtype):
+        """Flat pinned host storage that only grows (a pinned allocation costs milliseconds)."""
+        t = self._pin.get(name)
+        if t is None or t.numel() < numel or t.dtype != dtype:
+            t = self.torch.zeros((int(numel * 1.25) + 16,), dtype=dtype, pin_memory=True)
+            self._pin[name] = t
+        return t[:numel]
+
+    def _knife_tiles_device(self, xc, idx, tiles: int, tiles_w: int):
+        """The knife-edge tiles' values and every format's reconstruction of them, on the device: `idx` holds flat (tensor·tiles + tile)
+        indices (device int64; entries < 0 are padding and read tile 0).  ONE indexed gather, K2 once per format → float32
+        (1 + formats, len(idx), 32, 32), plane 0 the tile itself (pads of ragged edge tiles zero, as the reference's padded view has them)."""
+        torch = self.torch
+        n, h, w = xc.shape
+        dev = xc.device
+        k = int(idx.numel())
+        flat_idx = idx.clamp(min=0)
+        j, t = flat_idx // tiles, flat_idx % tiles
+        ar = torch.arange(32, device=dev)
+        rows = (t // tiles_w)[:, None] * 32 + ar
+        cols = (t % tiles_w)[:, None] * 32 + ar
+        vals = xc[j[:, None, None], rows.clamp(max=h - 1)[:, :, None], cols.clamp(max=w - 1)[:, None, :]].float()
+        if h % 32 or w % 32:
+            inside = (rows < h)[:, :, None] & (cols < w)[:, None, :]
+            vals = torch.where(inside, vals, torch.zeros((), dtype=torch.float32, device=dev))
+        both = torch.empty((1 + len(self.tile_formats), k, 32, 32), dtype=torch.float32, device=dev)
+        both[0] = vals
+        flat = both[0].reshape(k * 32, 32)
+        for i, f in enumerate(self.tile_formats):
+            hb.quantize(flat, f, out=both[1 + i].reshape(k * 32, 32))
+        return both
+
+    def _decide(self, host_tiles: np.ndarray, old: np.ndarray, near: np.ndarray) -> np.ndarray:
+        """The reference's literal float32 tile score (tile_utils.py:46-57, here tile_utils.pearson_corr_tiles: the per-tile call's bits
+        at a third of its cost) for exactly the (tile, format) pairs inside the band, and the map values that follow
+        (mixed_tile_threshold.decide_knife_tiles, reference :117-123)."""
+        from .compression_algorithms.mixed_tile_threshold import decide_knife_tiles
+        from .compression_algorithms.tile_utils import tile_metrics
+
+        fmts = list(self.tile_formats)
+        x_tiles = host_tiles[0]
+
+        def literal_scores(fmt: str, sel: np.ndarray) -> np.ndarray:
+            return tile_metrics(x_tiles[sel], host_tiles[1 + fmts.index(fmt)][sel], self.metric)
+
+        return decide_knife_tiles(old, near.astype(np.uint8), self.tile_formats, self.metric, self.threshold, literal_scores)
+
+    def run(self, x3d, numel: int | None = None) -> list[TensorResult]:
+        """One batch (count, rows, cols): enqueue, decide, wrap."""
+        st = self.enqueue(x3d, numel)
+        self.decide(st)
+        self.torch.cuda.current_stream().synchronize()                                         # one wait for all chunks' sums
+        return self.wrap(st)
+
+    def run_batches(self, batches) -> list[list[TensorResult]]:
+        """Batches of ANY shapes and storage types — a model's shape groups, vectors as (ceil(n/32), 32) matrices with their element
+        count — as `(x3d, numel | None)` pairs or bare tensors, in three sweeps instead of a blocking run() per batch (the reference's
+        loop is per tensor, wq:655-706): every batch's K1, K4 and knife-edge listing are ENQUEUED first, back to back on the main
+        stream with the listings and their tiles' way home on the side stream; then, batch by batch, the host takes the maps and the
+        listed tiles (events: batch k's literal float32 decisions run while the GPU works on the batches behind it) and launches the
+        batch's column sums; one wait at the end, then the results are wrapped.  Every batch has its own pinned mirrors (slot = its
+        position).  Same results as run() per batch (tests/test_hip_kernels.py::test_threshold_run_batches_equals_run)."""
+        items = [(b, None) if not isinstance(b, (tuple, list)) else (b[0], b[1]) for b in batches]
+        states = [self.enqueue(x, n, slot=i, overlap=True) for i, (x, n) in enumerate(items)]
+        for st in states:
+            self.decide(st)
+        self.torch.cuda.current_stream().synchronize()
+        return [self.wrap(st) for st in states]
+
+    def enqueue(self, x3d, numel: int | None = None, slot: int = 0, overlap: bool = False) -> dict:
+        """GPU half of a batch, nothing waited for: per chunk K1 → K4 → map and knife-edge mask home → (side stream) the chunk's knife-edge
+        tiles listed, fetched, quantised in every format and sent home.  `slot` names the batch's pinned mirrors (batches in flight at
+        the same time need different slots); overlap: other batches follow before this one is decided (the listing then always takes the
+        side stream)."""
+        torch = self.torch
+        count, rows, cols = x3d.shape
+        dev = x3d.device
+        th, tw = hb.tiles_hw(rows, cols)
+        tiles, numel = th * tw, (rows * cols if numel is None else int(numel))
+        identity = x3d.dtype == torch.bfloat16 and (self.mask & 1) and (self.mask & 0xE)
+        k1_mask = self.mask & 0xE if identity else self.mask
+        dec_mask = k1_mask | hb.MASK_BF16_IDENTITY if identity else self.mask
+        P = 1 + len(self.pure_formats)
+        planes = 1 + len(self.tile_formats)
+        chunks = [(first, min(self.chunk, count - first)) for first in range(0, count, self.chunk)]
+        single = len(chunks) == 1 and not overlap
+        cap = min(self.knife_cap, self.chunk * tiles)
+        # pinned mirrors of what comes back (2 B per tile, each chunk's knife-edge list and tiles, then 7 sums per tensor):
+        # kernels store into them (hb.device_copy) and the driver waits on events, it never blocks in a pageable copy with the GPU idle
+        both_host = self._pinned(f"both{slot}", 2 * count * tiles, torch.int8).view(2, count * tiles)
+        idx_host = self._pinned(f"idx{slot}", len(chunks) * (cap + 1), torch.int64).view(len(chunks), cap + 1)
+        knife_host = self._pinned(f"knife{slot}", len(chunks) * planes * cap * 1024, torch.float32).view(len(chunks), planes, cap, 32, 32)
+        sums_host = self._pinned(f"sums{slot}", P * count * 7, torch.float64).view(P, count, 7)
+        both_dev = torch.empty((2, count * tiles), dtype=torch.int8, device=dev)             # row 0 the maps, row 1 the knife-edge masks
+        idx_dev = torch.empty((len(chunks), cap + 1), dtype=torch.int64, device=dev)
+        knife_dev = torch.empty((len(chunks), planes, cap, 32, 32), dtype=torch.float32, device=dev)
+        launched = []  # (first, n, records, chunk's tile range, map-landed event, knife-tiles-landed event)
+        for c, (first, n) in enumerate(chunks):
+            recs = hb.tile_stats_batched(x3d[first:first + n], k1_mask)                       # [n, tiles, rec] on the device
+            part = slice(first * tiles, (first + n) * tiles)
+            hb.threshold_assign_device_raw(recs.view(n * tiles, -1), dec_mask, self.tile_formats, self.metric, self.threshold, self.band,
+                                           out=(both_dev[0, part], both_dev[1, part]))
+            hb.device_copy(both_host[:, part], both_dev[:, part])
+            decided = torch.cuda.Event()
+            decided.record()
+            # the chunk's knife-edge tiles are found, fetched and quantised in every format on the device (mtq_knife_tiles_device: two
+            # launches), before the driver has seen its map — on a stream of their own, beside the next chunk's K1, not before it: what
+            # the host does later is the literal float32 score of a few dozen tiles, while the GPU works on the chunks behind.  (As ~25
+            # small torch launches per chunk this cost the driver thread more than K1 took.)  A batch of one chunk with nothing behind it has
+            # nothing to overlap with: its steps stay on the main stream (a cross-stream wait is a barrier packet, ≈ 0.1 ms per call all told)
+            # and only the list comes home; the listed tiles follow when the host has seen that there are any.
+            with (contextlib.nullcontext() if single else torch.cuda.stream(self._side)):
+                if not single:
+                    self._side.wait_event(decided)
+                hb.knife_tiles_device(x3d[first:first + n], both_dev[1, part], self.tile_formats, cap, idx_dev[c], knife_dev[c])
+                hb.device_copy(idx_host[c], idx_dev[c])
+                if cap and not single and not overlap:   # (run_batches: the whole cap-sized buffer — 2.6 MB — per batch of a few thousand tiles cost more than its K1; the listed tiles follow on demand)
+                    hb.device_copy(knife_host[c], knife_dev[c])
+                landed = torch.cuda.Event()
+                landed.record()
+            launched.append((first, n, recs, part, decided, landed))
+        return {"x": x3d, "tiles_sent": bool(cap and not single and not overlap), "numel": numel, "hw": (th, tw), "tiles": tiles, "dec_mask": dec_mask, "cap": cap, "single": single, "planes": planes,
+                "launched": launched, "both_host": both_host, "idx_host": idx_host, "knife_host": knife_host, "sums_host": sums_host,
+                "both_dev": both_dev, "idx_dev": idx_dev, "knife_dev": knife_dev, "maps": np.empty((count, tiles), dtype=np.int8)}
+
+    def decide(self, st: dict) -> None:
+        """Host half, part 1: per chunk the map and the listed tiles (events), the literal float32 decisions of the knife-edge tiles
+        (mixed_tile_threshold.py:117-123 on the reference's own score), the patched map back up, the column sums launched and sent home."""
+        torch = self.torch
+        x3d, tiles, cap, planes, dec_mask = st["x"], st["tiles"], st["cap"], st["planes"], st["dec_mask"]
+        dev = x3d.device
+        tw = st["hw"][1]
+        both_host, idx_host, knife_host, sums_host = st["both_host"], st["idx_host"], st["knife_host"], st["sums_host"]
+        both_dev, idx_dev, knife_dev, maps_all = st["both_dev"], st["idx_dev"], st["knife_dev"], st["maps"]
+        scratch_n = int(hb.lib().mtq_columns_scratch_doubles())
+        P = 1 + len(self.pure_formats)
+        for c, (first, n, recs, part, decided, landed) in enumerate(st["launched"]):
+            landed.synchronize()      # the chunk's list is home ...
+            decided.synchronize()     # ... and its map (recorded earlier: passed by now unless the list took the side stream)
+            maps_all[first:first + n] = both_host[0, part].numpy().reshape(n, tiles)           # the mirror is reused by the slot's next batch
+            k = int(idx_host[c, cap])
+            if k:
+                near = both_host[1, part].numpy()
+                if k <= cap:
+                    flat = idx_host[c, :k].numpy().copy()                                      # the list is in no particular order: ids travel with their tiles
+                    if not st["tiles_sent"]:                                                   # the tiles were not sent with the list
+                        home = knife_host[c].reshape(-1)[:planes * k * 1024].view(planes, k, 32, 32)
+                        hb.device_copy(home, knife_dev[c, :, :k].contiguous())
+                        torch.cuda.current_stream().synchronize()
+                        host_tiles = home.numpy()
+                    else:
+                        host_tiles = knife_host[c, :, :k].numpy()
+                    where = idx_dev[c, :k]
+                else:                                                                          # more than the list holds: the same steps, one more trip
+                    flat = np.flatnonzero(near).astype(np.int64)
+                    where = torch.from_numpy(flat).to(dev)
+                    host_tiles = self._knife_tiles_device(x3d[first:first + n], where, tiles, tw).cpu().numpy()
+                mchunk = maps_all[first:first + n].reshape(-1)
+                new = self._decide(host_tiles, mchunk[flat], near[flat])
+                mchunk[flat] = new
+                both_dev[0, part].index_put_((where,), torch.from_numpy(np.ascontiguousarray(new, dtype=np.int8)).to(dev, non_blocking=True))
+                self.knife_tiles += k
+            dmaps = both_dev[0, part].view(n, tiles)
+            scratch = torch.empty((P, n, scratch_n), dtype=torch.float64, device=dev)
+            hb.check(hb.lib().mtq_column_sums_device_batched(recs.data_ptr(), n, tiles, dec_mask, dmaps.data_ptr(), scratch[0].data_ptr(), hb._stream_ptr()))
+            for q, f in enumerate(self.pure_formats):   # wq's `none` rows from the same records
+                pm = torch.full((n, tiles), MIXED_TILE_FORMATS.index(f), dtype=torch.int8, device=dev)
+                hb.check(hb.lib().mtq_column_sums_device_batched(recs.data_ptr(), n, tiles, dec_mask, pm.data_ptr(), scratch[1 + q].data_ptr(), hb._stream_ptr()))
+            for q in range(P):
+                hb.device_copy(sums_host[q, first:first + n], scratch[q, :, :7])
+
+    def wrap(self, st: dict) -> list[TensorResult]:
+        """Host half, part 2 (behind a wait for the main stream): counts from the host's copy of the maps (np.bincount per tensor — what the
+        reference does, mixed_tile_threshold.py:133-135), the columns from the seven sums."""
+        th, tw = st["hw"]
+        numel, maps_all = st["numel"], st["maps"]
+        count = maps_all.shape[0]
+        nf = len(MIXED_TILE_FORMATS)
+        k = {"pcc": 0, "mae": 1, "atol": 2}[self.metric]
+        sums = st["sums_host"].numpy()
+        cols = columns_from_sums_batch(sums[0], float(numel))
+        pure_cols = [columns_from_sums_batch(sums[1 + i], float(numel)) for i in range(len(self.pure_formats))]
+        results: list[TensorResult] = []
+        for j in range(count):
+            bc = np.bincount(maps_all[j].view(np.uint8), minlength=nf)
+            counts = {f: int(bc[i]) for i, f in enumerate(MIXED_TILE_FORMATS)}
+            pure = {f: tuple(float(v) for v in pure_cols[i][j]) for i, f in enumerate(self.pure_formats)} or None
+            results.append(TensorResult(j, maps_all[j].reshape(th, tw), counts, mixed_tile_total_bytes(counts), float(cols[j, 0]),
+                                        float(cols[j, 1]), float(cols[j, 2]), float(cols[j, k]), pure))
+        st["x"] = None
+        return results

@@ -2,7 +2,7 @@
 import sys, time
 sys.path.insert(0, '/root/repo')
 import torch
-from quantization_analysis_amd import hip_backend as hb, pipeline as pl
+from quantization_analysis_amd import hip_backend as hb, pipeline as pl, pipeline_greedy as plg   # plg: where the host-scan task lives (patched below)
 import bench
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 128
@@ -14,11 +14,11 @@ pipe = pl.GreedyPipeline(bench.FORMATS, bench.METRIC, bench.THRESHOLD, bench.SEE
 for _ in range(2): pipe.run(batch)
 torch.cuda.synchronize()
 
-orig_scan = pl._scan_chunk
+orig_scan = plg._scan_chunk
 marks = []
 def traced_scan(first, *a, **k):
     t0 = time.perf_counter(); r = orig_scan(first, *a, **k); marks.append(("scan", first, t0, time.perf_counter())); return r
-pl._scan_chunk = traced_scan
+plg._scan_chunk = traced_scan
 orig_sync = torch.cuda.Event.synchronize
 def traced_sync(self):
     t0 = time.perf_counter(); orig_sync(self); marks.append(("evt", None, t0, time.perf_counter()))

@@ -2,17 +2,17 @@
 import sys, time, gc
 sys.path.insert(0, '/root/repo')
 import torch
-from quantization_analysis_amd import hip_backend as hb, pipeline as pl
+from quantization_analysis_amd import hip_backend as hb, pipeline as pl, pipeline_greedy as plg   # plg: where the host-scan task lives (patched below)
 import bench
 hb.require_gpu()
 batch = bench.make_batch(128, 0, torch.device('cuda', 0))
 pipe = pl.GreedyPipeline(bench.FORMATS, bench.METRIC, bench.THRESHOLD, bench.SEED, chunk=16, workers=13)
 pipe.reserve(batch)
 marks = []
-orig_scan = pl._scan_chunk
+orig_scan = plg._scan_chunk
 def traced_scan(first, *a, **k):
     t0 = time.perf_counter(); r = orig_scan(first, *a, **k); marks.append(("scan", first, t0, time.perf_counter())); return r
-pl._scan_chunk = traced_scan
+plg._scan_chunk = traced_scan
 orig_sync = torch.cuda.Event.synchronize
 def traced_sync(self):
     t0 = time.perf_counter(); orig_sync(self); marks.append(("evt", None, t0, time.perf_counter()))

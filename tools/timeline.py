@@ -3,7 +3,7 @@ arrival and scan completion per chunk — where the step period comes from."""
 import sys, time
 sys.path.insert(0, '/root/repo')
 import torch, gc
-from quantization_analysis_amd import hip_backend as hb, pipeline as pl
+from quantization_analysis_amd import hip_backend as hb, pipeline as pl, pipeline_greedy as plg   # plg: where the host-scan task lives (patched below)
 import bench
 hb.require_gpu(); hb.bind_to_gpu_numa_node(0)
 batch = bench.make_batch(128, 0, torch.device('cuda', 0))
@@ -18,10 +18,10 @@ def wrap(obj, name, label):
         t0 = time.perf_counter(); r = f(*a, **k); marks.append((label, t0, time.perf_counter())); return r
     setattr(obj, name, g)
 wrap(pipe, "enqueue", "main enqueue"); wrap(pipe, "finish", "main finish"); wrap(pipe, "_launch_columns", "main   columns"); wrap(pipe, "resolve", "main resolve")
-orig_scan = pl._scan_chunk
+orig_scan = plg._scan_chunk
 def traced_scan(first, *a, **k):
     t0 = time.perf_counter(); r = orig_scan(first, *a, **k); marks.append((f"scan chunk@{first}", t0, time.perf_counter())); return r
-pl._scan_chunk = traced_scan
+plg._scan_chunk = traced_scan
 orig_sync = torch.cuda.Event.synchronize
 def traced_sync(self):
     t0 = time.perf_counter(); orig_sync(self); marks.append(("main   wait records", t0, time.perf_counter()))
