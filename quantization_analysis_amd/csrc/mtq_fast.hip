@@ -839,8 +839,7 @@ extern "C" int mtq_launch_tile_stats_bf16_fast(const void *x, int64_t count, int
     case 0x01: MTQ_LAUNCH_FAST(1u, 0u); break;           // partial records: the last evaluated format without Σ|x−y|, max|x−y|
     case 0x02: MTQ_LAUNCH_FAST(2u, 0u); break;
     case 0x13: MTQ_LAUNCH_FAST(3u, 1u); break;
-    default:                                             // no BFP format evaluated: the launcher's callers never ask for that
-        work_counter_abandon(*work_out);
+    default:                                             // no BFP format evaluated: the launcher's callers never ask for that (they abandon the slot on any error: once, there)
         return fail(MTQ_ERR_INVALID, "the bf16 fast kernel needs at least one BFP format to evaluate");
     }
 #undef MTQ_LAUNCH_FAST

@@ -805,11 +805,15 @@ namespace {
 class ScanPool {
 public:
     static ScanPool &instance() { static ScanPool *p = new ScanPool(); return *p; }
+    // Every GENERATION of workers has its own stop flag (captured by its threads): shutdown() retires the current generation and
+    // joins it, and an ensure() racing with that join starts a new generation instead of clearing the flag the retiring threads are
+    // about to read (one shared flag: they went back to sleep and the join never returned).
     void ensure(int n)
     {
         std::lock_guard<std::mutex> lock(mu_);
-        stop_ = false;
-        while ((int)threads_.size() < n) threads_.emplace_back([this] { loop(); });
+        if (!gen_) gen_ = std::make_shared<std::atomic<bool>>(false);
+        auto gen = gen_;
+        while ((int)threads_.size() < n) threads_.emplace_back([this, gen] { loop(gen); });
     }
     void submit(std::function<void()> fn)
     {
@@ -821,21 +825,22 @@ public:
         std::vector<std::thread> mine;
         {
             std::lock_guard<std::mutex> lock(mu_);
-            stop_ = true;
+            if (gen_) gen_->store(true);
+            gen_.reset();                                    // the next ensure() starts a fresh generation
             mine.swap(threads_);
         }
         cv_.notify_all();
         for (auto &t : mine) if (t.joinable()) t.join();
     }
 private:
-    void loop()
+    void loop(std::shared_ptr<std::atomic<bool>> stop)
     {
         for (;;) {
             std::function<void()> fn;
             {
                 std::unique_lock<std::mutex> lock(mu_);
-                cv_.wait(lock, [this] { return stop_ || !queue_.empty(); });
-                if (queue_.empty()) return;              // stop_ and nothing left to do
+                cv_.wait(lock, [&] { return stop->load() || !queue_.empty(); });
+                if (queue_.empty()) return;              // retired and nothing left to do
                 fn = std::move(queue_.front());
                 queue_.pop_front();
             }
@@ -846,7 +851,7 @@ private:
     std::condition_variable cv_;
     std::deque<std::function<void()>> queue_;
     std::vector<std::thread> threads_;
-    bool stop_ = false;
+    std::shared_ptr<std::atomic<bool>> gen_;
 };
 
 struct BatchState {

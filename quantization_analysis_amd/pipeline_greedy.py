@@ -358,7 +358,11 @@ class GreedyPipeline:
                 e0.record(self.stream)
                 # bf16 storage in whole 32x128 units: K1 as the exact-integer kernel alone (it resets its own unit counters), its literal
                 # fix-up — usually nothing to do — on the search stream: nothing sits between two K1 launches on this stream
-                two_launch = x3d.dtype == torch.bfloat16 and (k1_mask & 1) == 0 and rows % 32 == 0 and cols % 128 == 0 and settings().k1_two_launch
+                # (what mtq_tile_stats_partial_begin takes: 16-byte aligned rows of every tensor of the chunk, and no MTQ_FORCE_GENERIC — anything
+                # else goes through the one-call forms below, which pick the generic / direct kernel themselves)
+                two_launch = (x3d.dtype == torch.bfloat16 and (k1_mask & 1) == 0 and rows % 32 == 0 and cols % 128 == 0 and settings().k1_two_launch
+                              and x3d.data_ptr() % 16 == 0 and (x3d.stride(0) * 2) % 16 == 0 and (x3d.stride(1) * 2) % 16 == 0
+                              and os.environ.get("MTQ_FORCE_GENERIC", "0") != "1")
                 k1_id = None
                 if two_launch:
                     k1_id = hb.tile_stats_partial_begin(x3d[first:first + n], k1_mask, full_now if lazy else k1_mask, prev_bit if lazy else 0,

@@ -2,6 +2,7 @@
 on the same seeded inputs and against the committed golden vectors.  Bit-exact bar for y bits, stats
 records (float64, identical summation order) and assignment maps."""
 import json
+from pathlib import Path
 
 import numpy as np
 import pytest
@@ -1065,3 +1066,28 @@ def test_lazy_pipeline_equals_whole_record_pipeline(monkeypatch):
         assert np.array_equal(r1.assignment, r2.assignment) and r1.counts == r2.counts and (r1.pcc, r1.mae, r1.atol) == (r2.pcc, r2.mae, r2.atol)
     a, counts, _st = orc.greedy(x0, ALL, "pcc", 0.9, 77)
     assert np.array_equal(first[0].assignment, a) and first[0].counts == counts
+
+
+def test_pipeline_under_force_generic_switch():
+    """MTQ_FORCE_GENERIC=1 (the A/B switch that sends every K1 through the literal kernel; read once per process by the library, hence a
+    subprocess): GreedyPipeline must not take the two-launch form the exact kernel's entry point refuses then — same maps as the oracle."""
+    import os
+    import subprocess
+    import sys
+
+    code = (
+        "import numpy as np, torch\n"
+        "from oracle import mtq_oracle as orc\n"
+        "from quantization_analysis_amd.pipeline import GreedyPipeline\n"
+        "from tests.inputs import gen\n"
+        "xs = np.stack([gen('normal_bf16', 40 + i, (64, 256)) for i in range(3)])\n"
+        "x = torch.from_numpy(xs).cuda().to(torch.bfloat16)\n"
+        "with GreedyPipeline(['bf16', 'bfp8', 'bfp4', 'bfp2'], 'pcc', 0.999, 123, chunk=2, workers=2) as pipe:\n"
+        "    res = pipe.run(x)\n"
+        "for i, r in enumerate(res):\n"
+        "    a, c, _ = orc.greedy(xs[i], ['bf16', 'bfp8', 'bfp4', 'bfp2'], 'pcc', 0.999, 123)\n"
+        "    assert np.array_equal(r.assignment, a) and r.counts == c, i\n"
+        "print('ok')\n")
+    env = dict(os.environ, MTQ_FORCE_GENERIC="1")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env, cwd=str(Path(__file__).resolve().parent.parent))
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stderr[-2000:]
