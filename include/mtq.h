@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define MTQ_VERSION 141 /* 0.1.4.1: + partial / listed K1 (mtq_tile_stats_partial, mtq_tile_stats_listed), the search in phases with shared visiting orders, mtq_shutdown, mtq_knife_tiles_device */
+#define MTQ_VERSION 142 /* 0.1.4.2: - chain records, + mtq_threshold_enqueue / _columns; 0.1.4.1: + partial / listed K1 (mtq_tile_stats_partial, mtq_tile_stats_listed), the search in phases with shared visiting orders, mtq_shutdown, mtq_knife_tiles_device */
 
 typedef enum {
     MTQ_OK = 0,
@@ -342,6 +342,22 @@ int mtq_scan_orders_device(uint64_t seed, int64_t tiles, int n_orders, void *ord
  * (tiles_out 16-byte aligned). */
 int mtq_knife_tiles_device(const void *x, int in_dtype, int64_t count, int64_t stride_elems, int64_t rows, int64_t cols, int64_t ld,
                            const int8_t *near, const int *formats, int n_formats, int64_t cap, int64_t *list, float *tiles_out, void *stream);
+
+/* One batch of the streamed threshold driver as ONE call (round 4: behind Python every launch costs the driver 10–20 us, and a model's
+ * small tensors — DeepSeek-R1 layer 0: seven tensors, 183 k tiles, 0.45 ms of K1 — were launch-bound at a dozen calls per batch):
+ * mtq_tile_stats_batched(k1_mask) → mtq_threshold_assign_device(dec_mask: k1_mask, or k1_mask | MTQ_MASK_BF16_IDENTITY) into
+ * both_dev[0 .. T) (maps) and both_dev[T .. 2T) (knife-edge masks), T = count * tiles → both of them into the pinned mirror both_host
+ * (mtq_device_copy_2d) on `stream`; then, behind an event, on `side_stream` (NULL: on `stream`): mtq_knife_tiles_device(cap) and the list
+ * (cap + 1 int64) into the pinned list_host.  Replaces the per-tensor body of wq:655-706 / mixed_tile_threshold.py:97-123 up to the
+ * knife-edge decisions.  Everything asynchronous; the caller waits for an event of its own behind the call. */
+int mtq_threshold_enqueue(const void *x, int in_dtype, int64_t count, int64_t stride_elems, int64_t rows, int64_t cols, int64_t ld,
+                          uint32_t k1_mask, uint32_t dec_mask, const int *formats, int n_formats, int metric, double threshold, double band,
+                          double *stats, int8_t *both_dev, int8_t *both_host, int64_t cap, int64_t *list_dev, float *knife_dev,
+                          int64_t *list_host, void *stream, void *side_stream);
+/* … and its second half: mtq_column_sums_device_batched under the (patched) maps, the seven sums of every tensor into the pinned
+ * sums_host[count][7] (wq:683-706's columns come from them: mtq_columns_from_sums). */
+int mtq_threshold_columns(const double *stats, int64_t count, int64_t tiles, uint32_t dec_mask, const int8_t *maps_dev, double *scratch,
+                          double *sums_host, void *stream);
 
 /* Results home without a copy engine (no reference counterpart: the reference's arrays are host arrays).  A kernel copies `rows` rows
  * of `width_bytes` bytes from src (pitch src_pitch) to dst (pitch dst_pitch) on `stream`; dst may be pinned host memory

@@ -160,3 +160,37 @@ extern "C" int mtq_column_sums_device(const double *stats, int64_t tiles, uint32
     return mtq_column_sums_device_batched(stats, 1, tiles, fmt_mask, map, scratch, stream);
 }
 
+// One batch of the streamed threshold driver as one call (include/mtq.h): the launches ThresholdPipeline.enqueue issued one by one.
+extern "C" int mtq_threshold_enqueue(const void *x, int in_dtype, int64_t count, int64_t stride_elems, int64_t rows, int64_t cols, int64_t ld,
+                                     uint32_t k1_mask, uint32_t dec_mask, const int *formats, int n_formats, int metric, double threshold, double band,
+                                     double *stats, int8_t *both_dev, int8_t *both_host, int64_t cap, int64_t *list_dev, float *knife_dev,
+                                     int64_t *list_host, void *stream, void *side_stream)
+{
+    if (!x || !formats || !stats || !both_dev || !both_host || !list_dev || !list_host) return fail(MTQ_ERR_INVALID, "null argument");
+    if (count <= 0 || rows <= 0 || cols <= 0 || cap < 0) return fail(MTQ_ERR_INVALID, "count, rows, cols must be positive and cap non-negative");
+    const int64_t tiles = ((rows + 31) / 32) * ((cols + 31) / 32), T = count * tiles;
+    if (int rc = mtq_tile_stats_batched(x, in_dtype, count, stride_elems, rows, cols, ld, k1_mask, stats, stream)) return rc;
+    if (int rc = mtq_threshold_assign_device(stats, T, dec_mask, formats, n_formats, metric, threshold, band, both_dev,
+                                             reinterpret_cast<uint8_t *>(both_dev + T), stream)) return rc;
+    if (int rc = mtq_device_copy_2d(both_host, (size_t)(2 * T), both_dev, (size_t)(2 * T), (size_t)(2 * T), 1, stream)) return rc;
+    hipStream_t main_s = static_cast<hipStream_t>(stream), side = side_stream ? static_cast<hipStream_t>(side_stream) : main_s;
+    if (side != main_s) {   // the listing waits for the masks; the event's resources go when it has completed
+        hipEvent_t ev;
+        if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return fail(MTQ_ERR_HIP, "hipEventCreate failed");
+        const bool ok = hipEventRecord(ev, main_s) == hipSuccess && hipStreamWaitEvent(side, ev, 0) == hipSuccess;
+        (void)hipEventDestroy(ev);
+        if (!ok) return fail(MTQ_ERR_HIP, "could not order the side stream behind the masks");
+    }
+    if (int rc = mtq_knife_tiles_device(x, in_dtype, count, stride_elems, rows, cols, ld, both_dev + T, formats, n_formats, cap, list_dev,
+                                        cap ? knife_dev : nullptr, side)) return rc;
+    return mtq_device_copy_2d(list_host, (size_t)(cap + 1) * 8, list_dev, (size_t)(cap + 1) * 8, (size_t)(cap + 1) * 8, 1, side);
+}
+
+extern "C" int mtq_threshold_columns(const double *stats, int64_t count, int64_t tiles, uint32_t dec_mask, const int8_t *maps_dev, double *scratch,
+                                     double *sums_host, void *stream)
+{
+    if (!sums_host) return fail(MTQ_ERR_INVALID, "null argument");
+    if (int rc = mtq_column_sums_device_batched(stats, count, tiles, dec_mask, maps_dev, scratch, stream)) return rc;
+    const size_t pitch = mtq_columns_scratch_doubles() * sizeof(double);
+    return mtq_device_copy_2d(sums_host, 7 * sizeof(double), scratch, pitch, 7 * sizeof(double), (size_t)count, stream);
+}

@@ -32,7 +32,7 @@ EXPORTS = [
     "mtq_threshold_assign_device", "mtq_columns_scratch_doubles", "mtq_column_sums_device", "mtq_column_sums_device_batched",
     "mtq_rng_create", "mtq_rng_permutation", "mtq_rng_integers", "mtq_rng_destroy", "mtq_greedy_run", "mtq_greedy_run_batch",
     "mtq_selftest_slot_ring", "mtq_device_copy_2d", "mtq_knife_tiles_device", "mtq_greedy_scan_scratch_bytes", "mtq_greedy_scan_device", "mtq_greedy_scan_device_ex", "mtq_scan_carry_bytes",
-    "mtq_scan_orders_bytes", "mtq_scan_orders_device", "mtq_debug_scan_ticks",
+    "mtq_scan_orders_bytes", "mtq_scan_orders_device", "mtq_debug_scan_ticks", "mtq_threshold_enqueue", "mtq_threshold_columns",
 ]
 
 
@@ -122,6 +122,8 @@ def lib() -> ctypes.CDLL:
     L.mtq_selftest_slot_ring.restype = ci
     L.mtq_device_copy_2d.argtypes = [vp, ctypes.c_size_t, vp, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_size_t, vp]
     L.mtq_knife_tiles_device.argtypes = [vp, ci, i64, i64, i64, i64, i64, vp, vp, ci, i64, vp, vp, vp]
+    L.mtq_threshold_enqueue.argtypes = [vp, ci, i64, i64, i64, i64, i64, u32, u32, vp, ci, ci, dbl, dbl, vp, vp, vp, i64, vp, vp, vp, vp, vp]
+    L.mtq_threshold_columns.argtypes = [vp, i64, i64, u32, vp, vp, vp, vp]
     if L.mtq_version() < 141:
         raise MtqError("libmtq_hip.so is older than this package")
     _lib = L

@@ -3,6 +3,7 @@ from __future__ import annotations
 
 import concurrent.futures as cf
 import contextlib
+import ctypes
 import os
 import time
 from dataclasses import dataclass, field
@@ -39,11 +40,13 @@ class ThresholdPipeline:
         self._side = torch.cuda.Stream()      # the knife-edge tiles' fetch and way home, beside the main stream's K1
         self.knife_cap = settings().knife_cap   # knife-edge tiles per chunk fetched without a round trip (more: one extra trip)
         self._pin = {}
+        self._dev = {}
 
     def close(self) -> None:
         """Drains the device and releases the pinned mirrors now (see GreedyPipeline.close)."""
         self.torch.cuda.synchronize()
         self._pin.clear()
+        self._dev.clear()
 
     def __enter__(self):
         return self
@@ -51,6 +54,15 @@ class ThresholdPipeline:
     def __exit__(self, *exc):
         self.close()
         return False
+
+    def _devbuf(self, name: str, numel: int, dtype, device):
+        """Flat device storage that only grows, by name (a batch's maps, lists, records: an allocator call per batch and buffer was a
+        sizeable part of the driver's time on small batches)."""
+        t = self._dev.get(name)
+        if t is None or t.numel() < numel or t.dtype != dtype or t.device != device:
+            t = self.torch.empty((int(numel * 1.25) + 16,), dtype=dtype, device=device)
+            self._dev[name] = t
+        return t[:numel]
 
     def _pinned(self, name: str, numel: int, dtype):
         """Flat pinned host storage that only grows (a pinned allocation costs milliseconds)."""
@@ -145,35 +157,48 @@ class ThresholdPipeline:
         idx_host = self._pinned(f"idx{slot}", len(chunks) * (cap + 1), torch.int64).view(len(chunks), cap + 1)
         knife_host = self._pinned(f"knife{slot}", len(chunks) * planes * cap * 1024, torch.float32).view(len(chunks), planes, cap, 32, 32)
         sums_host = self._pinned(f"sums{slot}", P * count * 7, torch.float64).view(P, count, 7)
-        both_dev = torch.empty((2, count * tiles), dtype=torch.int8, device=dev)             # row 0 the maps, row 1 the knife-edge masks
-        idx_dev = torch.empty((len(chunks), cap + 1), dtype=torch.int64, device=dev)
-        knife_dev = torch.empty((len(chunks), planes, cap, 32, 32), dtype=torch.float32, device=dev)
+        both_dev = self._devbuf(f"both{slot}", 2 * count * tiles, torch.int8, dev).view(2, count * tiles)   # row 0 the maps, row 1 the knife-edge masks
+        idx_dev = self._devbuf(f"idx{slot}", len(chunks) * (cap + 1), torch.int64, dev).view(len(chunks), cap + 1)
+        knife_dev = self._devbuf(f"knife{slot}", len(chunks) * planes * cap * 1024, torch.float32, dev).view(len(chunks), planes, cap, 32, 32)
+        rec = hb.record_doubles(k1_mask)
+        recs_all = self._devbuf(f"recs{slot}", count * tiles * rec, torch.float64, dev).view(count, tiles, rec)
+        fm = (ctypes.c_int * len(self.tile_formats))(*[MIXED_TILE_FORMATS.index(f) for f in self.tile_formats])
+        main_ptr = torch.cuda.current_stream().cuda_stream
         launched = []  # (first, n, records, chunk's tile range, map-landed event, knife-tiles-landed event)
         for c, (first, n) in enumerate(chunks):
-            recs = hb.tile_stats_batched(x3d[first:first + n], k1_mask)                       # [n, tiles, rec] on the device
+            # ONE call per chunk (mtq_threshold_enqueue): K1 → K4 → map and knife-edge masks into the pinned mirror on the main stream; then,
+            # behind an event, the chunk's knife-edge tiles found, fetched and quantised in every format (mtq_knife_tiles_device) and their list
+            # sent home — on the side stream, beside the next chunk's K1, unless the batch is a single chunk with nothing behind it (a
+            # cross-stream wait is a barrier packet).  As a dozen Python-level launches per chunk this cost the driver 10–20 us each: the
+            # seven DeepSeek layer-0 tensors were launch-bound at 1.7 ms for 0.45 ms of K1.  The listed tiles themselves follow on demand.
+            xs = x3d[first:first + n]
+            recs = recs_all[first:first + n]
             part = slice(first * tiles, (first + n) * tiles)
-            hb.threshold_assign_device_raw(recs.view(n * tiles, -1), dec_mask, self.tile_formats, self.metric, self.threshold, self.band,
-                                           out=(both_dev[0, part], both_dev[1, part]))
-            hb.device_copy(both_host[:, part], both_dev[:, part])
-            decided = torch.cuda.Event()
-            decided.record()
-            # the chunk's knife-edge tiles are found, fetched and quantised in every format on the device (mtq_knife_tiles_device: two
-            # launches), before the driver has seen its map — on a stream of their own, beside the next chunk's K1, not before it: what
-            # the host does later is the literal float32 score of a few dozen tiles, while the GPU works on the chunks behind.  (As ~25
-            # small torch launches per chunk this cost the driver thread more than K1 took.)  A batch of one chunk with nothing behind it has
-            # nothing to overlap with: its steps stay on the main stream (a cross-stream wait is a barrier packet, ≈ 0.1 ms per call all told)
-            # and only the list comes home; the listed tiles follow when the host has seen that there are any.
-            with (contextlib.nullcontext() if single else torch.cuda.stream(self._side)):
-                if not single:
-                    self._side.wait_event(decided)
-                hb.knife_tiles_device(x3d[first:first + n], both_dev[1, part], self.tile_formats, cap, idx_dev[c], knife_dev[c])
-                hb.device_copy(idx_host[c], idx_dev[c])
-                if cap and not single and not overlap:   # (run_batches: the whole cap-sized buffer — 2.6 MB — per batch of a few thousand tiles cost more than its K1; the listed tiles follow on demand)
-                    hb.device_copy(knife_host[c], knife_dev[c])
+            if len(chunks) > 1:
+                # several chunks: a chunk's maps and masks are not adjacent in the batch's [2, T] arrays — the calls one by one
+                hb.tile_stats_batched(xs, k1_mask, out=recs)
+                hb.threshold_assign_device_raw(recs.view(n * tiles, -1), dec_mask, self.tile_formats, self.metric, self.threshold, self.band,
+                                               out=(both_dev[0, part], both_dev[1, part]))
+                hb.device_copy(both_host[:, part], both_dev[:, part])
+                decided = torch.cuda.Event()
+                decided.record()
+                with (contextlib.nullcontext() if single else torch.cuda.stream(self._side)):
+                    if not single:
+                        self._side.wait_event(decided)
+                    hb.knife_tiles_device(xs, both_dev[1, part], self.tile_formats, cap, idx_dev[c], knife_dev[c])
+                    hb.device_copy(idx_host[c], idx_dev[c])
+                    landed = torch.cuda.Event()
+                    landed.record()
+            else:
+                hb.check(hb.lib().mtq_threshold_enqueue(
+                    xs.data_ptr(), hb._dtype_code(xs), n, xs.stride(0) if n > 1 else rows * xs.stride(1), rows, cols, xs.stride(1), k1_mask, dec_mask, fm,
+                    len(self.tile_formats), hb.METRIC_CODE[self.metric], self.threshold, self.band, recs.data_ptr(), both_dev.data_ptr(), both_host.data_ptr(),
+                    cap, idx_dev[c].data_ptr(), knife_dev[c].data_ptr(), idx_host[c].data_ptr(), main_ptr, None if single else self._side.cuda_stream))
                 landed = torch.cuda.Event()
-                landed.record()
+                landed.record(torch.cuda.current_stream() if single else self._side)
+                decided = landed      # the side stream runs behind the masks' copy: one event covers both
             launched.append((first, n, recs, part, decided, landed))
-        return {"x": x3d, "tiles_sent": bool(cap and not single and not overlap), "numel": numel, "hw": (th, tw), "tiles": tiles, "dec_mask": dec_mask, "cap": cap, "single": single, "planes": planes,
+        return {"x": x3d, "tiles_sent": False, "slot": slot, "numel": numel, "hw": (th, tw), "tiles": tiles, "dec_mask": dec_mask, "cap": cap, "single": single, "planes": planes,
                 "launched": launched, "both_host": both_host, "idx_host": idx_host, "knife_host": knife_host, "sums_host": sums_host,
                 "both_dev": both_dev, "idx_dev": idx_dev, "knife_dev": knife_dev, "maps": np.empty((count, tiles), dtype=np.int8)}
 
@@ -215,13 +240,12 @@ class ThresholdPipeline:
                 both_dev[0, part].index_put_((where,), torch.from_numpy(np.ascontiguousarray(new, dtype=np.int8)).to(dev, non_blocking=True))
                 self.knife_tiles += k
             dmaps = both_dev[0, part].view(n, tiles)
-            scratch = torch.empty((P, n, scratch_n), dtype=torch.float64, device=dev)
-            hb.check(hb.lib().mtq_column_sums_device_batched(recs.data_ptr(), n, tiles, dec_mask, dmaps.data_ptr(), scratch[0].data_ptr(), hb._stream_ptr()))
+            scratch = self._devbuf(f"colscr{st['slot']}_{c}", P * n * scratch_n, torch.float64, dev).view(P, n, scratch_n)
+            sp = hb._stream_ptr()
+            hb.check(hb.lib().mtq_threshold_columns(recs.data_ptr(), n, tiles, dec_mask, dmaps.data_ptr(), scratch[0].data_ptr(), sums_host[0, first:first + n].data_ptr(), sp))
             for q, f in enumerate(self.pure_formats):   # wq's `none` rows from the same records
                 pm = torch.full((n, tiles), MIXED_TILE_FORMATS.index(f), dtype=torch.int8, device=dev)
-                hb.check(hb.lib().mtq_column_sums_device_batched(recs.data_ptr(), n, tiles, dec_mask, pm.data_ptr(), scratch[1 + q].data_ptr(), hb._stream_ptr()))
-            for q in range(P):
-                hb.device_copy(sums_host[q, first:first + n], scratch[q, :, :7])
+                hb.check(hb.lib().mtq_threshold_columns(recs.data_ptr(), n, tiles, dec_mask, pm.data_ptr(), scratch[1 + q].data_ptr(), sums_host[1 + q, first:first + n].data_ptr(), sp))
 
     def wrap(self, st: dict) -> list[TensorResult]:
         """Host half, part 2 (behind a wait for the main stream): counts from the host's copy of the maps (np.bincount per tensor — what the

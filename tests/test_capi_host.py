@@ -25,7 +25,7 @@ def test_header_symbols_exported():
     L = hb.lib()
     for name in declared:
         assert hasattr(L, name), name
-    assert L.mtq_version() == 141
+    assert L.mtq_version() == 142
     assert L.mtq_stats_record_doubles(0xF) == 22 and L.mtq_stats_record_doubles(0b0110) == 12
 
 
