@@ -573,35 +573,40 @@ __global__ __launch_bounds__(kFastWaves * 64, rolled_waves(SUMS, ERRS)) void til
               o2 = 2 + 5 * __builtin_popcount(fmt_mask & 7u);
     const bool holes = !LISTED && (eval_mask & ~part_mask & MTQ_MASK_ALL) != (fmt_mask & MTQ_MASK_ALL);   // some slot (or part of one) is not written
 
-    auto unit_base = [&](int u, int &b, int &tr, int &uc) {
-        b = u / units_per_tensor;
-        const int r = u - b * units_per_tensor;
-        tr = r / units_w;
-        uc = r - tr * units_w;
-    };
+    // Where a unit lives is worked out ONCE, when the unit is claimed: its first row segment (the DMA base) and its records' place.  (Round 3
+    // divided by the launch's runtime tensor and row geometry in every issue_dma and again for the records: six 32-bit divisions per
+    // unit, each a dozen vector instructions — 5 % of the kernel; the listed form did two per LANE and call.)
+    struct Where { const unsigned char *base; double *out; unsigned long long mine; };
     // listed form: the global tile this lane's 16-lane group serves in unit u (a short last unit repeats the list's last tile)
     auto listed_tile = [&](int u, uint32_t q) -> uint32_t { return la.list[min((uint32_t)u * 4u + q, n_listed - 1u)]; };
-    // the four pieces of unit u's even (odd = 0) or odd (odd = 1) rows into the half at LDS address `half`
-    auto issue_rows = [&](int u, int odd, uint32_t half) {
+    auto locate = [&](int u) -> Where {
+        Where w{nullptr, nullptr, 0ull};
         if constexpr (LISTED) {
-            // lane q < 4 works out where tile q of the unit starts; every lane then picks the start of the tile its chunk belongs to
+            // lane q < 4 works out where tile q of the unit starts; issue_rows lets every lane pick the start of the tile its chunk belongs to
             const uint32_t gt = listed_tile(u, (uint32_t)lane & 3u);
             const uint32_t b = gt / (uint32_t)tiles, tt = gt - b * (uint32_t)tiles;
             const uint32_t tr = tt / la.tiles_w32, tc = tt - tr * la.tiles_w32;
-            const unsigned long long mine = (unsigned long long)(uintptr_t)(x + (int64_t)b * stride + ((int64_t)tr * kTile) * ld + (int64_t)tc * kTile);
+            w.mine = (unsigned long long)(uintptr_t)(x + (int64_t)b * stride + ((int64_t)tr * kTile) * ld + (int64_t)tc * kTile);
+        } else {
+            const int b = u / units_per_tensor, r = u - b * units_per_tensor, tr = r / units_w, uc = r - tr * units_w;
+            w.base = reinterpret_cast<const unsigned char *>(x + (int64_t)b * stride + ((int64_t)tr * kTile) * ld + (int64_t)uc * kUnitCols);
+            w.out = stats + ((int64_t)b * tiles + (int64_t)tr * tiles_w + uc * kUnitTiles) * rec;
+        }
+        return w;
+    };
+    // the four pieces of a unit's even (odd = 0) or odd (odd = 1) rows into the half at LDS address `half`
+    auto issue_rows = [&](const Where &w, int odd, uint32_t half) {
+        if constexpr (LISTED) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const uint32_t tl = odd ? dma_tile[4 + i] : dma_tile[i], off = odd ? dma_off[4 + i] : dma_off[i];
-                const unsigned lo = (unsigned)__shfl((int)(unsigned)mine, (int)tl, 64), hi = (unsigned)__shfl((int)(unsigned)(mine >> 32), (int)tl, 64);
+                const unsigned lo = (unsigned)__shfl((int)(unsigned)w.mine, (int)tl, 64), hi = (unsigned)__shfl((int)(unsigned)(w.mine >> 32), (int)tl, 64);
                 const unsigned long long src = (((unsigned long long)hi << 32) | lo) + off;
                 glds16v(reinterpret_cast<const void *>((uintptr_t)src), half + i * 1024);
             }
         } else {
-            int b, tr, uc;
-            unit_base(u, b, tr, uc);
-            const unsigned char *base = reinterpret_cast<const unsigned char *>(x + (int64_t)b * stride + ((int64_t)tr * kTile) * ld + (int64_t)uc * kUnitCols);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) glds16(base, odd ? dma_off[4 + i] : dma_off[i], half + i * 1024);
+            for (int i = 0; i < 4; ++i) glds16(w.base, odd ? dma_off[4 + i] : dma_off[i], half + i * 1024);
         }
     };
     // lane j of a tile's 16 lanes reduces one statistic and puts it where the record wants it (place_stat: everything by value — as a
@@ -625,7 +630,8 @@ __global__ __launch_bounds__(kFastWaves * 64, rolled_waves(SUMS, ERRS)) void til
     int u = claim_first();
     --left;
     uint32_t par = 0u;                                                        // the half the current unit's even rows are in
-    if (u < total_units) { issue_rows(u, 0, in_addr); issue_rows(u, 1, in_addr + kHalfBytes); }
+    Where here{nullptr, nullptr, 0ull}, next{nullptr, nullptr, 0ull};
+    if (u < total_units) { here = locate(u); issue_rows(here, 0, in_addr); issue_rows(here, 1, in_addr + kHalfBytes); }
     while (u < total_units) {
         unsigned char *half_a = in + par * kHalfBytes, *half_b = in + (par ^ 1u) * kHalfBytes;
         double *scratch = reinterpret_cast<double *>(half_a);                  // overlays the even rows after groups 0 and 1 have read them
@@ -679,7 +685,7 @@ __global__ __launch_bounds__(kFastWaves * 64, rolled_waves(SUMS, ERRS)) void til
         const bool tile_bad = ((bad_lanes >> (16 * t)) & 0xFFFFull) != 0ull;
         const int u_next = more ? claim_value(claimed) : 0x7FFFFFFF;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                   // every lane's image reads are done: both halves are free
-        if (u_next < total_units) issue_rows(u_next, 0, in_addr + (par ^ 1u) * kHalfBytes);   // EARLY: the next unit's even rows, into the half the odd rows were in
+        if (u_next < total_units) { next = locate(u_next); issue_rows(next, 0, in_addr + (par ^ 1u) * kHalfBytes); }   // EARLY: the next unit's even rows, into the half the odd rows were in
 
         // the reduce, `per` statistics at a time: lane j < per of a tile's 16 adds the 16 row pairs' partials of one statistic by the balanced tree
         auto reduce_pass = [&](int pass, auto &&sink) {
@@ -711,8 +717,9 @@ __global__ __launch_bounds__(kFastWaves * 64, rolled_waves(SUMS, ERRS)) void til
                 if (ERRS & 4u) rec_g[o2 + 4] = (double)mx[2];
             }
             if (j == 0 && real && tile_bad) la.redo[atomicAdd(la.n_redo, 1u)] = gt;   // the direct listed kernel takes it (literal route)
-            if (u_next < total_units) issue_rows(u_next, 1, in_addr + par * kHalfBytes);   // LATE: the next unit's odd rows — the unit's last vector-memory operations
+            if (u_next < total_units) issue_rows(next, 1, in_addr + par * kHalfBytes);   // LATE: the next unit's odd rows — the unit's last vector-memory operations
             u = u_next;
+            here = next;
             par ^= 1u;
             continue;
         }
@@ -740,17 +747,16 @@ __global__ __launch_bounds__(kFastWaves * 64, rolled_waves(SUMS, ERRS)) void til
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 
-        int b, tr, uc;
-        unit_base(u, b, tr, uc);
-        double *out = stats + ((int64_t)b * tiles + (int64_t)tr * tiles_w + uc * kUnitTiles) * rec;
+        double *out = here.out;
         double r0 = 0.0, r1 = 0.0;
         if (lane < nrec) r0 = recbuf[lane];
         if (lane + 64 < nrec) r1 = recbuf[lane + 64];
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                   // records are in registers: this half may be refilled
         if (lane < nrec) out[lane] = r0;
         if (lane + 64 < nrec) out[lane + 64] = r1;
-        if (u_next < total_units) issue_rows(u_next, 1, in_addr + par * kHalfBytes);   // LATE: the next unit's odd rows — the unit's last vector-memory operations
+        if (u_next < total_units) issue_rows(next, 1, in_addr + par * kHalfBytes);   // LATE: the next unit's odd rows — the unit's last vector-memory operations
         u = u_next;
+        here = next;
         par ^= 1u;
     }
     if constexpr (!LISTED) {
