@@ -107,7 +107,7 @@ int mtq_tile_stats_batched(const void *x, int in_dtype, int64_t count, int64_t s
 /*
  * K1 with part of the record left for later (round 3) — same records, same layout (`layout_mask` names the slots that exist), but only
  * the five statistics of the formats in `full_mask` and Σy, Σy², Σxy of the formats in `sums_mask` are promised; every other statistic of
- * the layout is UNSPECIFIED afterwards (the exact-integer bf16 kernel leaves NaN there, the other routes write the whole record).
+ * the layout is UNSPECIFIED afterwards (the LDS-staged bf16 kernel of csrc/mtq_fast.hip leaves NaN there, the other routes write the whole record).
  * Σx, Σx² are always written.  What the greedy search needs of a format before any tile has ended up in it is Σy, Σy², Σxy
  * (mixed_tile_greedy.py:245-261), and it only looks at format p for the tiles that accepted every earlier format (:227-231): the
  * streamed driver evaluates the last format of the list — and Σ|x−y|, max|x−y| of the one before it — for those tiles alone
@@ -118,7 +118,7 @@ int mtq_tile_stats_partial(const void *x, int in_dtype, int64_t count, int64_t s
                            uint32_t layout_mask, uint32_t full_mask, uint32_t sums_mask, double *stats, void *stream);
 
 /* mtq_tile_stats_partial as two launches the caller places itself (bf16 storage in whole 32x128 units with 16-byte aligned rows;
- * MTQ_ERR_UNSUPPORTED otherwise): _begin launches the exact-integer kernel alone — it resets its own unit counters, and stores *launch_id
+ * MTQ_ERR_UNSUPPORTED otherwise): _begin launches the LDS-staged bf16 kernel alone — it resets its own unit counters, and stores *launch_id
  * (returned to the host) into the device word *mark if it meets a tile it cannot take; _end, given that id, recomputes those tiles by the
  * literal route (it returns at once when *mark holds another value).  The records are complete behind _end.  The streamed driver puts
  * _begin on its K1 stream, where nothing then sits between two K1 launches, and _end on the batch's search stream. */
@@ -133,7 +133,7 @@ int mtq_tile_stats_partial_end(const void *x, int in_dtype, int64_t count, int64
  * at most `capacity` entries are read) names tiles as tensor * tiles + tile; for each of them the five statistics of the formats in
  * full_mask and Σ|x−y|, max|x−y| of those in err_mask are written into the tile's record (layout `layout_mask`), bit for bit what
  * mtq_tile_stats writes there; nothing else of the record is touched.  BFP formats only.  scratch: device memory of capacity + 1 uint32
- * (bf16 storage goes through the exact-integer kernel, four listed tiles per wave, and parks the few tiles that kernel cannot take
+ * (bf16 storage goes through the LDS-staged exact kernel, four listed tiles per wave, and parks the few tiles that kernel cannot take
  * there for the one-wave-per-tile kernel), or NULL (every tile through the one-wave-per-tile kernel).  The list comes from phase 1 of a split search
  * (mtq_greedy_scan_device_ex), which is the only reader of these statistics before the map is final.
  */
