@@ -671,7 +671,11 @@ __global__ __launch_bounds__(kFastWaves * 64, rolled_waves(SUMS, ERRS)) void til
 #pragma unroll
             for (int s = 0; s < kSums; ++s)
                 if (term_needed(SUMS, ERRS, XS, s)) acc[s] = acc[s] + G.term[s];   // 0.0 + t = t exactly: sequential ((g0+g1)+g2)+g3
-            mx[0] = fmaxf(mx[0], G.mx[0]); mx[1] = fmaxf(mx[1], G.mx[1]); mx[2] = fmaxf(mx[2], G.mx[2]);
+            // (plain v_max_f32: fmaxf makes the compiler canonicalise both operands first — two more slow-class instructions per maximum;
+            //  the values are maxima of finite magnitudes, or the tile is marked and they are never used)
+#pragma unroll
+            for (int f = 0; f < 3; ++f)
+                if (ERRS & (1u << f)) asm("v_max_f32 %0, %0, %1" : "+v"(mx[f]) : "v"(G.mx[f]));
             bad |= G.bad;
         }
 
@@ -679,7 +683,7 @@ __global__ __launch_bounds__(kFastWaves * 64, rolled_waves(SUMS, ERRS)) void til
         for (int f = 0; f < 3; ++f) {
             if (!(ERRS & (1u << f))) continue;
 #pragma unroll
-            for (int sft = 1; sft < 16; sft <<= 1) mx[f] = fmaxf(mx[f], __shfl_xor(mx[f], sft, 16));
+            for (int sft = 1; sft < 16; sft <<= 1) { const float o = __shfl_xor(mx[f], sft, 16); asm("v_max_f32 %0, %0, %1" : "+v"(mx[f]) : "v"(o)); }
         }
         const unsigned long long bad_lanes = __ballot(bad);
         const bool tile_bad = ((bad_lanes >> (16 * t)) & 0xFFFFull) != 0ull;
