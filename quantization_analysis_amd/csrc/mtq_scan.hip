@@ -25,6 +25,7 @@
 #include <stdint.h>
 
 #include <atomic>
+#include <type_traits>
 #include <stdlib.h>
 #include <mutex>
 
@@ -713,60 +714,75 @@ __device__ void scan_tensor(const ScanArgs &a, const Order &ord, int b, unsigned
 
         // ---- initial sums in tile order (:147-174): chains Σx, Σx², Σy, Σy², Σxy on lanes 0..4
         const int off5[5] = {0, 1, mae ? a.oab[base] : a.oy[base], a.oy2[base], a.oxy[base]};
-        double acc = 0.0;
-        // the records of four blocks of 64 tiles are in flight ahead of the chain (they come from HBM or the Infinity Cache — K1 wrote them a
-        // batch ago — and one block of look-ahead left the chain waiting for them: 21 cycles per tile against ≈ 10 for the additions)
-        constexpr int kAhead = 4;
-        double nx[kAhead][5];
-#pragma unroll
-        for (int r = 0; r < kAhead; ++r) {
-#pragma unroll
-            for (int c = 0; c < 5; ++c) nx[r][c] = 0.0;
-            if (64 * r + lane < T) {
-                const double *rt = st + (int64_t)(64 * r + lane) * rec;
-#pragma unroll
-                for (int c = 0; c < 5; ++c) nx[r][c] = rec_at(rt, (uint32_t)off5[c]);
-            }
-        }
-        for (int t00 = 0; t00 < T; t00 += 64 * kAhead) {
+        // The chains' additions are ≈ 6 cycles each; what the wave waits for is the records: 136-byte strided gathers out of HBM or the Infinity
+        // Cache (K1 wrote them a batch ago), as many in flight as the wave holds registers for.  kNc chains, kAhead blocks of 64 tiles ahead:
+        //   any base format: five values per tile, four blocks ahead (22 cycles per tile on a 57 344-tile tensor, tools/scan_ticks.py);
+        //   the identity bf16 base of bf16 storage (round 4): Σy, Σy², Σxy are the SAME additions of the same values as Σx, Σx², Σx²
+        //   (mtq_decide.hpp load5) — two values per tile, ten blocks ahead, three chains copied from the two.
+        auto init_sums = [&](auto nc_tag, auto ahead_tag, const int *offs) -> double {
+            constexpr int kNc = decltype(nc_tag)::value, kAhead = decltype(ahead_tag)::value;
+            double acc = 0.0;
+            double nx[kAhead][kNc];
 #pragma unroll
             for (int r = 0; r < kAhead; ++r) {
-                const int t0 = t00 + 64 * r;
-                if (t0 < T) {
-                    const int m = min(64, T - t0);
-                    if (lane < m) {
 #pragma unroll
-                        for (int c = 0; c < 5; ++c) lds_i[lane * 5 + c] = nx[r][c];
-                    }
-                    if (t0 + 64 * kAhead + lane < T) {   // the block four ahead takes this block's registers
-                        const double *rt = st + (int64_t)(t0 + 64 * kAhead + lane) * rec;
+                for (int c = 0; c < kNc; ++c) nx[r][c] = 0.0;
+                if (64 * r + lane < T) {
+                    const double *rt = st + (int64_t)(64 * r + lane) * rec;
 #pragma unroll
-                        for (int c = 0; c < 5; ++c) nx[r][c] = rec_at(rt, (uint32_t)off5[c]);
-                    }
-                    compiler_fence();
-                    if (lane < 5) {
-                        if (m == 64) {   // sixteen staged values ahead: the additions stay one dependent chain in tile order, the LDS reads do not wait for it
-                            double v[16], w[16];
-#pragma unroll
-                            for (int u = 0; u < 16; ++u) v[u] = lds_i[u * 5 + lane];
-#pragma unroll
-                            for (int i0 = 0; i0 < 64; i0 += 16) {
-                                if (i0 + 16 < 64) {
-#pragma unroll
-                                    for (int u = 0; u < 16; ++u) w[u] = lds_i[(i0 + 16 + u) * 5 + lane];
-                                }
-#pragma unroll
-                                for (int u = 0; u < 16; ++u) acc = acc + v[u];
-#pragma unroll
-                                for (int u = 0; u < 16; ++u) v[u] = w[u];
-                            }
-                        } else {
-                            for (int i = 0; i < m; ++i) acc = acc + lds_i[i * 5 + lane];
-                        }
-                    }
-                    compiler_fence();
+                    for (int c = 0; c < kNc; ++c) nx[r][c] = rec_at(rt, (uint32_t)offs[c]);
                 }
             }
+            for (int t00 = 0; t00 < T; t00 += 64 * kAhead) {
+#pragma unroll
+                for (int r = 0; r < kAhead; ++r) {
+                    const int t0 = t00 + 64 * r;
+                    if (t0 < T) {
+                        const int m = min(64, T - t0);
+                        if (lane < m) {
+#pragma unroll
+                            for (int c = 0; c < kNc; ++c) lds_i[lane * kNc + c] = nx[r][c];
+                        }
+                        if (t0 + 64 * kAhead + lane < T) {   // the block kAhead ahead takes this block's registers
+                            const double *rt = st + (int64_t)(t0 + 64 * kAhead + lane) * rec;
+#pragma unroll
+                            for (int c = 0; c < kNc; ++c) nx[r][c] = rec_at(rt, (uint32_t)offs[c]);
+                        }
+                        compiler_fence();
+                        if (lane < kNc) {
+                            if (m == 64) {   // sixteen staged values ahead: the additions stay one dependent chain in tile order, the LDS reads do not wait for it
+                                double v[16], w[16];
+#pragma unroll
+                                for (int u = 0; u < 16; ++u) v[u] = lds_i[u * kNc + lane];
+#pragma unroll
+                                for (int i0 = 0; i0 < 64; i0 += 16) {
+                                    if (i0 + 16 < 64) {
+#pragma unroll
+                                        for (int u = 0; u < 16; ++u) w[u] = lds_i[(i0 + 16 + u) * kNc + lane];
+                                    }
+#pragma unroll
+                                    for (int u = 0; u < 16; ++u) acc = acc + v[u];
+#pragma unroll
+                                    for (int u = 0; u < 16; ++u) v[u] = w[u];
+                                }
+                            } else {
+                                for (int i = 0; i < m; ++i) acc = acc + lds_i[i * kNc + lane];
+                            }
+                        }
+                        compiler_fence();
+                    }
+                }
+            }
+            return acc;
+        };
+        const bool identity_base = !mae && off5[2] == 0 && off5[3] == 1 && off5[4] == 1;
+        double acc;
+        if (identity_base) {
+            acc = init_sums(std::integral_constant<int, 2>{}, std::integral_constant<int, 10>{}, off5);
+            const double s1 = shfl_f64(acc, 1), s0 = shfl_f64(acc, 0);
+            acc = lane == 0 || lane == 2 ? s0 : s1;      // lanes 2, 3, 4: Σy = Σx, Σy² = Σxy = Σx²
+        } else {
+            acc = init_sums(std::integral_constant<int, 5>{}, std::integral_constant<int, 4>{}, off5);
         }
         sum_x = shfl_f64(acc, 0); sum_x2 = shfl_f64(acc, 1);
         Sy = shfl_f64(acc, 2); Sy2 = shfl_f64(acc, 3); Sxy = shfl_f64(acc, 4);
