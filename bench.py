@@ -582,7 +582,7 @@ def run_llama_workload(args, dist, rank, world, device, barrier, numa) -> None:
         secs = per_rank_all[:, 0] / args.steps
         frac = BYTES_PER_TILE_READ * kt.tiles / max(kt.kernel_ms, 1e-9) / 1e6 / HBM_PEAK_GBS
         out = {"metric": METRIC_NAME, "value": total_tiles * args.steps / dt, "unit": "tiles/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-               "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u32/f64", "data": "synthetic",
+               "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32/f64", "data": "synthetic",
                "config": {"workload": "Llama-3-8B model.layers.* linear weights: 224 synthetic bf16 tensors (6.8 M tiles, 14 GB) drawn on the device, mixed-tile-greedy "
                                       "{bf16,bfp8,bfp4,bfp2} pcc>=0.999 seed 123 (BASELINE.json configs[3]); a step = the whole model once",
                           "sharding": f"224 tensors LPT by element count over {world} ranks (model_source.lpt_shards), RCCL gather of summary rows",
@@ -679,7 +679,7 @@ def run_m1_workload(args, dist, rank, world, device, barrier, numa) -> None:
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "u32/f64", "data": "synthetic",
+            "dtype": "f32/f64", "data": "synthetic",
             "config": {"workload": f"{args.tensors} x 4096x4096 bf16 N(0,0.02^2) per GPU per step, mixed-tile-greedy "
                                    f"{{bf16,bfp8,bfp4,bfp2}} pcc>=0.999 seed 123 (BASELINE.json configs[1], streamed)",
                        "tensors_per_step_per_gpu": args.tensors, "tiles_per_step_per_gpu": tiles_per_step,
