@@ -56,6 +56,26 @@ def test_argument_errors_are_reported():
     assert L.mtq_scan_orders_device(1, 16, 3, p, 1 << 20, None) < 0 and L.mtq_scan_orders_device(1, 16, 1, None, 0, None) < 0
     assert int(L.mtq_scan_orders_bytes(16384)) >= 128 + 2 * 4 * 16384 and int(L.mtq_scan_carry_bytes(3)) == 3 * int(L.mtq_scan_carry_bytes(1))
     assert int(L.mtq_greedy_scan_scratch_bytes(2, 100)) >= 2 * (100 * 8 * 8 + 100 * 4)
+    # round 4: a threshold batch as one call — arguments first, device second
+    assert L.mtq_threshold_enqueue(p, 0, 1, 1024, 32, 32, 32, 0xE, 0x1E, fm, 4, 0, 0.999, 2e-6, None, p, p, 8, p, p, p, None, None) == -1 and b"null" in L.mtq_last_error()
+    assert L.mtq_threshold_enqueue(p, 0, 0, 1024, 32, 32, 32, 0xE, 0x1E, fm, 4, 0, 0.999, 2e-6, p, p, p, 8, p, p, p, None, None) == -1     # count 0
+    assert L.mtq_threshold_enqueue(p, 0, 1, 1024, 32, 32, 32, 0xE, 0x1E, fm, 4, 0, 0.999, 2e-6, p, p, p, -1, p, p, p, None, None) == -1    # negative cap
+    assert L.mtq_threshold_columns(p, 1, 1, 0xE, p, p, None, None) == -1 and b"null" in L.mtq_last_error()
+
+
+def test_settings_are_read_once_and_refreshable(monkeypatch):
+    """quantization_analysis_amd/settings.py: the documented defaults, one read per process, refresh on request."""
+    from quantization_analysis_amd.settings import settings
+
+    for k in ("MTQ_PIPE_SLOTS", "MTQ_LAZY", "MTQ_SCAN_STREAMS", "MTQ_KNIFE_CAP"):
+        monkeypatch.delenv(k, raising=False)
+    s = settings(refresh=True)
+    assert (s.pipe_slots, s.lazy, s.scan_streams, s.knife_cap, s.shared_orders, s.lazy_max_listed) == (4, True, None, 128, True, 0.35)
+    monkeypatch.setenv("MTQ_PIPE_SLOTS", "6")
+    monkeypatch.setenv("MTQ_LAZY", "0")
+    assert settings().pipe_slots == 4 and settings().lazy is True            # not re-read behind the process's back
+    s = settings(refresh=True)
+    assert s.pipe_slots == 6 and s.lazy is False
 
 
 def test_no_gpu_means_error_not_fallback():
