@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define MTQ_VERSION 142 /* 0.1.4.2: - chain records, + mtq_threshold_enqueue / _columns; 0.1.4.1: + partial / listed K1 (mtq_tile_stats_partial, mtq_tile_stats_listed), the search in phases with shared visiting orders, mtq_shutdown, mtq_knife_tiles_device */
+#define MTQ_VERSION 143 /* 0.1.4.3: + ragged batches (MtqMatrix, mtq_tile_stats_ragged, mtq_threshold_enqueue_ragged / _columns_ragged); 0.1.4.2: - chain records, + mtq_threshold_enqueue / _columns; 0.1.4.1: + partial / listed K1 (mtq_tile_stats_partial, mtq_tile_stats_listed), the search in phases with shared visiting orders, mtq_shutdown, mtq_knife_tiles_device */
 
 typedef enum {
     MTQ_OK = 0,
@@ -279,9 +279,10 @@ int mtq_threshold_assign_device(const double *stats, int64_t tiles, uint32_t fmt
                                 int metric, double threshold, double band, int8_t *map, uint8_t *knife, void *stream);
 
 
-/* Σx, Σx², Σy, Σy², Σxy, Σ|d|, max|d| of the reconstruction `map` implies → scratch[0..6] (device).  scratch must hold
- * mtq_columns_scratch_doubles() doubles.  Σx is NaN when the map names a format that is not available.  The caller
- * turns the seven values into pcc / mae / atol with the formulas of mtq_columns_from_stats. */
+/* Σx, Σx², Σy, Σy², Σxy, Σ|d|, max|d| of the reconstruction `map` implies → scratch[0..6] (device), and the map's number of tiles per
+ * format code 0..3 → scratch[7..10] (whole numbers as doubles: mixed_tile_threshold.py:133-135's bincount without the map leaving the
+ * device first).  scratch must hold mtq_columns_scratch_doubles() doubles.  Σx is NaN when the map names a format that is not
+ * available.  The caller turns the seven sums into pcc / mae / atol with the formulas of mtq_columns_from_stats. */
 size_t mtq_columns_scratch_doubles(void);
 int mtq_column_sums_device(const double *stats, int64_t tiles, uint32_t fmt_mask, const int8_t *map, double *scratch, void *stream);
 /* The same for `count` equally sized tensors in one launch pair: records [count][tiles][rec], maps [count][tiles], scratch
@@ -349,15 +350,41 @@ int mtq_knife_tiles_device(const void *x, int in_dtype, int64_t count, int64_t s
  * both_dev[0 .. T) (maps) and both_dev[T .. 2T) (knife-edge masks), T = count * tiles → both of them into the pinned mirror both_host
  * (mtq_device_copy_2d) on `stream`; then, behind an event, on `side_stream` (NULL: on `stream`): mtq_knife_tiles_device(cap) and the list
  * (cap + 1 int64) into the pinned list_host.  Replaces the per-tensor body of wq:655-706 / mixed_tile_threshold.py:97-123 up to the
- * knife-edge decisions.  Everything asynchronous; the caller waits for an event of its own behind the call. */
+ * knife-edge decisions.  scratch and sums_host both non-NULL: mtq_threshold_columns under the maps as K4 left them follows on `stream`
+ * at once — the batch's final sums unless its list names a knife-edge tile (the band is 2e-6 wide: rarely), in which case the caller
+ * patches the maps and calls mtq_threshold_columns again; the host's look at the list is then off the GPU's critical path.
+ * Everything asynchronous; the caller waits for an event of its own behind the call. */
 int mtq_threshold_enqueue(const void *x, int in_dtype, int64_t count, int64_t stride_elems, int64_t rows, int64_t cols, int64_t ld,
                           uint32_t k1_mask, uint32_t dec_mask, const int *formats, int n_formats, int metric, double threshold, double band,
                           double *stats, int8_t *both_dev, int8_t *both_host, int64_t cap, int64_t *list_dev, float *knife_dev,
-                          int64_t *list_host, void *stream, void *side_stream);
-/* … and its second half: mtq_column_sums_device_batched under the (patched) maps, the seven sums of every tensor into the pinned
- * sums_host[count][7] (wq:683-706's columns come from them: mtq_columns_from_sums). */
+                          int64_t *list_host, double *scratch, double *sums_host, void *stream, void *side_stream);
+/* … and its second half: mtq_column_sums_device_batched under the (patched) maps, the seven sums of every tensor and behind them the
+ * map's tile count per format code 0..3 (mixed_tile_threshold.py:133-135's bincount, as doubles) into the pinned sums_host[count][11]
+ * (wq:683-706's columns come from the sums: mtq_columns_from_sums). */
 int mtq_threshold_columns(const double *stats, int64_t count, int64_t tiles, uint32_t dec_mask, const int8_t *maps_dev, double *scratch,
                           double *sums_host, void *stream);
+
+/* RAGGED batches (round 4): n <= MTQ_RAGGED_MAX matrices of ONE storage type and ANY shapes as one launch per stage — a model's odd
+ * tensors (DeepSeek-R1 layer 0's five float32 projections of five shapes, its two norm vectors as (ceil(n/32), 32) matrices) cost a
+ * launch chain each through the calls above, and the chain, not the arithmetic, was their time.  The batch's tiles are numbered
+ * through: matrix j's tiles, row-major (tile_utils.py:96-113), follow matrix j-1's; records, maps, masks and list ids use that number.
+ * Per tile the kernels, the arithmetic and the summation order are those of the per-matrix calls (mtq_tile_stats on float32 or on bf16
+ * storage the LDS-staged kernel does not take: the direct kernel + its fix-up): same records, bit for bit; the column sums of matrix j
+ * are formed in the order mtq_column_sums_device uses for that matrix alone.  Replaces the same reference lines as the calls they
+ * generalise (wq:655-706, mixed_tile_threshold.py:97-123). */
+#define MTQ_RAGGED_MAX 24
+typedef struct MtqMatrix { const void *x; int64_t rows, cols, ld; } MtqMatrix;   /* device pointer, leading dimension in elements */
+int mtq_tile_stats_ragged(const MtqMatrix *mats, int n, int in_dtype, uint32_t fmt_mask, double *stats, void *stream);
+int mtq_knife_tiles_ragged(const MtqMatrix *mats, int n, int in_dtype, const int8_t *near, const int *formats, int n_formats, int64_t cap,
+                           int64_t *list, float *tiles_out, void *stream);
+int mtq_column_sums_device_ragged(const double *stats, const int64_t *tiles_per, int n, uint32_t fmt_mask, const int8_t *maps, double *scratch,
+                                  void *stream);   /* scratch: n * mtq_columns_scratch_doubles(); tensor j's sums at scratch[j * that] */
+int mtq_threshold_enqueue_ragged(const MtqMatrix *mats, int n, int in_dtype, uint32_t k1_mask, uint32_t dec_mask, const int *formats, int n_formats,
+                                 int metric, double threshold, double band, double *stats, int8_t *both_dev, int8_t *both_host, int64_t cap,
+                                 int64_t *list_dev, float *knife_dev, int64_t *list_host, double *scratch, double *sums_host, void *stream,
+                                 void *side_stream);
+int mtq_threshold_columns_ragged(const double *stats, const int64_t *tiles_per, int n, uint32_t dec_mask, const int8_t *maps_dev, double *scratch,
+                                 double *sums_host, void *stream);
 
 /* Results home without a copy engine (no reference counterpart: the reference's arrays are host arrays).  A kernel copies `rows` rows
  * of `width_bytes` bytes from src (pitch src_pitch) to dst (pitch dst_pitch) on `stream`; dst may be pinned host memory

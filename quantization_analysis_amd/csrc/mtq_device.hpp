@@ -129,6 +129,23 @@ template <> struct Loader<float> {
     }
 };
 
+// A RAGGED batch (include/mtq.h, mtq_tile_stats_ragged): up to kRaggedMax matrices of one storage type and any shapes whose tiles are
+// numbered through — matrix j's tiles, row-major, are first[j] .. first[j] + tiles_j − 1 of the launch.  The table rides in the kernel
+// arguments (1.2 KB): a wave finds the matrix of a tile with scalar compares, no upload precedes the launch.  n = 0: the launch is a uniform
+// batch described by the kernel's other arguments.
+constexpr int kRaggedMax = 24;
+struct RaggedSeg { const void *x; int64_t rows, cols, ld; uint32_t tiles_w, first; int32_t vec_ok, pad_; };
+struct RaggedTable { uint32_t n, total; RaggedSeg seg[kRaggedMax]; };
+struct TileSite { const void *x; int64_t rows, cols, ld; uint32_t tiles_w, t; int vec_ok; };
+
+__device__ __forceinline__ TileSite ragged_site(const RaggedTable &tb, uint32_t gt)
+{
+    uint32_t b = 0;
+    for (uint32_t i = 1; i < tb.n; ++i) b += gt >= tb.seg[i].first ? 1u : 0u;
+    const RaggedSeg &s = tb.seg[b];
+    return TileSite{s.x, s.rows, s.cols, s.ld, s.tiles_w, gt - s.first, s.vec_ok};
+}
+
 __device__ __forceinline__ uint32_t group_shared_exp(const uint32_t u[kGroup])
 {
     uint32_t m = 0u;

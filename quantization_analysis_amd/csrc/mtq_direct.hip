@@ -189,7 +189,8 @@ __device__ __forceinline__ void direct_group(const uint32_t (&u)[kGroup], double
 template <typename T, uint32_t FM>
 __global__ __launch_bounds__(kDirectWaves * 64, MTQ_DIRECT_WAVES_PER_SIMD) void tile_stats_direct(
     const T *__restrict__ x, int64_t stride, int64_t rows, int64_t cols, int64_t ld, uint32_t tiles_w, uint32_t tiles,
-    uint32_t total_tiles, double *__restrict__ stats, int vec_ok, unsigned *__restrict__ work, unsigned launch_id, int tiles_per_wave)
+    uint32_t total_tiles, double *__restrict__ stats, int vec_ok, unsigned *__restrict__ work, unsigned launch_id, int tiles_per_wave,
+    const RaggedTable tb)
 {
     constexpr int nf = popc4(FM), nsum = 2 + 4 * nf, pad = direct_pad(FM), rec = 2 + 5 * nf;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -206,6 +207,13 @@ __global__ __launch_bounds__(kDirectWaves * 64, MTQ_DIRECT_WAVES_PER_SIMD) void 
     };
 
     auto fetch = [&](uint32_t gt, uint32_t (&u)[kGroup]) {
+        if (tb.n) {   // a ragged batch (mtq_tile_stats_ragged): the tile's matrix from the table in the kernel arguments
+            const TileSite w = ragged_site(tb, gt);
+            const uint32_t tr = w.t / w.tiles_w, tc = w.t - tr * w.tiles_w;
+            Loader<T>::group(static_cast<const T *>(w.x), (int64_t)tr * kTile + (lane >> 1), (int64_t)tc * kTile + (lane & 1) * kGroup, w.rows,
+                             w.cols, w.ld, w.vec_ok != 0, u);
+            return;
+        }
         const uint32_t b = gt / tiles, t = gt - b * tiles;
         const uint32_t tr = t / tiles_w, tc = t - tr * tiles_w;
         Loader<T>::group(x + (int64_t)b * stride, (int64_t)tr * kTile + (lane >> 1), (int64_t)tc * kTile + (lane & 1) * kGroup, rows,
@@ -392,12 +400,13 @@ static void launch_listed(uint32_t fm, dim3 grid, hipStream_t st, const T *x, in
 
 template <typename T>
 static void launch_direct(uint32_t fm, dim3 grid, hipStream_t st, const T *x, int64_t stride, int64_t rows, int64_t cols, int64_t ld,
-                          uint32_t tiles_w, uint32_t tiles, uint32_t total, double *stats, int vec_ok, unsigned *work, unsigned launch_id, int tiles_per_wave)
+                          uint32_t tiles_w, uint32_t tiles, uint32_t total, double *stats, int vec_ok, unsigned *work, unsigned launch_id, int tiles_per_wave,
+                          const RaggedTable &tb)
 {
     const dim3 block(kDirectWaves * 64);
 #define MTQ_LAUNCH_DIRECT(M) \
     case M: hipLaunchKernelGGL((tile_stats_direct<T, M>), grid, block, (size_t)kDirectWaves * 64 * direct_pad(M) * sizeof(double), st, x, \
-                               stride, rows, cols, ld, tiles_w, tiles, total, stats, vec_ok, work, launch_id, tiles_per_wave); break;
+                               stride, rows, cols, ld, tiles_w, tiles, total, stats, vec_ok, work, launch_id, tiles_per_wave, tb); break;
     switch (fm) { // one instantiation per requested format subset: unrequested formats cost nothing
         MTQ_LAUNCH_DIRECT(1u) MTQ_LAUNCH_DIRECT(2u) MTQ_LAUNCH_DIRECT(3u) MTQ_LAUNCH_DIRECT(4u) MTQ_LAUNCH_DIRECT(5u)
         MTQ_LAUNCH_DIRECT(6u) MTQ_LAUNCH_DIRECT(7u) MTQ_LAUNCH_DIRECT(8u) MTQ_LAUNCH_DIRECT(9u) MTQ_LAUNCH_DIRECT(10u)
@@ -413,11 +422,9 @@ using namespace mtq;
 
 // Launcher used by mtq_tile_stats_batched for every input the bf16 LDS-staged kernel does not take (mtq_kernels.hip
 // decides and follows up with tile_stats_redo_flagged).  fmt_mask != 0, count * tiles < 2^31.
-extern "C" int mtq_launch_tile_stats_direct(const void *x, int in_dtype, int64_t count, int64_t stride_elems, int64_t rows, int64_t cols,
-                                            int64_t ld, uint32_t fmt_mask, double *stats, int vec_ok, void *stream, mtq::WorkSlot *work_out, unsigned launch_id)
+// Grid of a direct launch over `total` tiles and the per-wave tile quota that goes with it (0: waves never retire).
+static int direct_grid(int64_t total, dim3 &grid, int &quota)
 {
-    const int64_t th = (rows + kTile - 1) / kTile, tw = (cols + kTile - 1) / kTile, tiles = th * tw, total = count * tiles;
-    if (total >= ((int64_t)1 << 31) || (fmt_mask & MTQ_MASK_ALL) == 0) return fail(MTQ_ERR_INVALID, "direct tile_stats launch out of range");
     static int cus = 0;
     if (cus == 0) {
         int dev = 0;
@@ -432,24 +439,57 @@ extern "C" int mtq_launch_tile_stats_direct(const void *x, int in_dtype, int64_t
     static int tpw = -1;
     if (tpw < 0) { const char *e = getenv("MTQ_K1_UNITS_PER_WAVE"); tpw = 16 * (e ? atoi(e) : 8); if (tpw < 0) tpw = 0; }
     int64_t want = need < max_blocks ? need : max_blocks;
-    int quota = 0;
+    quota = 0;
     if (tpw > 0 && need > max_blocks) {
         const int64_t by_quota = (total + (int64_t)kDirectWaves * tpw - 1) / ((int64_t)kDirectWaves * tpw);
         want = ((by_quota + kWorkGroups - 1) / kWorkGroups + 1) * kWorkGroups;
         if (want < max_blocks) want = max_blocks;
         quota = tpw;
     }
-    const dim3 grid((unsigned)want);
+    grid = dim3((unsigned)want);
+    return MTQ_OK;
+}
+
+// Launcher used by mtq_tile_stats_batched for every input the bf16 LDS-staged kernel does not take (mtq_kernels.hip
+// decides and follows up with tile_stats_redo_flagged).  fmt_mask != 0, count * tiles < 2^31.
+extern "C" int mtq_launch_tile_stats_direct(const void *x, int in_dtype, int64_t count, int64_t stride_elems, int64_t rows, int64_t cols,
+                                            int64_t ld, uint32_t fmt_mask, double *stats, int vec_ok, void *stream, mtq::WorkSlot *work_out, unsigned launch_id)
+{
+    const int64_t th = (rows + kTile - 1) / kTile, tw = (cols + kTile - 1) / kTile, tiles = th * tw, total = count * tiles;
+    if (total >= ((int64_t)1 << 31) || (fmt_mask & MTQ_MASK_ALL) == 0) return fail(MTQ_ERR_INVALID, "direct tile_stats launch out of range");
+    dim3 grid;
+    int quota = 0;
+    if (int rc = direct_grid(total, grid, quota)) return rc;
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (int rc = work_counter_acquire(stream, work_out)) return rc;   // `st` now waits for the slot's previous launch to have reset it
     unsigned *work = work_out->counters;
+    static const RaggedTable none{};   // n = 0: a uniform batch
     if (in_dtype == MTQ_DTYPE_BF16)
         launch_direct<uint16_t>(fmt_mask & MTQ_MASK_ALL, grid, st, static_cast<const uint16_t *>(x), stride_elems, rows, cols, ld, (uint32_t)tw,
-                                (uint32_t)tiles, (uint32_t)total, stats, vec_ok, work, launch_id, quota);
+                                (uint32_t)tiles, (uint32_t)total, stats, vec_ok, work, launch_id, quota, none);
     else
         launch_direct<float>(fmt_mask & MTQ_MASK_ALL, grid, st, static_cast<const float *>(x), stride_elems, rows, cols, ld, (uint32_t)tw,
-                             (uint32_t)tiles, (uint32_t)total, stats, vec_ok, work, launch_id, quota);
+                             (uint32_t)tiles, (uint32_t)total, stats, vec_ok, work, launch_id, quota, none);
     return check_launch("mtq_tile_stats (direct)");
+}
+
+// The same kernel over a ragged batch (mtq_tile_stats_ragged, mtq_kernels.hip): tb.total tiles numbered through the table's matrices.
+int mtq_launch_tile_stats_direct_ragged(const mtq::RaggedTable &tb, int in_dtype, uint32_t fmt_mask, double *stats, void *stream,
+                                        mtq::WorkSlot *work_out, unsigned launch_id)
+{
+    if (tb.n == 0 || tb.n > (uint32_t)kRaggedMax || tb.total == 0 || tb.total >= (1u << 31) || (fmt_mask & MTQ_MASK_ALL) == 0)
+        return fail(MTQ_ERR_INVALID, "ragged tile_stats launch out of range");
+    dim3 grid;
+    int quota = 0;
+    if (int rc = direct_grid(tb.total, grid, quota)) return rc;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (int rc = work_counter_acquire(stream, work_out)) return rc;
+    unsigned *work = work_out->counters;
+    if (in_dtype == MTQ_DTYPE_BF16)
+        launch_direct<uint16_t>(fmt_mask & MTQ_MASK_ALL, grid, st, nullptr, 0, 0, 0, 0, 1u, 1u, tb.total, stats, 0, work, launch_id, quota, tb);
+    else
+        launch_direct<float>(fmt_mask & MTQ_MASK_ALL, grid, st, nullptr, 0, 0, 0, 0, 1u, 1u, tb.total, stats, 0, work, launch_id, quota, tb);
+    return check_launch("mtq_tile_stats_ragged (direct)");
 }
 
 extern "C" int mtq_launch_tile_stats_bf16_listed(const void *x, int64_t count, int64_t stride_elems, int64_t rows, int64_t cols, int64_t ld,

@@ -27,15 +27,19 @@ namespace mtq {
 template <typename T>
 __device__ __forceinline__ void tile_stats_one(const T *__restrict__ x, int64_t gt, int64_t stride, int64_t rows, int64_t cols,
                                                int64_t ld, int tiles_w, int64_t tiles, uint32_t fmt_mask, int rec,
-                                               double *__restrict__ stats, int vec_ok)
+                                               double *__restrict__ stats, int vec_ok, const RaggedTable &tb)
 {
     const int lane = threadIdx.x & 63;
-    const int64_t b = gt / tiles, t = gt - b * tiles;
-    const int64_t tr = t / tiles_w, tc = t - tr * tiles_w;
-    const T *xb = x + b * stride;
-
     uint32_t u[kGroup];
-    Loader<T>::group(xb, tr * kTile + (lane >> 1), tc * kTile + (lane & 1) * kGroup, rows, cols, ld, vec_ok != 0, u);
+    if (tb.n) {   // a ragged batch: the tile's matrix from the table (mtq_device.hpp)
+        const TileSite w = ragged_site(tb, (uint32_t)gt);
+        const int64_t tr = w.t / w.tiles_w, tc = w.t - tr * w.tiles_w;
+        Loader<T>::group(static_cast<const T *>(w.x), tr * kTile + (lane >> 1), tc * kTile + (lane & 1) * kGroup, w.rows, w.cols, w.ld, w.vec_ok != 0, u);
+    } else {
+        const int64_t b = gt / tiles, t = gt - b * tiles;
+        const int64_t tr = t / tiles_w, tc = t - tr * tiles_w;
+        Loader<T>::group(x + b * stride, tr * kTile + (lane >> 1), tc * kTile + (lane & 1) * kGroup, rows, cols, ld, vec_ok != 0, u);
+    }
     double acc[2 + 5 * kNumFmt]; // registers are indexed by FORMAT (static); the record is compacted when written
     tile_terms_literal(u, fmt_mask, acc);
     if (lane == 0) {
@@ -57,11 +61,11 @@ template <typename T>
 __global__ __launch_bounds__(256) void tile_stats_generic(const T *__restrict__ x, int64_t count, int64_t stride,
                                                           int64_t rows, int64_t cols, int64_t ld, int tiles_w,
                                                           int64_t tiles, uint32_t fmt_mask, int rec,
-                                                          double *__restrict__ stats, int vec_ok)
+                                                          double *__restrict__ stats, int vec_ok, const RaggedTable tb)
 {
     const int64_t gt = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); // global tile over the batch, one wave per tile
-    if (gt >= count * tiles) return;                                   // wave-uniform
-    tile_stats_one<T>(x, gt, stride, rows, cols, ld, tiles_w, tiles, fmt_mask, rec, stats, vec_ok);
+    if (gt >= (tb.n ? (int64_t)tb.total : count * tiles)) return;      // wave-uniform
+    tile_stats_one<T>(x, gt, stride, rows, cols, ld, tiles_w, tiles, fmt_mask, rec, stats, vec_ok, tb);
 }
 
 // Follow-up of the exact-route kernels (mtq_fast.hip, mtq_direct.hip): every wave inspects 64 records, and recomputes
@@ -71,14 +75,15 @@ template <typename T>
 __global__ __launch_bounds__(256) void tile_stats_redo_flagged(const T *__restrict__ x, int64_t count, int64_t stride,
                                                                int64_t rows, int64_t cols, int64_t ld, int tiles_w,
                                                                int64_t tiles, uint32_t fmt_mask, int rec,
-                                                               double *__restrict__ stats, int vec_ok, unsigned *__restrict__ work, unsigned launch_id)
+                                                               double *__restrict__ stats, int vec_ok, unsigned *__restrict__ work, unsigned launch_id,
+                                                               const RaggedTable tb)
 {
     if (blockIdx.x == 0 && threadIdx.x < kWorkGroups) work[threadIdx.x * kWorkStride] = 0u; // the launch's unit counters, ready for their next user
     if (work[kWorkStamp] != launch_id) return;                          // no tile of this launch was marked (the usual case): nothing to read
     // a grid of at most kRedoBlocks blocks strides over the records (round 3: the follow-up sits on the K1 stream between two K1 launches,
     // and a grid of one wave per 64 records — 8 192 blocks for a 128-tensor batch — took 20–55 µs to pass through the chip just to find nothing)
     const int lane = threadIdx.x & 63;
-    const int64_t total = count * tiles;
+    const int64_t total = tb.n ? (int64_t)tb.total : count * tiles;
     for (int64_t first = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 64; first < total; first += (int64_t)gridDim.x * 4 * 64) {
         const int64_t mine = first + lane;
         bool flagged = false;
@@ -87,7 +92,7 @@ __global__ __launch_bounds__(256) void tile_stats_redo_flagged(const T *__restri
         while (todo) {                                                     // wave-uniform loop over the flagged tiles
             const int k = __builtin_ctzll(todo);
             todo &= todo - 1;
-            tile_stats_one<T>(x, first + k, stride, rows, cols, ld, tiles_w, tiles, fmt_mask, rec, stats, vec_ok);
+            tile_stats_one<T>(x, first + k, stride, rows, cols, ld, tiles_w, tiles, fmt_mask, rec, stats, vec_ok, tb);
         }
     }
 }
@@ -112,7 +117,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void
         while (todo) {
             const int k = __builtin_ctzll(todo);
             todo &= todo - 1;
-            tile_stats_one<uint16_t>(x, first + k, stride, rows, cols, ld, tiles_w, tiles, fmt_mask, rec, stats, vec_ok);
+            tile_stats_one<uint16_t>(x, first + k, stride, rows, cols, ld, tiles_w, tiles, fmt_mask, rec, stats, vec_ok, RaggedTable{});
         }
     }
 }
@@ -455,17 +460,24 @@ __global__ __launch_bounds__(256) void knife_list(const int8_t *__restrict__ nea
 
 template <typename T>
 __global__ __launch_bounds__(64) void knife_tiles(const T *__restrict__ x, int64_t stride, int64_t rows, int64_t cols, int64_t ld, int tiles_w, int64_t tiles,
-                                                  const long long *__restrict__ list, int64_t cap, int4 fmts, int n_fmts, float *__restrict__ out, int vec_ok)
+                                                  const long long *__restrict__ list, int64_t cap, int4 fmts, int n_fmts, float *__restrict__ out, int vec_ok,
+                                                  const RaggedTable tb)
 {
     const int64_t listed = list[cap] < cap ? list[cap] : cap;
     const int64_t b = blockIdx.x;
     if (b >= listed) return;
-    const int64_t id = list[b], j = id / tiles, t = id - j * tiles;
+    const int64_t id = list[b];
     const int lane = threadIdx.x;
     const int64_t r = lane >> 1, c0 = (int64_t)(lane & 1) * kGroup;
-    const int64_t row = (t / tiles_w) * kTile + r, col0 = (t % tiles_w) * kTile + c0;
     uint32_t u[kGroup];
-    Loader<T>::group(x + j * stride, row, col0, rows, cols, ld, vec_ok != 0, u);
+    if (tb.n) {   // a ragged batch: the listed id is a tile number of the launch (mtq_device.hpp)
+        const TileSite w = ragged_site(tb, (uint32_t)__builtin_amdgcn_readfirstlane((int)id));
+        Loader<T>::group(static_cast<const T *>(w.x), (int64_t)(w.t / w.tiles_w) * kTile + r, (int64_t)(w.t % w.tiles_w) * kTile + c0, w.rows, w.cols, w.ld,
+                         w.vec_ok != 0, u);
+    } else {
+        const int64_t j = id / tiles, t = id - j * tiles;
+        Loader<T>::group(x + j * stride, (t / tiles_w) * kTile + r, (t % tiles_w) * kTile + c0, rows, cols, ld, vec_ok != 0, u);
+    }
     const uint32_t shared = group_shared_exp(u);
     const int f4[4] = {fmts.x, fmts.y, fmts.z, fmts.w};
     for (int p = 0; p <= n_fmts; ++p) {
@@ -479,21 +491,18 @@ __global__ __launch_bounds__(64) void knife_tiles(const T *__restrict__ x, int64
 }
 } // namespace
 
-extern "C" int mtq_knife_tiles_device(const void *x, int in_dtype, int64_t count, int64_t stride_elems, int64_t rows, int64_t cols, int64_t ld,
-                                      const int8_t *near, const int *formats, int n_formats, int64_t cap, int64_t *list, float *tiles_out, void *stream)
+static int knife_tiles_launch(const void *x, int in_dtype, int64_t stride_elems, int64_t rows, int64_t cols, int64_t ld, int64_t tw, int64_t tiles, int64_t total,
+                              int vec_ok, const RaggedTable &tb, const int8_t *near, const int *formats, int n_formats, int64_t cap, int64_t *list,
+                              float *tiles_out, void *stream)
 {
-    if (int rc = check_matrix(x, in_dtype, rows, cols, ld)) return rc;
     if (!near || !list || !formats) return fail(MTQ_ERR_INVALID, "null argument");
-    if (count <= 0 || cap < 0 || (cap > 0 && !tiles_out)) return fail(MTQ_ERR_INVALID, "count must be positive, cap non-negative, tiles_out set when cap > 0");
+    if (cap < 0 || (cap > 0 && !tiles_out)) return fail(MTQ_ERR_INVALID, "cap must be non-negative and tiles_out set when cap > 0");
     if (n_formats < 1 || n_formats > 4) return fail(MTQ_ERR_INVALID, "n_formats must be 1..4");
     for (int i = 0; i < n_formats; ++i)
         if (formats[i] < 0 || formats[i] > 3) return fail(MTQ_ERR_INVALID, "format codes are 0..3 (bf16, bfp8, bfp4, bfp2)");
     if (!aligned16(tiles_out)) return fail(MTQ_ERR_INVALID, "tiles_out must be 16-byte aligned");
     if (int rc = require_device()) return rc;
-    const int64_t th = (rows + kTile - 1) / kTile, tw = (cols + kTile - 1) / kTile, tiles = th * tw, total = count * tiles;
     if (tw > INT32_MAX || total > ((int64_t)1 << 40) || cap > (1 << 22)) return fail(MTQ_ERR_INVALID, "too many tiles for one launch");
-    const int64_t esz = in_dtype == MTQ_DTYPE_BF16 ? 2 : 4;
-    const int vec_ok = aligned16(x) && (ld * esz) % 16 == 0 && (stride_elems * esz) % 16 == 0;
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (hipMemsetAsync(list + cap, 0, sizeof(int64_t), s) != hipSuccess) return fail(MTQ_ERR_HIP, "hipMemsetAsync failed");
     hipLaunchKernelGGL(knife_list, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, near, total, cap, reinterpret_cast<long long *>(list));
@@ -502,11 +511,56 @@ extern "C" int mtq_knife_tiles_device(const void *x, int in_dtype, int64_t count
     int4 f = make_int4(formats[0], n_formats > 1 ? formats[1] : 0, n_formats > 2 ? formats[2] : 0, n_formats > 3 ? formats[3] : 0);
     if (in_dtype == MTQ_DTYPE_BF16)
         hipLaunchKernelGGL(knife_tiles<uint16_t>, dim3((unsigned)cap), dim3(64), 0, s, static_cast<const uint16_t *>(x), stride_elems, rows, cols, ld, (int)tw, tiles,
-                           reinterpret_cast<const long long *>(list), cap, f, n_formats, tiles_out, vec_ok);
+                           reinterpret_cast<const long long *>(list), cap, f, n_formats, tiles_out, vec_ok, tb);
     else
         hipLaunchKernelGGL(knife_tiles<float>, dim3((unsigned)cap), dim3(64), 0, s, static_cast<const float *>(x), stride_elems, rows, cols, ld, (int)tw, tiles,
-                           reinterpret_cast<const long long *>(list), cap, f, n_formats, tiles_out, vec_ok);
+                           reinterpret_cast<const long long *>(list), cap, f, n_formats, tiles_out, vec_ok, tb);
     return check_launch("mtq_knife_tiles_device");
+}
+
+static const RaggedTable kUniform{};   // n = 0: the kernel's other arguments describe a uniform batch
+
+extern "C" int mtq_knife_tiles_device(const void *x, int in_dtype, int64_t count, int64_t stride_elems, int64_t rows, int64_t cols, int64_t ld,
+                                      const int8_t *near, const int *formats, int n_formats, int64_t cap, int64_t *list, float *tiles_out, void *stream)
+{
+    if (int rc = check_matrix(x, in_dtype, rows, cols, ld)) return rc;
+    if (count <= 0) return fail(MTQ_ERR_INVALID, "count must be positive");
+    const int64_t th = (rows + kTile - 1) / kTile, tw = (cols + kTile - 1) / kTile, tiles = th * tw, total = count * tiles;
+    const int64_t esz = in_dtype == MTQ_DTYPE_BF16 ? 2 : 4;
+    const int vec_ok = aligned16(x) && (ld * esz) % 16 == 0 && (stride_elems * esz) % 16 == 0;
+    return knife_tiles_launch(x, in_dtype, stride_elems, rows, cols, ld, tw, tiles, total, vec_ok, kUniform, near, formats, n_formats, cap, list, tiles_out, stream);
+}
+
+// The table of a ragged batch from the caller's matrices (include/mtq.h, MtqMatrix): every matrix checked as mtq_tile_stats checks one.
+static int ragged_table(const MtqMatrix *mats, int n, int in_dtype, RaggedTable &tb)
+{
+    if (!mats) return fail(MTQ_ERR_INVALID, "mats is null");
+    if (n <= 0 || n > kRaggedMax) return fail(MTQ_ERR_INVALID, "a ragged batch holds 1..MTQ_RAGGED_MAX matrices");
+    const int64_t esz = in_dtype == MTQ_DTYPE_BF16 ? 2 : 4;
+    int64_t first = 0;
+    for (int j = 0; j < n; ++j) {
+        const MtqMatrix &m = mats[j];
+        if (int rc = check_matrix(m.x, in_dtype, m.rows, m.cols, m.ld)) return rc;
+        const int64_t th = (m.rows + kTile - 1) / kTile, tw = (m.cols + kTile - 1) / kTile;
+        if (tw > INT32_MAX || first + th * tw >= ((int64_t)1 << 31)) return fail(MTQ_ERR_INVALID, "too many tiles for one launch");
+        RaggedSeg &s = tb.seg[j];
+        s.x = m.x; s.rows = m.rows; s.cols = m.cols; s.ld = m.ld;
+        s.tiles_w = (uint32_t)tw; s.first = (uint32_t)first;
+        s.vec_ok = aligned16(m.x) && (m.ld * esz) % 16 == 0;
+        s.pad_ = 0;
+        first += th * tw;
+    }
+    tb.n = (uint32_t)n;
+    tb.total = (uint32_t)first;
+    return MTQ_OK;
+}
+
+extern "C" int mtq_knife_tiles_ragged(const MtqMatrix *mats, int n, int in_dtype, const int8_t *near, const int *formats, int n_formats, int64_t cap,
+                                      int64_t *list, float *tiles_out, void *stream)
+{
+    RaggedTable tb{};
+    if (int rc = ragged_table(mats, n, in_dtype, tb)) return rc;
+    return knife_tiles_launch(nullptr, in_dtype, 0, 0, 0, 0, 1, 1, tb.total, 0, tb, near, formats, n_formats, cap, list, tiles_out, stream);
 }
 
 extern "C" int mtq_selftest_slot_ring(void)
@@ -629,7 +683,7 @@ static int tile_stats_launch(const void *x, int in_dtype, int64_t count, int64_t
         }
         const int64_t waves = (count * tiles + 63) / 64;
         hipLaunchKernelGGL(tile_stats_redo_flagged<uint16_t>, dim3((unsigned)std::min<int64_t>((waves + 3) / 4, kRedoBlocks)), dim3(256), 0, static_cast<hipStream_t>(stream),
-                           static_cast<const uint16_t *>(x), count, stride_elems, rows, cols, ld, (int)tw, tiles, fmt_mask, rec, stats, vec_ok, work.counters, launch_id);
+                           static_cast<const uint16_t *>(x), count, stride_elems, rows, cols, ld, (int)tw, tiles, fmt_mask, rec, stats, vec_ok, work.counters, launch_id, kUniform);
         return finish_counter_launch(work, static_cast<hipStream_t>(stream));
     }
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -644,19 +698,19 @@ static int tile_stats_launch(const void *x, int in_dtype, int64_t count, int64_t
         const dim3 rgrid((unsigned)std::min<int64_t>(((count * tiles + 63) / 64 + 3) / 4, kRedoBlocks));
         if (in_dtype == MTQ_DTYPE_BF16)
             hipLaunchKernelGGL(tile_stats_redo_flagged<uint16_t>, rgrid, dim3(256), 0, s, static_cast<const uint16_t *>(x), count, stride_elems,
-                               rows, cols, ld, (int)tw, tiles, fmt_mask, rec, stats, vec_ok, work.counters, launch_id);
+                               rows, cols, ld, (int)tw, tiles, fmt_mask, rec, stats, vec_ok, work.counters, launch_id, kUniform);
         else
             hipLaunchKernelGGL(tile_stats_redo_flagged<float>, rgrid, dim3(256), 0, s, static_cast<const float *>(x), count, stride_elems, rows,
-                               cols, ld, (int)tw, tiles, fmt_mask, rec, stats, vec_ok, work.counters, launch_id);
+                               cols, ld, (int)tw, tiles, fmt_mask, rec, stats, vec_ok, work.counters, launch_id, kUniform);
         return finish_counter_launch(work, s);
     }
     const int64_t blocks = (count * tiles + 3) / 4;
     if (in_dtype == MTQ_DTYPE_BF16)
         hipLaunchKernelGGL(tile_stats_generic<uint16_t>, dim3((unsigned)blocks), dim3(256), 0, s, static_cast<const uint16_t *>(x), count,
-                           stride_elems, rows, cols, ld, (int)tw, tiles, fmt_mask, rec, stats, vec_ok);
+                           stride_elems, rows, cols, ld, (int)tw, tiles, fmt_mask, rec, stats, vec_ok, kUniform);
     else
         hipLaunchKernelGGL(tile_stats_generic<float>, dim3((unsigned)blocks), dim3(256), 0, s, static_cast<const float *>(x), count,
-                           stride_elems, rows, cols, ld, (int)tw, tiles, fmt_mask, rec, stats, vec_ok);
+                           stride_elems, rows, cols, ld, (int)tw, tiles, fmt_mask, rec, stats, vec_ok, kUniform);
     return check_launch("mtq_tile_stats");
 }
 
@@ -664,6 +718,47 @@ extern "C" int mtq_tile_stats_batched(const void *x, int in_dtype, int64_t count
                                       int64_t cols, int64_t ld, uint32_t fmt_mask, double *stats, void *stream)
 {
     return tile_stats_launch(x, in_dtype, count, stride_elems, rows, cols, ld, fmt_mask, fmt_mask, 0u, stats, stream);
+}
+
+int mtq_launch_tile_stats_direct_ragged(const mtq::RaggedTable &tb, int in_dtype, uint32_t fmt_mask, double *stats, void *stream,
+                                        mtq::WorkSlot *work_out, unsigned launch_id);
+
+// K1 over a ragged batch (include/mtq.h): the direct kernel over the batch's tiles numbered through, then its fix-up — two launches whatever
+// the number of matrices.
+extern "C" int mtq_tile_stats_ragged(const MtqMatrix *mats, int n, int in_dtype, uint32_t fmt_mask, double *stats, void *stream)
+{
+    if (in_dtype != MTQ_DTYPE_BF16 && in_dtype != MTQ_DTYPE_F32) return fail(MTQ_ERR_INVALID, "in_dtype must be MTQ_DTYPE_F32 or MTQ_DTYPE_BF16");
+    RaggedTable tb{};
+    if (int rc = ragged_table(mats, n, in_dtype, tb)) return rc;
+    if (!stats) return fail(MTQ_ERR_INVALID, "stats is null");
+    if ((fmt_mask & ~MTQ_MASK_ALL) != 0) return fail(MTQ_ERR_INVALID, "fmt_mask has bits outside bf16|bfp8|bfp4|bfp2");
+    if (int rc = require_device()) return rc;
+    const int rec = (int)mtq_stats_record_doubles(fmt_mask);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if ((fmt_mask & MTQ_MASK_ALL) != 0 && !force_generic()) {
+        WorkSlot work;
+        const unsigned launch_id = next_launch_id();
+        if (int rc = mtq_launch_tile_stats_direct_ragged(tb, in_dtype, fmt_mask, stats, stream, &work, launch_id)) {
+            work_counter_abandon(work);
+            return rc;
+        }
+        const dim3 rgrid((unsigned)std::min<int64_t>((((int64_t)tb.total + 63) / 64 + 3) / 4, kRedoBlocks));
+        if (in_dtype == MTQ_DTYPE_BF16)
+            hipLaunchKernelGGL(tile_stats_redo_flagged<uint16_t>, rgrid, dim3(256), 0, s, static_cast<const uint16_t *>(nullptr), 0, 0, 0, 0, 0, 1, 1, fmt_mask,
+                               rec, stats, 0, work.counters, launch_id, tb);
+        else
+            hipLaunchKernelGGL(tile_stats_redo_flagged<float>, rgrid, dim3(256), 0, s, static_cast<const float *>(nullptr), 0, 0, 0, 0, 0, 1, 1, fmt_mask, rec,
+                               stats, 0, work.counters, launch_id, tb);
+        return finish_counter_launch(work, s);
+    }
+    const int64_t blocks = ((int64_t)tb.total + 3) / 4;
+    if (in_dtype == MTQ_DTYPE_BF16)
+        hipLaunchKernelGGL(tile_stats_generic<uint16_t>, dim3((unsigned)blocks), dim3(256), 0, s, static_cast<const uint16_t *>(nullptr), 0, 0, 0, 0, 0, 1, 1,
+                           fmt_mask, rec, stats, 0, tb);
+    else
+        hipLaunchKernelGGL(tile_stats_generic<float>, dim3((unsigned)blocks), dim3(256), 0, s, static_cast<const float *>(nullptr), 0, 0, 0, 0, 0, 1, 1, fmt_mask,
+                           rec, stats, 0, tb);
+    return check_launch("mtq_tile_stats_ragged");
 }
 
 extern "C" int mtq_tile_stats_partial(const void *x, int in_dtype, int64_t count, int64_t stride_elems, int64_t rows, int64_t cols,

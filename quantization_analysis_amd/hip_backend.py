@@ -33,6 +33,7 @@ EXPORTS = [
     "mtq_rng_create", "mtq_rng_permutation", "mtq_rng_integers", "mtq_rng_destroy", "mtq_greedy_run", "mtq_greedy_run_batch",
     "mtq_selftest_slot_ring", "mtq_device_copy_2d", "mtq_knife_tiles_device", "mtq_greedy_scan_scratch_bytes", "mtq_greedy_scan_device", "mtq_greedy_scan_device_ex", "mtq_scan_carry_bytes",
     "mtq_scan_orders_bytes", "mtq_scan_orders_device", "mtq_debug_scan_ticks", "mtq_threshold_enqueue", "mtq_threshold_columns",
+    "mtq_tile_stats_ragged", "mtq_knife_tiles_ragged", "mtq_column_sums_device_ragged", "mtq_threshold_enqueue_ragged", "mtq_threshold_columns_ragged",
 ]
 
 
@@ -122,8 +123,13 @@ def lib() -> ctypes.CDLL:
     L.mtq_selftest_slot_ring.restype = ci
     L.mtq_device_copy_2d.argtypes = [vp, ctypes.c_size_t, vp, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_size_t, vp]
     L.mtq_knife_tiles_device.argtypes = [vp, ci, i64, i64, i64, i64, i64, vp, vp, ci, i64, vp, vp, vp]
-    L.mtq_threshold_enqueue.argtypes = [vp, ci, i64, i64, i64, i64, i64, u32, u32, vp, ci, ci, dbl, dbl, vp, vp, vp, i64, vp, vp, vp, vp, vp]
+    L.mtq_threshold_enqueue.argtypes = [vp, ci, i64, i64, i64, i64, i64, u32, u32, vp, ci, ci, dbl, dbl, vp, vp, vp, i64, vp, vp, vp, vp, vp, vp, vp]
     L.mtq_threshold_columns.argtypes = [vp, i64, i64, u32, vp, vp, vp, vp]
+    L.mtq_tile_stats_ragged.argtypes = [vp, ci, ci, u32, vp, vp]
+    L.mtq_knife_tiles_ragged.argtypes = [vp, ci, ci, vp, vp, ci, i64, vp, vp, vp]
+    L.mtq_column_sums_device_ragged.argtypes = [vp, vp, ci, u32, vp, vp, vp]
+    L.mtq_threshold_enqueue_ragged.argtypes = [vp, ci, ci, u32, u32, vp, ci, ci, dbl, dbl, vp, vp, vp, i64, vp, vp, vp, vp, vp, vp, vp]
+    L.mtq_threshold_columns_ragged.argtypes = [vp, vp, ci, u32, vp, vp, vp, vp]
     if L.mtq_version() < 141:
         raise MtqError("libmtq_hip.so is older than this package")
     _lib = L
@@ -318,6 +324,42 @@ def tile_stats_batched(x3d, mask: int, out=None):
         out = torch.empty((count, th * tw, rec), dtype=torch.float64, device=x3d.device)
     check(lib().mtq_tile_stats_batched(x3d.data_ptr(), _dtype_code(x3d), count, rows * cols, rows, cols, cols, mask,
                                        out.data_ptr(), _stream_ptr()))
+    return out
+
+
+RAGGED_MAX = 24   # include/mtq.h MTQ_RAGGED_MAX
+
+
+class MtqMatrix(ctypes.Structure):
+    """include/mtq.h MtqMatrix: one matrix of a ragged batch (device pointer, leading dimension in elements)."""
+    _fields_ = [("x", ctypes.c_void_p), ("rows", ctypes.c_int64), ("cols", ctypes.c_int64), ("ld", ctypes.c_int64)]
+
+
+def ragged_matrices(mats):
+    """(MtqMatrix array, storage code, tiles per matrix) of 2-D device tensors of one storage type with contiguous rows."""
+    require_gpu()
+    if not 0 < len(mats) <= RAGGED_MAX:
+        raise MtqError(f"a ragged batch holds 1..{RAGGED_MAX} matrices")
+    code = _dtype_code(mats[0])
+    arr = (MtqMatrix * len(mats))()
+    tiles = []
+    for j, m in enumerate(mats):
+        if m.dim() != 2 or not m.is_cuda or m.stride(1) != 1 or _dtype_code(m) != code or m.device != mats[0].device:
+            raise MtqError("a ragged batch is 2-D tensors of one storage type on one device with contiguous rows")
+        arr[j] = MtqMatrix(m.data_ptr(), m.shape[0], m.shape[1], m.stride(0))
+        th, tw = tiles_hw(m.shape[0], m.shape[1])
+        tiles.append(th * tw)
+    return arr, code, tiles
+
+
+def tile_stats_ragged(mats, mask: int, out=None):
+    """K1 over matrices of ANY shapes (one storage type) in one launch (mtq_tile_stats_ragged) → [sum of their tiles, rec], matrix j's
+    tiles row-major behind matrix j-1's."""
+    torch = _torch()
+    arr, code, tiles = ragged_matrices(mats)
+    if out is None:
+        out = torch.empty((sum(tiles), record_doubles(mask)), dtype=torch.float64, device=mats[0].device)
+    check(lib().mtq_tile_stats_ragged(arr, len(mats), code, mask, out.data_ptr(), _stream_ptr()))
     return out
 
 

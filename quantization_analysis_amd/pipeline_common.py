@@ -95,9 +95,11 @@ def _when_landed(event, fn, *args):
     return fn(*args)
 
 
-def columns_from_sums_batch(sums: np.ndarray, n: float) -> np.ndarray:
+def columns_from_sums_batch(sums: np.ndarray, n) -> np.ndarray:
     """mtq_columns_from_sums for many tensors at once: sums [count, 7] (Σx, Σx², Σy, Σy², Σxy, Σ|d|, max|d|) → [count, 3]
-    pcc, mae, atol — the same double operations in the same order (metrics.py:6-16 as moments), element-wise in NumPy."""
+    pcc, mae, atol — the same double operations in the same order (metrics.py:6-16 as moments), element-wise in NumPy.  n: the tensors'
+    element count, one number or one per tensor."""
+    n = np.asarray(n, dtype=np.float64)
     sx, sx2, sy, sy2, sxy, sab, mx = (sums[:, i] for i in range(7))
     mean_x, mean_y = sx / n, sy / n
     am2 = np.maximum(sx2 - n * mean_x * mean_x, 0.0)
@@ -105,4 +107,5 @@ def columns_from_sums_batch(sums: np.ndarray, n: float) -> np.ndarray:
     denom = np.sqrt(am2 * bm2)
     with np.errstate(all="ignore"):
         pcc = np.where(denom == 0.0, np.where(sab == 0.0, 1.0, 0.0), (sxy - n * mean_x * mean_y) / denom)
-    return np.stack([pcc, sab / n if n != 0.0 else np.zeros_like(sab), mx], axis=1)
+        mae = np.where(n != 0.0, sab / n, 0.0)
+    return np.stack([pcc, mae, mx], axis=1)

@@ -6,7 +6,7 @@ import contextlib
 import ctypes
 import os
 import time
-from dataclasses import dataclass, field
+from dataclasses import replace
 
 import numpy as np
 
@@ -39,6 +39,7 @@ class ThresholdPipeline:
         self.knife_tiles = 0
         self._side = torch.cuda.Stream()      # the knife-edge tiles' fetch and way home, beside the main stream's K1
         self.knife_cap = settings().knife_cap   # knife-edge tiles per chunk fetched without a round trip (more: one extra trip)
+        self._scratch_n = int(hb.lib().mtq_columns_scratch_doubles())
         self._pin = {}
         self._dev = {}
 
@@ -127,11 +128,101 @@ class ThresholdPipeline:
         batch's column sums; one wait at the end, then the results are wrapped.  Every batch has its own pinned mirrors (slot = its
         position).  Same results as run() per batch (tests/test_hip_kernels.py::test_threshold_run_batches_equals_run)."""
         items = [(b, None) if not isinstance(b, (tuple, list)) else (b[0], b[1]) for b in batches]
-        states = [self.enqueue(x, n, slot=i, overlap=True) for i, (x, n) in enumerate(items)]
+        # Batches the direct kernel serves anyway (float32 storage; bf16 the LDS-staged kernel does not take) travel as RAGGED groups: one
+        # launch per stage for up to hb.RAGGED_MAX matrices of any shapes (mtq_threshold_enqueue_ragged) instead of a launch chain per
+        # batch — the chains, not the arithmetic, were a model's small tensors' time.  The largest group first: its K1 runs while the host
+        # enqueues the others (about 0.1 ms of driver time each).
+        plan, ragged = [], {}
+        for i, (x, n) in enumerate(items):
+            if settings().threshold_ragged and self._raggable(x):
+                ragged.setdefault((x.dtype, x.device), []).append(i)
+            else:
+                plan.append(("uniform", [i]))
+        for members in ragged.values():
+            group, used = [], 0
+            for i in members:
+                if group and used + items[i][0].shape[0] > hb.RAGGED_MAX:
+                    plan.append(("ragged", group))
+                    group, used = [], 0
+                group.append(i)
+                used += items[i][0].shape[0]
+            plan.append(("ragged", group))
+        weight = lambda g: sum(items[i][0].numel() for i in g[1])
+        plan.sort(key=weight, reverse=True)
+        states = []
+        for slot, (kind, members) in enumerate(plan):
+            if kind == "uniform":
+                states.append(self.enqueue(items[members[0]][0], items[members[0]][1], slot=slot, overlap=True))
+            else:
+                states.append(self.enqueue_ragged([items[i] for i in members], slot=slot, overlap=len(plan) > 1))
         for st in states:
             self.decide(st)
         self.torch.cuda.current_stream().synchronize()
-        return [self.wrap(st) for st in states]
+        out: list = [None] * len(items)
+        for (kind, members), st in zip(plan, states):
+            res = self.wrap(st)
+            if kind == "uniform":
+                out[members[0]] = res
+            else:
+                at = 0
+                for i in members:
+                    c = items[i][0].shape[0]
+                    out[i] = [replace(r, index=j) for j, r in enumerate(res[at:at + c])]
+                    at += c
+        return out
+
+    def _raggable(self, x3d) -> bool:
+        """A batch of few matrices that K1's direct kernel serves anyway (hb.RAGGED_MAX of them fit a launch; the LDS-staged bf16 kernel
+        is the faster one where it applies: csrc/mtq_kernels.hip tile_stats_launch)."""
+        count, rows, cols = x3d.shape
+        if count > 4 or x3d.stride(2) != 1:
+            return False
+        staged = (x3d.dtype == self.torch.bfloat16 and rows % 32 == 0 and cols % 128 == 0 and x3d.data_ptr() % 16 == 0
+                  and (x3d.stride(1) * 2) % 16 == 0 and (x3d.stride(0) * 2) % 16 == 0 and (self.mask & 0xE))
+        return not staged
+
+    def enqueue_ragged(self, group, slot: int = 0, overlap: bool = False) -> dict:
+        """GPU half of a RAGGED group — `group` = (x3d, numel | None) batches of one storage type, every matrix of them an entry of the
+        launch's table: K1 → K4 → maps and masks home → knife-edge listing, one launch each for the whole group (mtq_threshold_enqueue_ragged).
+        The state reads like enqueue()'s with one chunk whose tiles are numbered through the group's matrices."""
+        torch = self.torch
+        mats, numels = [], []
+        for x3d, numel in group:
+            for j in range(x3d.shape[0]):
+                mats.append(x3d[j])
+                numels.append(x3d.shape[1] * x3d.shape[2] if numel is None else int(numel))
+        arr, code, tiles_per = hb.ragged_matrices(mats)
+        dev = mats[0].device
+        T, n = sum(tiles_per), len(mats)
+        identity = mats[0].dtype == torch.bfloat16 and (self.mask & 1) and (self.mask & 0xE)
+        k1_mask = self.mask & 0xE if identity else self.mask
+        dec_mask = k1_mask | hb.MASK_BF16_IDENTITY if identity else self.mask
+        P = 1 + len(self.pure_formats)
+        planes = 1 + len(self.tile_formats)
+        single = not overlap
+        cap = min(self.knife_cap, T)
+        both_host = self._pinned(f"both{slot}", 2 * T, torch.int8).view(2, T)
+        idx_host = self._pinned(f"idx{slot}", cap + 1, torch.int64).view(1, cap + 1)
+        knife_host = self._pinned(f"knife{slot}", planes * cap * 1024, torch.float32).view(1, planes, cap, 32, 32)
+        sums_host = self._pinned(f"sums{slot}", P * n * 11, torch.float64).view(P, n, 11)
+        both_dev = self._devbuf(f"both{slot}", 2 * T, torch.int8, dev).view(2, T)
+        idx_dev = self._devbuf(f"idx{slot}", cap + 1, torch.int64, dev).view(1, cap + 1)
+        knife_dev = self._devbuf(f"knife{slot}", planes * cap * 1024, torch.float32, dev).view(1, planes, cap, 32, 32)
+        rec = hb.record_doubles(k1_mask)
+        recs = self._devbuf(f"recs{slot}", T * rec, torch.float64, dev).view(T, rec)
+        fm = (ctypes.c_int * len(self.tile_formats))(*[MIXED_TILE_FORMATS.index(f) for f in self.tile_formats])
+        scratch = self._devbuf(f"colscr{slot}_0", P * n * self._scratch_n, torch.float64, dev)
+        hb.check(hb.lib().mtq_threshold_enqueue_ragged(
+            arr, n, code, k1_mask, dec_mask, fm, len(self.tile_formats), hb.METRIC_CODE[self.metric], self.threshold, self.band, recs.data_ptr(),
+            both_dev.data_ptr(), both_host.data_ptr(), cap, idx_dev[0].data_ptr(), knife_dev[0].data_ptr(), idx_host[0].data_ptr(),
+            scratch.data_ptr(), sums_host.data_ptr(), torch.cuda.current_stream().cuda_stream, None if single else self._side.cuda_stream))
+        landed = torch.cuda.Event()
+        landed.record(torch.cuda.current_stream() if single else self._side)
+        first = np.concatenate([[0], np.cumsum(tiles_per)]).astype(np.int64)
+        return {"x": None, "ragged": {"mats": mats, "arr": arr, "tiles_per": tiles_per, "first": first, "numels": numels}, "tiles_sent": False, "slot": slot, "speculated": True,
+                "numel": None, "hw": None, "tiles": T, "dec_mask": dec_mask, "cap": cap, "single": single, "planes": planes,
+                "launched": [(0, n, recs, slice(0, T), landed, landed)], "both_host": both_host, "idx_host": idx_host, "knife_host": knife_host,
+                "sums_host": sums_host, "both_dev": both_dev, "idx_dev": idx_dev, "knife_dev": knife_dev, "maps": np.empty((T,), dtype=np.int8)}
 
     def enqueue(self, x3d, numel: int | None = None, slot: int = 0, overlap: bool = False) -> dict:
         """GPU half of a batch, nothing waited for: per chunk K1 → K4 → map and knife-edge mask home → (side stream) the chunk's knife-edge
@@ -156,7 +247,7 @@ class ThresholdPipeline:
         both_host = self._pinned(f"both{slot}", 2 * count * tiles, torch.int8).view(2, count * tiles)
         idx_host = self._pinned(f"idx{slot}", len(chunks) * (cap + 1), torch.int64).view(len(chunks), cap + 1)
         knife_host = self._pinned(f"knife{slot}", len(chunks) * planes * cap * 1024, torch.float32).view(len(chunks), planes, cap, 32, 32)
-        sums_host = self._pinned(f"sums{slot}", P * count * 7, torch.float64).view(P, count, 7)
+        sums_host = self._pinned(f"sums{slot}", P * count * 11, torch.float64).view(P, count, 11)
         both_dev = self._devbuf(f"both{slot}", 2 * count * tiles, torch.int8, dev).view(2, count * tiles)   # row 0 the maps, row 1 the knife-edge masks
         idx_dev = self._devbuf(f"idx{slot}", len(chunks) * (cap + 1), torch.int64, dev).view(len(chunks), cap + 1)
         knife_dev = self._devbuf(f"knife{slot}", len(chunks) * planes * cap * 1024, torch.float32, dev).view(len(chunks), planes, cap, 32, 32)
@@ -164,6 +255,7 @@ class ThresholdPipeline:
         recs_all = self._devbuf(f"recs{slot}", count * tiles * rec, torch.float64, dev).view(count, tiles, rec)
         fm = (ctypes.c_int * len(self.tile_formats))(*[MIXED_TILE_FORMATS.index(f) for f in self.tile_formats])
         main_ptr = torch.cuda.current_stream().cuda_stream
+        speculated = len(chunks) == 1   # one chunk: the call sums the columns under K4's maps at once (final unless a knife-edge tile is listed)
         launched = []  # (first, n, records, chunk's tile range, map-landed event, knife-tiles-landed event)
         for c, (first, n) in enumerate(chunks):
             # ONE call per chunk (mtq_threshold_enqueue): K1 → K4 → map and knife-edge masks into the pinned mirror on the main stream; then,
@@ -190,15 +282,17 @@ class ThresholdPipeline:
                     landed = torch.cuda.Event()
                     landed.record()
             else:
+                scratch = self._devbuf(f"colscr{slot}_{c}", P * n * self._scratch_n, torch.float64, dev)
                 hb.check(hb.lib().mtq_threshold_enqueue(
                     xs.data_ptr(), hb._dtype_code(xs), n, xs.stride(0) if n > 1 else rows * xs.stride(1), rows, cols, xs.stride(1), k1_mask, dec_mask, fm,
                     len(self.tile_formats), hb.METRIC_CODE[self.metric], self.threshold, self.band, recs.data_ptr(), both_dev.data_ptr(), both_host.data_ptr(),
-                    cap, idx_dev[c].data_ptr(), knife_dev[c].data_ptr(), idx_host[c].data_ptr(), main_ptr, None if single else self._side.cuda_stream))
+                    cap, idx_dev[c].data_ptr(), knife_dev[c].data_ptr(), idx_host[c].data_ptr(), scratch.data_ptr(), sums_host.data_ptr(), main_ptr,
+                    None if single else self._side.cuda_stream))
                 landed = torch.cuda.Event()
                 landed.record(torch.cuda.current_stream() if single else self._side)
                 decided = landed      # the side stream runs behind the masks' copy: one event covers both
             launched.append((first, n, recs, part, decided, landed))
-        return {"x": x3d, "tiles_sent": False, "slot": slot, "numel": numel, "hw": (th, tw), "tiles": tiles, "dec_mask": dec_mask, "cap": cap, "single": single, "planes": planes,
+        return {"x": x3d, "tiles_sent": False, "slot": slot, "speculated": speculated, "numel": numel, "hw": (th, tw), "tiles": tiles, "dec_mask": dec_mask, "cap": cap, "single": single, "planes": planes,
                 "launched": launched, "both_host": both_host, "idx_host": idx_host, "knife_host": knife_host, "sums_host": sums_host,
                 "both_dev": both_dev, "idx_dev": idx_dev, "knife_dev": knife_dev, "maps": np.empty((count, tiles), dtype=np.int8)}
 
@@ -207,17 +301,22 @@ class ThresholdPipeline:
         (mixed_tile_threshold.py:117-123 on the reference's own score), the patched map back up, the column sums launched and sent home."""
         torch = self.torch
         x3d, tiles, cap, planes, dec_mask = st["x"], st["tiles"], st["cap"], st["planes"], st["dec_mask"]
-        dev = x3d.device
-        tw = st["hw"][1]
+        rg = st.get("ragged")
+        dev = st["both_dev"].device
+        tw = None if rg else st["hw"][1]
         both_host, idx_host, knife_host, sums_host = st["both_host"], st["idx_host"], st["knife_host"], st["sums_host"]
         both_dev, idx_dev, knife_dev, maps_all = st["both_dev"], st["idx_dev"], st["knife_dev"], st["maps"]
-        scratch_n = int(hb.lib().mtq_columns_scratch_doubles())
+        scratch_n = self._scratch_n
         P = 1 + len(self.pure_formats)
         for c, (first, n, recs, part, decided, landed) in enumerate(st["launched"]):
             landed.synchronize()      # the chunk's list is home ...
             decided.synchronize()     # ... and its map (recorded earlier: passed by now unless the list took the side stream)
-            maps_all[first:first + n] = both_host[0, part].numpy().reshape(n, tiles)           # the mirror is reused by the slot's next batch
+            if rg:
+                maps_all[:] = both_host[0, part].numpy()
+            else:
+                maps_all[first:first + n] = both_host[0, part].numpy().reshape(n, tiles)       # the mirror is reused by the slot's next batch
             k = int(idx_host[c, cap])
+            final = st["speculated"] and k == 0    # the sums the enqueue call launched under K4's maps stand
             if k:
                 near = both_host[1, part].numpy()
                 if k <= cap:
@@ -230,40 +329,67 @@ class ThresholdPipeline:
                     else:
                         host_tiles = knife_host[c, :, :k].numpy()
                     where = idx_dev[c, :k]
+                elif rg:                                                                       # more than the list holds, ragged: matrix by matrix
+                    flat = np.flatnonzero(near).astype(np.int64)
+                    where = torch.from_numpy(flat).to(dev)
+                    owner = np.searchsorted(rg["first"], flat, side="right") - 1
+                    parts = []
+                    for j in np.unique(owner):
+                        m = rg["mats"][j]
+                        local = torch.from_numpy(flat[owner == j] - rg["first"][j]).to(dev)
+                        parts.append(self._knife_tiles_device(m[None], local, rg["tiles_per"][j], hb.tiles_hw(*m.shape)[1]).cpu().numpy())
+                    host_tiles = np.concatenate(parts, axis=1)
                 else:                                                                          # more than the list holds: the same steps, one more trip
                     flat = np.flatnonzero(near).astype(np.int64)
                     where = torch.from_numpy(flat).to(dev)
                     host_tiles = self._knife_tiles_device(x3d[first:first + n], where, tiles, tw).cpu().numpy()
-                mchunk = maps_all[first:first + n].reshape(-1)
+                mchunk = maps_all if rg else maps_all[first:first + n].reshape(-1)
                 new = self._decide(host_tiles, mchunk[flat], near[flat])
                 mchunk[flat] = new
                 both_dev[0, part].index_put_((where,), torch.from_numpy(np.ascontiguousarray(new, dtype=np.int8)).to(dev, non_blocking=True))
                 self.knife_tiles += k
-            dmaps = both_dev[0, part].view(n, tiles)
+            dmaps = both_dev[0, part]
             scratch = self._devbuf(f"colscr{st['slot']}_{c}", P * n * scratch_n, torch.float64, dev).view(P, n, scratch_n)
             sp = hb._stream_ptr()
-            hb.check(hb.lib().mtq_threshold_columns(recs.data_ptr(), n, tiles, dec_mask, dmaps.data_ptr(), scratch[0].data_ptr(), sums_host[0, first:first + n].data_ptr(), sp))
+            if rg:
+                per = (ctypes.c_int64 * n)(*rg["tiles_per"])
+
+                def columns(maps_dev, q):
+                    hb.check(hb.lib().mtq_threshold_columns_ragged(recs.data_ptr(), per, n, dec_mask, maps_dev.data_ptr(), scratch[q].data_ptr(), sums_host[q].data_ptr(), sp))
+            else:
+                def columns(maps_dev, q):
+                    hb.check(hb.lib().mtq_threshold_columns(recs.data_ptr(), n, tiles, dec_mask, maps_dev.data_ptr(), scratch[q].data_ptr(), sums_host[q, first:first + n].data_ptr(), sp))
+            if not final:
+                columns(dmaps, 0)
             for q, f in enumerate(self.pure_formats):   # wq's `none` rows from the same records
-                pm = torch.full((n, tiles), MIXED_TILE_FORMATS.index(f), dtype=torch.int8, device=dev)
-                hb.check(hb.lib().mtq_threshold_columns(recs.data_ptr(), n, tiles, dec_mask, pm.data_ptr(), scratch[1 + q].data_ptr(), sums_host[1 + q, first:first + n].data_ptr(), sp))
+                columns(torch.full((dmaps.numel(),), MIXED_TILE_FORMATS.index(f), dtype=torch.int8, device=dev), 1 + q)
 
     def wrap(self, st: dict) -> list[TensorResult]:
-        """Host half, part 2 (behind a wait for the main stream): counts from the host's copy of the maps (np.bincount per tensor — what the
-        reference does, mixed_tile_threshold.py:133-135), the columns from the seven sums."""
-        th, tw = st["hw"]
-        numel, maps_all = st["numel"], st["maps"]
-        count = maps_all.shape[0]
-        nf = len(MIXED_TILE_FORMATS)
+        """Host half, part 2 (behind a wait for the main stream): counts = the column kernel's histogram of the final device map (the
+        reference's np.bincount, mixed_tile_threshold.py:133-135 — on the host it cost more than the whole K4), the columns from the seven sums."""
+        rg = st.get("ragged")
+        maps_all = st["maps"]
         k = {"pcc": 0, "mae": 1, "atol": 2}[self.metric]
         sums = st["sums_host"].numpy()
-        cols = columns_from_sums_batch(sums[0], float(numel))
-        pure_cols = [columns_from_sums_batch(sums[1 + i], float(numel)) for i in range(len(self.pure_formats))]
+        if rg:   # one tensor per matrix of the group, each with its own element count and tile grid
+            count = len(rg["mats"])
+            numel = np.asarray(rg["numels"], dtype=np.float64)
+            grids = [hb.tiles_hw(*m.shape) for m in rg["mats"]]
+            maps_of = [maps_all[rg["first"][j]:rg["first"][j + 1]] for j in range(count)]
+        else:
+            count = maps_all.shape[0]
+            numel = float(st["numel"])
+            grids = [st["hw"]] * count
+            maps_of = [maps_all[j] for j in range(count)]
+        cols = columns_from_sums_batch(sums[0], numel)
+        pure_cols = [columns_from_sums_batch(sums[1 + i], numel) for i in range(len(self.pure_formats))]
         results: list[TensorResult] = []
         for j in range(count):
-            bc = np.bincount(maps_all[j].view(np.uint8), minlength=nf)
-            counts = {f: int(bc[i]) for i, f in enumerate(MIXED_TILE_FORMATS)}
+            counts = {f: int(sums[0][j, 7 + i]) for i, f in enumerate(MIXED_TILE_FORMATS)}   # the column kernel's histogram of the final map
             pure = {f: tuple(float(v) for v in pure_cols[i][j]) for i, f in enumerate(self.pure_formats)} or None
-            results.append(TensorResult(j, maps_all[j].reshape(th, tw), counts, mixed_tile_total_bytes(counts), float(cols[j, 0]),
+            results.append(TensorResult(j, maps_of[j].reshape(grids[j]), counts, mixed_tile_total_bytes(counts), float(cols[j, 0]),
                                         float(cols[j, 1]), float(cols[j, 2]), float(cols[j, k]), pure))
         st["x"] = None
+        if rg:
+            rg["mats"] = None
         return results

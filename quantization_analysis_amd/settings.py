@@ -24,6 +24,7 @@ Python side (this module)
 | MTQ_SLIM_RECORDS | 1 | host-scan route, pcc: 3 doubles per format cross PCIe |
 | MTQ_K1_TWO_LAUNCH | 1 | K1 and its literal fix-up as two launches on two streams |
 | MTQ_KNIFE_CAP | 128 | knife-edge tiles per chunk listed without a second round trip (ThresholdPipeline) |
+| MTQ_THRESHOLD_RAGGED | 1 | run_batches sends batches the direct K1 serves as ragged groups (one launch per stage for many shapes) |
 | MTQ_SWEEP_THREADS | CPU share | literal-scoring threads of the sweep |
 | MTQ_WQ_MAX_SLOTS | 8 | record slots of `wq --backend hip`'s windows |
 | MTQ_WQ_DEVICE_SCAN_MAX_TILES | 2^22 | device-scan limit behind `wq` |
@@ -78,6 +79,7 @@ class Settings:
     slim_records: bool
     k1_two_launch: bool
     knife_cap: int
+    threshold_ragged: bool
     sweep_threads: int | None
     wq_max_slots: int
     wq_device_scan_max_tiles: int
@@ -97,7 +99,7 @@ def settings(refresh: bool = False) -> Settings:
             chunk_tasks=_int("MTQ_CHUNK_TASKS", 8), scan_workers=_int("MTQ_SCAN_WORKERS", None), device_scan=_flag("MTQ_DEVICE_SCAN", True),
             device_scan_max_tiles=_int("MTQ_DEVICE_SCAN_MAX_TILES", None), shared_orders=_flag("MTQ_SHARED_ORDERS", True), lazy=_flag("MTQ_LAZY", True),
             lazy_max_listed=float(os.environ.get("MTQ_LAZY_MAX_LISTED", "0.35")), identity_records=_flag("MTQ_IDENTITY_RECORDS", True),
-            slim_records=_flag("MTQ_SLIM_RECORDS", True), k1_two_launch=_flag("MTQ_K1_TWO_LAUNCH", True), knife_cap=_int("MTQ_KNIFE_CAP", 128),
+            slim_records=_flag("MTQ_SLIM_RECORDS", True), k1_two_launch=_flag("MTQ_K1_TWO_LAUNCH", True), knife_cap=_int("MTQ_KNIFE_CAP", 128), threshold_ragged=_flag("MTQ_THRESHOLD_RAGGED", True),
             sweep_threads=_int("MTQ_SWEEP_THREADS", None), wq_max_slots=_int("MTQ_WQ_MAX_SLOTS", 8),
             wq_device_scan_max_tiles=_int("MTQ_WQ_DEVICE_SCAN_MAX_TILES", 1 << 22), pipe_trace=os.environ.get("MTQ_PIPE_TRACE") == "1",
             numa_bind=_flag("MTQ_NUMA_BIND", True))

@@ -25,7 +25,7 @@ def test_header_symbols_exported():
     L = hb.lib()
     for name in declared:
         assert hasattr(L, name), name
-    assert L.mtq_version() == 142
+    assert L.mtq_version() == 143
     assert L.mtq_stats_record_doubles(0xF) == 22 and L.mtq_stats_record_doubles(0b0110) == 12
 
 
@@ -57,10 +57,27 @@ def test_argument_errors_are_reported():
     assert int(L.mtq_scan_orders_bytes(16384)) >= 128 + 2 * 4 * 16384 and int(L.mtq_scan_carry_bytes(3)) == 3 * int(L.mtq_scan_carry_bytes(1))
     assert int(L.mtq_greedy_scan_scratch_bytes(2, 100)) >= 2 * (100 * 8 * 8 + 100 * 4)
     # round 4: a threshold batch as one call — arguments first, device second
-    assert L.mtq_threshold_enqueue(p, 0, 1, 1024, 32, 32, 32, 0xE, 0x1E, fm, 4, 0, 0.999, 2e-6, None, p, p, 8, p, p, p, None, None) == -1 and b"null" in L.mtq_last_error()
-    assert L.mtq_threshold_enqueue(p, 0, 0, 1024, 32, 32, 32, 0xE, 0x1E, fm, 4, 0, 0.999, 2e-6, p, p, p, 8, p, p, p, None, None) == -1     # count 0
-    assert L.mtq_threshold_enqueue(p, 0, 1, 1024, 32, 32, 32, 0xE, 0x1E, fm, 4, 0, 0.999, 2e-6, p, p, p, -1, p, p, p, None, None) == -1    # negative cap
+    assert L.mtq_threshold_enqueue(p, 0, 1, 1024, 32, 32, 32, 0xE, 0x1E, fm, 4, 0, 0.999, 2e-6, None, p, p, 8, p, p, p, None, None, None, None) == -1 and b"null" in L.mtq_last_error()
+    assert L.mtq_threshold_enqueue(p, 0, 0, 1024, 32, 32, 32, 0xE, 0x1E, fm, 4, 0, 0.999, 2e-6, p, p, p, 8, p, p, p, None, None, None, None) == -1     # count 0
+    assert L.mtq_threshold_enqueue(p, 0, 1, 1024, 32, 32, 32, 0xE, 0x1E, fm, 4, 0, 0.999, 2e-6, p, p, p, -1, p, p, p, None, None, None, None) == -1    # negative cap
     assert L.mtq_threshold_columns(p, 1, 1, 0xE, p, p, None, None) == -1 and b"null" in L.mtq_last_error()
+    # ragged batches: the table's limits and every matrix checked before the device is asked for
+    M = (hb.MtqMatrix * 25)(*[hb.MtqMatrix(p, 32, 32, 32) for _ in range(25)])
+    assert L.mtq_tile_stats_ragged(None, 1, 1, 0xF, p, None) == -1 and b"null" in L.mtq_last_error()
+    assert L.mtq_tile_stats_ragged(M, 0, 1, 0xF, p, None) == -1 and L.mtq_tile_stats_ragged(M, 25, 1, 0xF, p, None) == -1 and b"MTQ_RAGGED_MAX" in L.mtq_last_error()
+    assert L.mtq_tile_stats_ragged(M, 2, 7, 0xF, p, None) == -1                                             # unknown storage type
+    assert L.mtq_tile_stats_ragged(M, 2, 1, 0xF, None, None) == -1 and L.mtq_tile_stats_ragged(M, 2, 1, 0x1F, p, None) == -1
+    M[1].ld = 16
+    assert L.mtq_tile_stats_ragged(M, 2, 1, 0xF, p, None) == -1                                             # a leading dimension below cols
+    M[1].ld, M[1].rows = 32, 0
+    assert L.mtq_knife_tiles_ragged(M, 2, 1, p, fm, 4, 8, p, p, None) == -1
+    assert L.mtq_threshold_enqueue_ragged(M, 2, 1, 0xF, 0xF, fm, 4, 0, 0.999, 2e-6, p, p, p, 8, p, p, p, None, None, None, None) == -1
+    M[1].rows = 32
+    assert L.mtq_threshold_enqueue_ragged(M, 2, 1, 0xF, 0xF, fm, 4, 0, 0.999, 2e-6, None, p, p, 8, p, p, p, None, None, None, None) == -1 and b"null" in L.mtq_last_error()
+    per = (ctypes.c_int64 * 3)(4, 0, 9)
+    assert L.mtq_column_sums_device_ragged(p, per, 3, 0xF, p, p, None) == -1 and b"tiles" in L.mtq_last_error()   # a tensor without tiles
+    assert L.mtq_column_sums_device_ragged(p, per, 30, 0xF, p, p, None) == -1
+    assert L.mtq_threshold_columns_ragged(p, per, 1, 0xF, p, p, None, None) == -1 and b"null" in L.mtq_last_error()
 
 
 def test_settings_are_read_once_and_refreshable(monkeypatch):

@@ -529,6 +529,91 @@ def test_threshold_run_batches_equals_run():
         assert np.array_equal(got[3][0].assignment, a) and got[3][0].counts == counts
 
 
+def _ragged_inputs(bf16: bool):
+    """Matrices of assorted shapes (whole tiles, ragged edges, one tile, a (n/32, 32) vector form, a strided view), some with values the
+    exact routes hand to the literal fix-up (NaN, inf, huge, subnormal)."""
+    kind = "heavy_bf16" if bf16 else "heavy_f32"
+    hosts = [gen(kind, 300 + i, sh) for i, sh in enumerate([(70, 100), (32, 32), (48, 32), (256, 512), (33, 17), (64, 1000)])]
+    hosts[0][3, 5], hosts[0][40, 99] = np.nan, np.inf
+    hosts[3][100, 200:216] = np.float32(3e38)
+    hosts[3][7, 64:80] = np.float32(1e-41)
+    hosts[5][:, 500:] = 0.0
+    wide = dev(np.concatenate([hosts[5], hosts[5]], axis=1), bf16)
+    mats = [dev(h, bf16) for h in hosts[:5]] + [wide[:, :1000]]                     # the last: rows 2000 elements apart
+    return hosts, mats
+
+
+@pytest.mark.parametrize("bf16", [False, True])
+@pytest.mark.parametrize("mask", [0xF, 0xE, 0x6])
+def test_tile_stats_ragged_equals_per_matrix(bf16, mask):
+    """mtq_tile_stats_ragged: one launch over matrices of any shapes — the records of mtq_tile_stats matrix by matrix, bit for bit
+    (marked tiles included: the fix-up reads the same table).  The literal kernel's form: test_pipeline_under_force_generic_switch."""
+    hosts, mats = _ragged_inputs(bf16)
+    got = hb.tile_stats_ragged(mats, mask).cpu().numpy().view(np.int64)
+    at = 0
+    for h, m in zip(hosts, mats):
+        want = hb.tile_stats(m, mask).cpu().numpy().view(np.int64)
+        assert np.array_equal(got[at:at + want.shape[0]], want), (h.shape, bf16, mask)
+        at += want.shape[0]
+    assert at == got.shape[0]
+    with pytest.raises(hb.MtqError):
+        hb.tile_stats_ragged(mats * 5, mask)                                          # 30 matrices: more than a table holds
+    with pytest.raises(hb.MtqError):
+        hb.tile_stats_ragged([mats[0], mats[1].float() if bf16 else mats[1].to(torch.bfloat16)], mask)   # two storage types
+
+
+def test_column_sums_ragged_equals_per_tensor():
+    """mtq_column_sums_device_ragged: every tensor of a ragged batch summed in the order mtq_column_sums_device uses for it alone."""
+    import ctypes
+
+    _hosts, mats = _ragged_inputs(False)
+    mats = [m for m in mats] + [dev(gen("normal_f32", 5, (2048, 2048)))]               # 4096 tiles: 16 partial blocks
+    per = [hb.tiles_hw(*m.shape)[0] * hb.tiles_hw(*m.shape)[1] for m in mats]
+    recs = hb.tile_stats_ragged(mats, 0xF)
+    g = torch.Generator(device="cuda"); g.manual_seed(3)
+    maps = torch.randint(0, 4, (sum(per),), generator=g, device="cuda").to(torch.int8)
+    sn = int(hb.lib().mtq_columns_scratch_doubles())
+    scratch = torch.zeros((len(mats), sn), dtype=torch.float64, device="cuda")
+    hb.check(hb.lib().mtq_column_sums_device_ragged(recs.data_ptr(), (ctypes.c_int64 * len(per))(*per), len(per), 0xF, maps.data_ptr(), scratch.data_ptr(), None))
+    at = 0
+    for j, t in enumerate(per):
+        one = torch.zeros((sn,), dtype=torch.float64, device="cuda")
+        hb.check(hb.lib().mtq_column_sums_device(recs[at:at + t].contiguous().data_ptr(), t, 0xF, maps[at:at + t].contiguous().data_ptr(), one.data_ptr(), None))
+        a, b = scratch[j, :11].cpu().numpy().view(np.int64), one[:11].cpu().numpy().view(np.int64)
+        assert np.array_equal(a, b), (j, t)
+        assert np.array_equal(scratch[j, 7:11].cpu().numpy(), np.bincount(maps[at:at + t].cpu().numpy().view(np.uint8), minlength=4).astype(np.float64))
+        at += t
+
+
+@pytest.mark.parametrize("knife_cap", [128, 1])
+def test_threshold_ragged_groups(monkeypatch, knife_cap):
+    """run_batches with ragged groups (many shapes, two storage types, more matrices than one table holds, `none` rows on request) against
+    the same batches with the switch off (a launch chain per batch) and the oracle; knife_cap 1: more knife-edge tiles than the list holds
+    (the matrix-by-matrix second trip)."""
+    from quantization_analysis_amd.pipeline import ThresholdPipeline
+    from quantization_analysis_amd.settings import settings
+
+    shapes = [(70, 100), (32, 32), (96, 160), (33, 17), (64, 200)]
+    hosts = [gen("heavy_f32", 400 + i, shapes[i % len(shapes)]) for i in range(27)] + [gen("normal_bf16", 500 + i, shapes[i % len(shapes)]) for i in range(3)]
+    s4 = orc.threshold_scores(hosts[2], ALL, "pcc")["bfp4"]
+    thr = float(np.sort(s4)[len(s4) // 2])                                              # ON a tile's score: knife-edge tiles exist
+    batches = [dev(h, bf16=i >= 27)[None] for i, h in enumerate(hosts)]
+    runs = {}
+    for ragged in ("1", "0"):
+        monkeypatch.setenv("MTQ_THRESHOLD_RAGGED", ragged)
+        monkeypatch.setenv("MTQ_KNIFE_CAP", str(knife_cap))
+        settings(refresh=True)
+        with ThresholdPipeline(ALL, "pcc", thr, chunk=1, pure_formats=("bfp8", "bfp4")) as pipe:
+            runs[ragged] = pipe.run_batches(batches)
+            assert pipe.knife_tiles > 0
+    for i, (a, b) in enumerate(zip(runs["1"], runs["0"])):
+        r1, r2 = a[0], b[0]
+        assert np.array_equal(r1.assignment, r2.assignment) and r1.counts == r2.counts and (r1.pcc, r1.mae, r1.atol) == (r2.pcc, r2.mae, r2.atol), i
+        assert r1.pure == r2.pure and r1.index == 0
+        want, counts, _sc = orc.threshold(hosts[i], ALL, "pcc", thr)
+        assert np.array_equal(r1.assignment, want) and r1.counts == counts, i
+
+
 @pytest.mark.parametrize("scan", ["device", "host"])
 def test_streamed_pipeline_matches_oracle(scan):
     """GreedyPipeline (what bench.py times), with the scan on the device (csrc/mtq_scan.hip: maps come back, records stay) and
@@ -1070,7 +1155,8 @@ def test_lazy_pipeline_equals_whole_record_pipeline(monkeypatch):
 
 def test_pipeline_under_force_generic_switch():
     """MTQ_FORCE_GENERIC=1 (the A/B switch that sends every K1 through the literal kernel; read once per process by the library, hence a
-    subprocess): GreedyPipeline must not take the two-launch form the exact kernel's entry point refuses then — same maps as the oracle."""
+    subprocess): GreedyPipeline must not take the two-launch form the exact kernel's entry point refuses then — same maps as the oracle; and a
+    ragged batch goes through the literal kernel with its table — the records of the per-matrix calls."""
     import os
     import subprocess
     import sys
@@ -1087,6 +1173,11 @@ def test_pipeline_under_force_generic_switch():
         "for i, r in enumerate(res):\n"
         "    a, c, _ = orc.greedy(xs[i], ['bf16', 'bfp8', 'bfp4', 'bfp2'], 'pcc', 0.999, 123)\n"
         "    assert np.array_equal(r.assignment, a) and r.counts == c, i\n"
+        "from quantization_analysis_amd import hip_backend as hb\n"
+        "ms = [torch.from_numpy(gen('heavy_f32', 60 + i, sh)).cuda() for i, sh in enumerate([(70, 100), (32, 32), (64, 40)])]\n"
+        "got = hb.tile_stats_ragged(ms, 0xF).cpu().numpy().view(np.int64)\n"
+        "want = np.concatenate([hb.tile_stats(m, 0xF).cpu().numpy().view(np.int64) for m in ms])\n"
+        "assert np.array_equal(got, want)\n"
         "print('ok')\n")
     env = dict(os.environ, MTQ_FORCE_GENERIC="1")
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env, cwd=str(Path(__file__).resolve().parent.parent))
