@@ -396,6 +396,25 @@ __device__ inline bool pcc_good(double n, double mean_x, double am2, double thr,
 #define MTQ_SCAN_STAMP(slot) do { } while (0)
 #endif
 
+// The map, 64 tiles at a time in tile order, for the loops that sift it (candidates, the listed tiles, the final counts): f(t0, byte of
+// tile t0 + lane — 0x80, "fixed", past the end).  Eight blocks' bytes are in flight at once: one block per L2 round trip (≈ 750 cycles)
+// made each of these loops 670 k cycles on a 57 344-tile tensor — the two at the end of phase 1 and the two of phase 2 together more
+// than a pass's visits (round 4, found by adding up the shader-clock stamps: tools/scan_ticks.py).
+template <typename F>
+__device__ __forceinline__ void sift_map(const int8_t *map, int T, int lane, F &&f)
+{
+    for (int t00 = 0; t00 < T; t00 += 64 * 8) {
+        uint8_t b[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) b[u] = (uint8_t)ld_l2(map + min(t00 + 64 * u + lane, T - 1));   // unconditional (a branch per load would put each in a block of its own)
+#pragma unroll
+        for (int u = 0; u < 8; ++u) b[u] = t00 + 64 * u + lane < T ? b[u] : (uint8_t)0x80u;
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (t00 + 64 * u < T) f(t00 + 64 * u, b[u]);
+    }
+}
+
 struct Offsets3 { uint32_t y, y2, xy; };   // packed by format code, one byte each (rec <= 22): a per-lane code picks its offset with a shift
 
 // Deltas of every visit of a pass in visiting order (mixed_tile_greedy.py:259-261; mae :293): the candidate format's sums minus those of
@@ -629,7 +648,7 @@ __device__ inline int visit_pass(TileAt tile_at, const double *delta, int nc, in
 }
 
 template <bool kMae, typename Order>
-__device__ void scan_tensor(const ScanArgs &a, const Order &ord, int b, unsigned char *lds, int lane, int wave, bool two_waves)
+__device__ __forceinline__ void scan_tensor(const ScanArgs &a, const Order &ord, int b, unsigned char *lds, int lane, int wave, bool two_waves)
 {
     const int T = (int)a.tiles;
     const int rec = a.rec;
@@ -835,13 +854,12 @@ __device__ void scan_tensor(const ScanArgs &a, const Order &ord, int b, unsigned
             Pg = nullptr;
             // candidates = np.where(~fixed)[0] (:228): in tile order
             nc = 0;
-            for (int t0 = 0; t0 < T; t0 += 64) {
-                const int t = t0 + lane;
-                const bool cand = t < T && ((uint8_t)ld_l2(map + t) & 0x80u) == 0u;
+            sift_map(map, T, lane, [&](int t0, uint8_t code) {
+                const bool cand = (code & 0x80u) == 0u;
                 const uint64_t bm = __ballot(cand);
-                if (cand) ord.set((uint32_t)(nc + __builtin_popcountll(bm & below(lane))), (uint32_t)t);
+                if (cand) ord.set((uint32_t)(nc + __builtin_popcountll(bm & below(lane))), (uint32_t)(t0 + lane));
                 nc += __builtin_popcountll(bm);
-            }
+            });
             ord.sync();
             if (nc == 0) break;                                            // :229-230
             if (!wave_shuffle<true>(r, ord, nc, cnt, lane)) { status = 2; break; }   // order = rng.permutation(candidates), :231
@@ -861,21 +879,18 @@ __device__ void scan_tensor(const ScanArgs &a, const Order &ord, int b, unsigned
         // the last pass's candidates (:228) → the launch's list of tiles whose remaining statistics are evaluated now (mtq_tile_stats_listed)
         int nc = 0;
         if (status == 0 && !done) {
-            for (int t0 = 0; t0 < T; t0 += 64) {
-                const int t = t0 + lane;
-                nc += __builtin_popcountll(__ballot(t < T && ((uint8_t)ld_l2(map + t) & 0x80u) == 0u));
-            }
+            sift_map(map, T, lane, [&](int, uint8_t code) { nc += __builtin_popcountll(__ballot((code & 0x80u) == 0u)); });
             unsigned first = 0u;
             if (lane == 0 && nc > 0) first = atomicAdd(a.n_listed, (unsigned)nc);
             first = (unsigned)__builtin_amdgcn_readfirstlane((int)first);
             int at = 0;
-            for (int t0 = 0; t0 < T && nc > 0; t0 += 64) {
-                const int t = t0 + lane;
-                const bool cand = t < T && ((uint8_t)ld_l2(map + t) & 0x80u) == 0u;
-                const uint64_t bm = __ballot(cand);
-                if (cand) a.listed[first + (unsigned)(at + __builtin_popcountll(bm & below(lane)))] = (uint32_t)((int64_t)b * T + t);
-                at += __builtin_popcountll(bm);
-            }
+            if (nc > 0)
+                sift_map(map, T, lane, [&](int t0, uint8_t code) {
+                    const bool cand = (code & 0x80u) == 0u;
+                    const uint64_t bm = __ballot(cand);
+                    if (cand) a.listed[first + (unsigned)(at + __builtin_popcountll(bm & below(lane)))] = (uint32_t)((int64_t)b * T + t0 + lane);
+                    at += __builtin_popcountll(bm);
+                });
         }
         if (lane == 0) {
             Carry &c = a.carry[b];
@@ -887,13 +902,13 @@ __device__ void scan_tensor(const ScanArgs &a, const Order &ord, int b, unsigned
     }
 
     int per_fmt[MTQ_NUM_TILE_FORMATS] = {0, 0, 0, 0};
-    for (int t0 = 0; t0 < T; t0 += 64) {
+    sift_map(map, T, lane, [&](int t0, uint8_t raw) {
         const int t = t0 + lane;
         int code = -1;
-        if (t < T) { code = (int)((uint8_t)ld_l2(map + t) & 0x7Fu); map[t] = (int8_t)code; }
+        if (t < T) { code = (int)(raw & 0x7Fu); map[t] = (int8_t)code; }
 #pragma unroll
         for (int c = 0; c < MTQ_NUM_TILE_FORMATS; ++c) per_fmt[c] += __builtin_popcountll(__ballot(code == c));
-    }
+    });
     if (lane == 0) {
         a.status[b] = status;
         if (a.counts)

@@ -26,3 +26,5 @@ names = ["init sums", "base pass"] + [f"pass {p} {w}" for p in (1, 2) for w in (
 print(f"{T} tiles:", ", ".join(f"{n} {tk[i]/1e3:.0f}k" for i, n in enumerate(names)))
 r = max(int(tk[15]), 1)
 print(f"visit rounds {r}: per round window fetch {tk[8]/r:.0f}, staging + chains {tk[9]/r:.0f}, pcc {tk[10]/r:.0f}, decision + map {tk[11]/r:.0f} ticks")
+print(f"own shuffles (the last pass's): draws + acceptance {tk[12]/1e3:.0f}k, swaps {tk[13]/1e3:.0f}k, hand-back {tk[14]/1e3:.0f}k ticks; pass 3: order {tk[8]/1e3:.0f}k deltas {tk[9]/1e3:.0f}k visits {tk[10]/1e3:.0f}k"
+      " (slots 8-10 hold pass 3's stamps when the search has four formats: the per-round figures above are then meaningless)")
